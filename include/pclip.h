@@ -1,0 +1,174 @@
+/* pclip.h — C ABI of libpclip.so, the MI355X (gfx950) hot path of Proto-CLIP.
+ *
+ * The reference (IRVLUTD/Proto-CLIP) is pure Python and has no FFI of its own; each
+ * entry point below replaces the eager-PyTorch arithmetic of one reference function, cited as
+ * file:line relative to the reference tree.  The host layer (the Python modules under proto-clip_amd/) mirrors the
+ * reference's Python signatures and calls these through ctypes (binding shown in INTEGRATION.md).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (torch `data_ptr()`); fp16 buffers are
+ *    `const void*` (IEEE binary16, row-major, innermost dimension contiguous);
+ *  - work is enqueued on the hipStream_t passed as `stream` (void*; NULL = default stream); no entry
+ *    point synchronises, allocates or frees; scratch comes from the caller (`ws`, sized by
+ *    pclip_workspace_bytes) so every call is hipGraph-capturable and thread-safe per stream;
+ *  - return value: 0 = ok, <0 = error (PCLIP_E_*), text via pclip_last_error() (thread-local);
+ *  - no torch types, no C++ types, no exceptions cross this boundary.
+ */
+#ifndef PCLIP_H
+#define PCLIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCLIP_ABI_VERSION 1
+#define PCLIP_OK 0
+#define PCLIP_E_INVALID (-1)   /* bad shape / null pointer / unsupported size */
+#define PCLIP_E_LAUNCH (-2)    /* hipLaunch / hipGetLastError failure */
+#define PCLIP_E_WORKSPACE (-3) /* workspace too small */
+
+typedef void* pclip_stream_t;
+
+int pclip_abi_version(void);
+const char* pclip_last_error(void);
+/* number of compute units of the current device (used by host code to size batches) */
+int pclip_device_cus(void);
+
+/* ---- memory-bank / prototype reductions -------------------------------------------------- */
+
+/* In-place-capable row L2 normalise: y = r16(x / r16(||x||)).  utils.py:352, main.py:182-185,
+ * 408-409.  sq_out (nullable) receives the fp32 squared norm of the *output* row. */
+int pclip_l2norm_rows_f16(const void* x, void* y, int R, int D, float* sq_out, pclip_stream_t stream);
+
+/* fp32 squared norms of fp16 rows (the ||.||^2 terms torch.cdist adds, utils.py:230-233). */
+int pclip_row_sqnorm_f16(const void* x, int R, int D, float* sq_out, pclip_stream_t stream);
+
+/* Prototype reduction, main.py:399-402 (eval), 260-264 (train), 173-176 (zero-shot init):
+ * mem [N*K, D] fp16 (class c owns rows c*K..c*K+K-1) -> proto [N, D].
+ *   per_shot_norm=1: zs = r16(m / r16||m||) first (eval/train); 0: skip (zero-shot init).
+ *   proto_f16 (nullable): r16(z / r16||z||) with z = r16(mean_K zs)      — eval path
+ *   proto_f32 (nullable): fp32 z / ||z||  (no rounding)                     — train path
+ *   proto_sq  (nullable): fp32 ||proto_f16||^2 per class. */
+int pclip_proto_build_f16(const void* mem, int N, int K, int D, int per_shot_norm, void* proto_f16,
+                          float* proto_f32, float* proto_sq, pclip_stream_t stream);
+
+/* Visual-bank reduction, utils.py:318-326: feats [A, R, D] fp16 ->
+ * keys[j] = normalise(r16(mean_A feats[:, perm ? perm[j] : j, :])), row-major [R, D] fp16. */
+int pclip_bank_reduce_f16(const void* feats, int A, int R, int D, const int32_t* perm, void* keys,
+                          pclip_stream_t stream);
+
+/* fp16 matrix transpose x[R,C] -> y[C,R] (bank layout [D, N*K] <-> [N*K, D], utils.py:320). */
+int pclip_transpose_f16(const void* x, int R, int C, void* y, pclip_stream_t stream);
+
+/* Multi-GPU shard of the prototype mean: rows of this rank's support slab with
+ * NON-DECREASING int32 labels -> fp32 per-class sums of (optionally per-shot normalised) rows and
+ * int32 counts.  Classes absent from the slab get zero sums/counts.  Deterministic (no atomics). */
+int pclip_partial_sums_f16(const void* mem, const int32_t* labels, int R, int N, int D, int per_shot_norm,
+                           float* sums, int32_t* counts, pclip_stream_t stream);
+
+/* Combine W gathered slabs (sums [W,N,D], counts [W,N]) in rank order, then finish as
+ * pclip_proto_build_f16 does.  W=1 reproduces the single-GPU result. */
+int pclip_proto_finalize(const float* sums, const int32_t* counts, int W, int N, int D, void* proto_f16,
+                         float* proto_f32, float* proto_sq, pclip_stream_t stream);
+
+/* ---- classification: utils.py:225-244 `P` ------------------------------------------------ */
+
+/* Squared Euclidean distances against both prototype banks in one pass over the queries:
+ * d2x[q, n] = (sqrt(max(||q||^2 + ||z_n||^2 - 2 q.z_n, 0)))^2, fp32, leading dimension ldd >= N.
+ * q [Q,D], zi/zt [N,D] fp16; the dot products run on fp16-input / fp32-accumulate MFMA (exact
+ * products of the fp16 operands).  q_sq/zi_sq/zt_sq (nullable) are precomputed fp32
+ * squared norms; when NULL they are computed into `ws`.  zt may be NULL (single bank). */
+int pclip_sqdist_f16(const void* q, const void* zi, const void* zt, int Q, int N, int D,
+                     const float* q_sq, const float* zi_sq, const float* zt_sq,
+                     float* d2i, float* d2t, int ldd, void* ws, size_t ws_bytes, pclip_stream_t stream);
+
+/* p = alpha*softmax(-beta*d2i) + one_minus_alpha*softmax(-beta*d2t) over classes (max-subtracted,
+ * fp32).  Outputs (each nullable): p [Q, N] dense; argmax [Q] (lowest index among ties,
+ * main.py:190); top-k probabilities/indices [Q, k] sorted descending (toolkit
+ * proto_clip_classifier.py:146-147), k <= 16. */
+int pclip_fuse_probs(const float* d2i, const float* d2t, int Q, int N, int ldd, float alpha,
+                     float one_minus_alpha, float beta, float* p, int32_t* argmax, float* topk_p,
+                     int32_t* topk_i, int k, pclip_stream_t stream);
+
+/* Convenience: pclip_sqdist_f16 + pclip_fuse_probs with the distance rows held in `ws`. */
+int pclip_classify_f16(const void* q, const void* zi, const void* zt, int Q, int N, int D,
+                       const float* q_sq, const float* zi_sq, const float* zt_sq, float alpha,
+                       float one_minus_alpha, float beta, float* p, int32_t* argmax, float* topk_p,
+                       int32_t* topk_i, int k, void* ws, size_t ws_bytes, pclip_stream_t stream);
+
+/* (alpha, beta) grid, main.py:142-146, 187-199, 419-430: from the two distance matrices evaluate all
+ * na*nb pairs and accumulate correct[ia*nb + ib] += #{q : argmax_n p == labels[q]} (int32, the
+ * caller zeroes it; lowest-index tie rule).  Replaces 3*na*nb `P` calls + host syncs. */
+int pclip_hp_sweep(const float* d2i, const float* d2t, const int32_t* labels, int Q, int N, int ldd,
+                   const float* alphas, const float* one_minus_alphas, int na, const float* betas,
+                   int nb, int32_t* correct, pclip_stream_t stream);
+
+/* ---- query adapters: model.py:12-95 ------------------------------------------------------ */
+
+/* Adapter_FC.forward (model.py:81-95): y = r16(r16(ratio*LN_D(W2 LN_{D/r}(W1 x))) + r16((1-ratio)*x)).
+ * x [B,D]; w1 [H,D]; g1,b1 [H]; w2 [D,H]; g2,b2 [D]; all fp16.  l2norm_out=1 also applies the
+ * following row normalise (main.py:408-409).  y_sq nullable (fp32 ||y||^2). */
+int pclip_adapter_fc_f16(const void* x, int B, int D, int H, const void* w1, const void* g1, const void* b1,
+                         const void* w2, const void* g2, const void* b2, float ratio, float one_minus_ratio,
+                         int l2norm_out, void* y, float* y_sq, void* ws, size_t ws_bytes,
+                         pclip_stream_t stream);
+
+/* Adapter.forward (model.py:49-78), width 16: pad D -> s*s, conv1 1x1 -> LN[16,s,s] ->
+ * (three_x: conv2 3x3 pad 1 -> LN[16,s,s]) -> conv3 1x1 -> LN[1,s,s] -> +identity -> crop.  No ReLU.
+ * conv1 [16], ln1w/ln1b [16*s*s], conv2 [16*16*3*3], ln2w/ln2b [16*s*s], conv3 [16], ln3w/ln3b [s*s]. */
+int pclip_adapter_conv_f16(const void* x, int B, int D, int three_x, const void* conv1, const void* ln1w,
+                           const void* ln1b, const void* conv2, const void* ln2w, const void* ln2b,
+                           const void* conv3, const void* ln3w, const void* ln3b, int l2norm_out, void* y,
+                           float* y_sq, pclip_stream_t stream);
+
+/* ---- CLIP encoder building blocks: clip/model.py:155-238, 338-354 ------------------------- */
+
+/* C[M,N] = epilogue(A[M,K] . B[N,K]^T): fp16 operands, fp32-accumulate MFMA, fp16 output.
+ *   bias (nullable, fp16 [N]) is added before rounding (nn.Linear, clip/model.py:176-178);
+ *   act: 0 none, 1 QuickGELU x*sigmoid(1.702x) (clip/model.py:164-166) with per-op fp16 rounding;
+ *   residual (nullable, fp16 [M,N], ldc): out = r16(residual + r16(...)) (clip/model.py:188-189).
+ * lda/ldb/ldc in elements.  K % 32 == 0 required. */
+int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                   const void* bias, int act, const void* residual, pclip_stream_t stream);
+
+/* LayerNorm over the last dim with fp32 statistics and fp32 affine parameters, fp16 in/out
+ * (clip/model.py:155-161).  x rows are ld_x elements apart (lets ln_post read only the CLS rows). */
+int pclip_layernorm_f16(const void* x, int ld_x, const float* gamma, const float* beta, float eps, void* y,
+                        int R, int D, pclip_stream_t stream);
+
+/* Multi-head self-attention core on a fused QKV buffer (nn.MultiheadAttention inside
+ * ResidualAttentionBlock.attention, clip/model.py:183-185): qkv [B, L, 3*H*dh] fp16 (q|k|v blocks,
+ * heads contiguous inside each) -> out [B, L, H*dh] fp16 = softmax(q k^T / sqrt(dh) [+causal]) v.
+ * dh must be 64; L <= 272. */
+int pclip_attention_f16(const void* qkv, void* out, int B, int L, int H, int dh, int causal,
+                        pclip_stream_t stream);
+
+/* ViT stem (clip/model.py:222-227): patch-conv as an im2col gather of [B,3,R,R] fp16 images into
+ * [B*G*G, ld >= 3*P*P] rows, zero beyond 3*P*P (the GEMM against conv1.weight follows), and the token assembly
+ * x = [class_emb ; patches] + pos -> fp16 [B, 1+G*G, W]. */
+int pclip_im2col_patches_f16(const void* img, int B, int R, int P, void* cols, int ld, pclip_stream_t stream);
+int pclip_vit_assemble_tokens_f16(const void* patch_emb, const void* class_emb, const void* pos_emb, int B,
+                                  int G2, int W, void* tokens, pclip_stream_t stream);
+
+/* Text stem (clip/model.py:342-344): x = token_embedding[text] + positional_embedding, fp16. */
+int pclip_text_embed_f16(const int64_t* tokens, const void* tok_emb, const void* pos_emb, int B, int L, int W,
+                         int vocab, void* x, pclip_stream_t stream);
+/* Row gather x[b, idx[b], :] (EOT token, clip/model.py:352) ; idx computed by argmax over tokens. */
+int pclip_gather_eot_f16(const void* x, const int64_t* tokens, int B, int L, int W, void* out,
+                         pclip_stream_t stream);
+
+/* fp32 -> fp16 cast (image.type(self.dtype), clip/model.py:339). */
+int pclip_cast_f32_f16(const float* x, void* y, size_t n, pclip_stream_t stream);
+
+/* ---- workspace sizing -------------------------------------------------------------------- */
+#define PCLIP_OP_SQDIST 1
+#define PCLIP_OP_CLASSIFY 2
+#define PCLIP_OP_ADAPTER_FC 3
+size_t pclip_workspace_bytes(int op, int Q, int N, int D);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCLIP_H */

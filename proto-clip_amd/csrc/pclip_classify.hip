@@ -1,0 +1,286 @@
+// Classification against the two prototype banks: utils.py:225-244 `P`, the argmax/top-k consumers
+// (main.py:190, toolkit proto_clip_classifier.py:146-147) and the (alpha, beta) grid (main.py:187-199,
+// 419-430).  Split in two stages so that the distance rows — which do not depend on alpha/beta
+//  — are produced once by the MFMA contraction and then consumed by cheap VALU passes.
+#include "pclip_gemm.h"
+
+namespace {
+
+// ---- stage 1: squared distances on MFMA ---------------------------------------------------------
+// torch.cdist (mm path) evaluates ||q||^2 + ||z||^2 - 2 q.z in fp32, clamps at 0, takes sqrt; the
+// reference then squares it again (utils.py:230-233).  fp16 operands make every product exact in the
+// fp32 accumulator, so only summation order differs from the reference's fp32 GEMM.
+struct SqdistEpi {
+    const float* __restrict__ q_sq;
+    const float* __restrict__ z_sq;
+    float* __restrict__ out;
+    int ldd;
+    __device__ __forceinline__ void operator()(int row, int col, float dot) const {
+        float v = __fadd_rn(__fadd_rn(-2.f * dot, q_sq[row]), z_sq[col]);
+        float d = sqrtf(fmaxf(v, 0.f));
+        out[(size_t)row * ldd + col] = __fmul_rn(d, d);
+    }
+};
+
+__global__ __launch_bounds__(256, 2) void sqdist_kernel(const half_t* __restrict__ q, const half_t* __restrict__ zi,
+                                                        const half_t* __restrict__ zt, int Q, int N, int D,
+                                                        const float* __restrict__ q_sq, const float* __restrict__ zi_sq,
+                                                        const float* __restrict__ zt_sq, float* __restrict__ d2i,
+                                                        float* __restrict__ d2t, int ldd, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bank = blockIdx.y;
+    const int swz = pgemm::xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = swz / tiles_n, tile_n = swz - tile_m * tiles_n;
+    SqdistEpi epi{q_sq, bank ? zt_sq : zi_sq, bank ? d2t : d2i, ldd};
+    pgemm::gemm_tile(q, D, bank ? zt : zi, D, Q, N, D, tile_m, tile_n, smem, epi);
+}
+
+// ---- stage 2: softmax fusion, one wave per query row ----------------------------------------------
+// Lane l owns classes n = i*64 + l (scalar mapping) — coalesced 256-byte row segments.
+template <int NV>
+__device__ __forceinline__ void load_row(const float* __restrict__ row, int N, int lane, float (&v)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int n = i * 64 + lane;
+        v[i] = n < N ? row[n] : 0.f;
+    }
+}
+
+// e[i] = exp(beta*(-d_i) - max_n beta*(-d_n)) for valid classes (0 for padding); returns the wave-wide
+// sum.  Rounding is monotone, so the max is beta*(-dmin) for beta >= 0 and beta*(-dmax) otherwise.
+template <int NV>
+__device__ __forceinline__ float softmax_terms(const float (&d)[NV], float beta, float dmin, float dmax, int N,
+                                               int lane, float (&e)[NV]) {
+    const float mx = __fmul_rn(beta, beta >= 0.f ? -dmin : -dmax);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        e[i] = (i * 64 + lane < N) ? expf(__fsub_rn(__fmul_rn(beta, -d[i]), mx)) : 0.f;
+        s += e[i];
+    }
+    return wave_sum(s);
+}
+
+// (min, max) over the valid classes of a row
+template <int NV>
+__device__ __forceinline__ void row_minmax(const float (&d)[NV], int N, int lane, float& mn, float& mx) {
+    mn = __builtin_inff(); mx = -__builtin_inff();
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (i * 64 + lane < N) { mn = fminf(mn, d[i]); mx = fmaxf(mx, d[i]); }
+    mn = wave_min(mn); mx = wave_max(mx);
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void fuse_probs_kernel(const float* __restrict__ d2i, const float* __restrict__ d2t,
+                                                         int Q, int N, int ldd, float alpha, float oma, float beta,
+                                                         float* __restrict__ p, int32_t* __restrict__ argmax,
+                                                         float* __restrict__ topk_p, int32_t* __restrict__ topk_i,
+                                                         int k) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * 4 + wave; row < Q; row += gridDim.x * 4) {
+        float di[NV], dt[NV], ei[NV], et[NV];
+        float mn, mx;
+        load_row<NV>(d2i + (size_t)row * ldd, N, lane, di);
+        row_minmax<NV>(di, N, lane, mn, mx);
+        const float li = softmax_terms<NV>(di, beta, mn, mx, N, lane, ei);
+        float lt = 1.f;
+        if (d2t) {
+            load_row<NV>(d2t + (size_t)row * ldd, N, lane, dt);
+            row_minmax<NV>(dt, N, lane, mn, mx);
+            lt = softmax_terms<NV>(dt, beta, mn, mx, N, lane, et);
+        }
+        float best = -1.f;
+        int besti = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int n = i * 64 + lane;
+            float pv = __fmul_rn(alpha, __fdiv_rn(ei[i], li));
+            if (d2t) pv = __fadd_rn(pv, __fmul_rn(oma, __fdiv_rn(et[i], lt)));
+            ei[i] = pv;   // reuse as p
+            if (n < N) {
+                if (p) p[(size_t)row * N + n] = pv;
+                if (pv > best) { best = pv; besti = n; }   // ascending n: first max kept
+            } else {
+                ei[i] = -1.f;
+            }
+        }
+        if (argmax) {
+            float bv = best; int bi = besti;
+            wave_argmax(bv, bi);
+            if (lane == 0) argmax[row] = bi;
+        }
+        if (topk_p || topk_i) {
+            for (int t = 0; t < k; ++t) {
+                float bv = -2.f; int bi = 0x7fffffff;
+#pragma unroll
+                for (int i = 0; i < NV; ++i)
+                    if (ei[i] > bv) { bv = ei[i]; bi = i * 64 + lane; }
+                wave_argmax(bv, bi);
+                if (lane == 0) {
+                    if (topk_p) topk_p[(size_t)row * k + t] = bv;
+                    if (topk_i) topk_i[(size_t)row * k + t] = bi;
+                }
+#pragma unroll
+                for (int i = 0; i < NV; ++i)
+                    if (i * 64 + lane == bi) ei[i] = -2.f;   // remove the winner
+            }
+        }
+    }
+}
+
+// (alpha, beta) grid: distances are loaded once per row; per beta the two softmaxes are formed once and
+// every alpha only costs a fused multiply/add + argmax.  Correct-counts are accumulated in LDS and
+// flushed with one atomic per (pair, workgroup).
+template <int NV>
+__global__ __launch_bounds__(256) void hp_sweep_kernel(const float* __restrict__ d2i, const float* __restrict__ d2t,
+                                                       const int32_t* __restrict__ labels, int Q, int N, int ldd,
+                                                       const float* __restrict__ alphas, const float* __restrict__ omas,
+                                                       int na, const float* __restrict__ betas, int nb,
+                                                       int32_t* __restrict__ correct) {
+    extern __shared__ int32_t cnt[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < na * nb; i += 256) cnt[i] = 0;
+    __syncthreads();
+    for (int row = blockIdx.x * 4 + wave; row < Q; row += gridDim.x * 4) {
+        float di[NV], dt[NV], ei[NV], et[NV];
+        load_row<NV>(d2i + (size_t)row * ldd, N, lane, di);
+        load_row<NV>(d2t + (size_t)row * ldd, N, lane, dt);
+        float mni, mxi, mnt, mxt;
+        row_minmax<NV>(di, N, lane, mni, mxi);
+        row_minmax<NV>(dt, N, lane, mnt, mxt);
+        const int label = labels[row];
+        for (int ib = 0; ib < nb; ++ib) {
+            const float beta = betas[ib];
+            const float li = softmax_terms<NV>(di, beta, mni, mxi, N, lane, ei);
+            const float lt = softmax_terms<NV>(dt, beta, mnt, mxt, N, lane, et);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                ei[i] = __fdiv_rn(ei[i], li);
+                et[i] = __fdiv_rn(et[i], lt);
+            }
+            for (int ia = 0; ia < na; ++ia) {
+                const float a = alphas[ia], oma = omas[ia];
+                float best = -1.f; int besti = 0x7fffffff;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int n = i * 64 + lane;
+                    const float pv = __fadd_rn(__fmul_rn(a, ei[i]), __fmul_rn(oma, et[i]));
+                    if (n < N && pv > best) { best = pv; besti = n; }
+                }
+                wave_argmax(best, besti);
+                if (lane == 0 && besti == label) atomicAdd(&cnt[ia * nb + ib], 1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < na * nb; i += 256)
+        if (cnt[i]) atomicAdd(&correct[i], cnt[i]);
+}
+
+inline int row_grid(int R, int cap) { int g = ceil_div(R, 4); return g < 1 ? 1 : (g > cap ? cap : g); }
+
+struct SqWs { float *q_sq, *zi_sq, *zt_sq; size_t bytes; };
+inline SqWs carve_sq(void* ws, int Q, int N) {
+    SqWs w;
+    char* b = (char*)ws;
+    size_t o = 0;
+    w.q_sq = (float*)(b + o); o += align_up((size_t)Q * 4, 256);
+    w.zi_sq = (float*)(b + o); o += align_up((size_t)N * 4, 256);
+    w.zt_sq = (float*)(b + o); o += align_up((size_t)N * 4, 256);
+    w.bytes = o;
+    return w;
+}
+inline int padded_ld(int N) { return (N + 63) / 64 * 64; }
+
+}  // namespace
+
+#define DISPATCH_NV(N, CALL)                                   \
+    do {                                                       \
+        if ((N) <= 64) { constexpr int NV = 1; CALL; }         \
+        else if ((N) <= 256) { constexpr int NV = 4; CALL; }   \
+        else if ((N) <= 1024) { constexpr int NV = 16; CALL; } \
+        else { constexpr int NV = 64; CALL; }                  \
+    } while (0)
+
+extern "C" size_t pclip_workspace_bytes(int op, int Q, int N, int D) {
+    (void)D;
+    if (Q < 0 || N < 0) return 0;
+    size_t sq = carve_sq(nullptr, Q, N).bytes;
+    switch (op) {
+        case PCLIP_OP_SQDIST: return sq;
+        case PCLIP_OP_CLASSIFY: return sq + 2 * align_up((size_t)Q * padded_ld(N) * 4, 256);
+        case PCLIP_OP_ADAPTER_FC: {
+            // h1 [Q, D/4] fp16, h1n [Q, D/4] fp16, h2 [Q, D] fp16  (N is the hidden width here)
+            return 2 * align_up((size_t)Q * N * 2, 256) + align_up((size_t)Q * D * 2, 256);
+        }
+        default: return 0;
+    }
+}
+
+extern "C" int pclip_sqdist_f16(const void* q, const void* zi, const void* zt, int Q, int N, int D,
+                                const float* q_sq, const float* zi_sq, const float* zt_sq, float* d2i, float* d2t,
+                                int ldd, void* ws, size_t ws_bytes, pclip_stream_t stream) {
+    PCLIP_REQUIRE(q && zi && d2i, "pclip_sqdist_f16: null pointer");
+    PCLIP_REQUIRE(!zt || d2t, "pclip_sqdist_f16: zt given without d2t");
+    PCLIP_REQUIRE(Q >= 0 && N > 0 && ldd >= N, "pclip_sqdist_f16: bad Q=%d N=%d ldd=%d", Q, N, ldd);
+    PCLIP_REQUIRE(D > 0 && D % 64 == 0 && D <= 4096, "pclip_sqdist_f16: D=%d must be a multiple of 64, <= 4096", D);
+    if (Q == 0) return PCLIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (!q_sq || !zi_sq || (zt && !zt_sq)) {
+        SqWs w = carve_sq(ws, Q, N);
+        PCLIP_REQUIRE(ws != nullptr, "pclip_sqdist_f16: workspace required when norms are not supplied");
+        if (ws_bytes < w.bytes) { pclip_set_error("pclip_sqdist_f16: workspace %zu < %zu", ws_bytes, w.bytes); return PCLIP_E_WORKSPACE; }
+        int e;
+        if (!q_sq) { if ((e = pclip_row_sqnorm_f16(q, Q, D, w.q_sq, stream))) return e; q_sq = w.q_sq; }
+        if (!zi_sq) { if ((e = pclip_row_sqnorm_f16(zi, N, D, w.zi_sq, stream))) return e; zi_sq = w.zi_sq; }
+        if (zt && !zt_sq) { if ((e = pclip_row_sqnorm_f16(zt, N, D, w.zt_sq, stream))) return e; zt_sq = w.zt_sq; }
+    }
+    const int tiles_m = ceil_div(Q, pgemm::BM), tiles_n = ceil_div(N, pgemm::BN);
+    dim3 grid(tiles_m * tiles_n, zt ? 2 : 1);
+    sqdist_kernel<<<grid, 256, pgemm::LDS_BYTES, s>>>((const half_t*)q, (const half_t*)zi, (const half_t*)zt, Q, N, D,
+                                                      q_sq, zi_sq, zt_sq, d2i, d2t, ldd, tiles_n);
+    return pclip_check_launch("sqdist");
+}
+
+extern "C" int pclip_fuse_probs(const float* d2i, const float* d2t, int Q, int N, int ldd, float alpha,
+                                float one_minus_alpha, float beta, float* p, int32_t* argmax, float* topk_p,
+                                int32_t* topk_i, int k, pclip_stream_t stream) {
+    PCLIP_REQUIRE(d2i, "pclip_fuse_probs: null distances");
+    PCLIP_REQUIRE(Q >= 0 && N > 0 && N <= 4096 && ldd >= N, "pclip_fuse_probs: bad Q=%d N=%d (<=4096) ldd=%d", Q, N, ldd);
+    PCLIP_REQUIRE(k >= 0 && k <= 16 && k <= N, "pclip_fuse_probs: k=%d must be in [0, min(16, N)]", k);
+    PCLIP_REQUIRE((!topk_p && !topk_i) || k > 0, "pclip_fuse_probs: top-k output without k");
+    if (Q == 0) return PCLIP_OK;
+    DISPATCH_NV(N, (fuse_probs_kernel<NV><<<row_grid(Q, 16384), 256, 0, (hipStream_t)stream>>>(
+                       d2i, d2t, Q, N, ldd, alpha, one_minus_alpha, beta, p, argmax, topk_p, topk_i, k)));
+    return pclip_check_launch("fuse_probs");
+}
+
+extern "C" int pclip_classify_f16(const void* q, const void* zi, const void* zt, int Q, int N, int D,
+                                  const float* q_sq, const float* zi_sq, const float* zt_sq, float alpha,
+                                  float one_minus_alpha, float beta, float* p, int32_t* argmax, float* topk_p,
+                                  int32_t* topk_i, int k, void* ws, size_t ws_bytes, pclip_stream_t stream) {
+    PCLIP_REQUIRE(ws != nullptr, "pclip_classify_f16: workspace required");
+    const size_t need = pclip_workspace_bytes(PCLIP_OP_CLASSIFY, Q, N, D);
+    if (ws_bytes < need) { pclip_set_error("pclip_classify_f16: workspace %zu < %zu", ws_bytes, need); return PCLIP_E_WORKSPACE; }
+    if (Q == 0) return PCLIP_OK;
+    SqWs w = carve_sq(ws, Q, N);
+    const int ldd = padded_ld(N);
+    float* d2i = (float*)((char*)ws + w.bytes);
+    float* d2t = zt ? (float*)((char*)d2i + align_up((size_t)Q * ldd * 4, 256)) : nullptr;
+    int e = pclip_sqdist_f16(q, zi, zt, Q, N, D, q_sq, zi_sq, zt_sq, d2i, d2t, ldd, ws, w.bytes, stream);
+    if (e) return e;
+    return pclip_fuse_probs(d2i, d2t, Q, N, ldd, alpha, one_minus_alpha, beta, p, argmax, topk_p, topk_i, k, stream);
+}
+
+extern "C" int pclip_hp_sweep(const float* d2i, const float* d2t, const int32_t* labels, int Q, int N, int ldd,
+                              const float* alphas, const float* one_minus_alphas, int na, const float* betas, int nb,
+                              int32_t* correct, pclip_stream_t stream) {
+    PCLIP_REQUIRE(d2i && d2t && labels && alphas && one_minus_alphas && betas && correct, "pclip_hp_sweep: null pointer");
+    PCLIP_REQUIRE(Q >= 0 && N > 0 && N <= 4096 && ldd >= N, "pclip_hp_sweep: bad Q=%d N=%d (<=4096) ldd=%d", Q, N, ldd);
+    PCLIP_REQUIRE(na > 0 && nb > 0 && na * nb <= 8192, "pclip_hp_sweep: bad grid %d x %d", na, nb);
+    if (Q == 0) return PCLIP_OK;
+    DISPATCH_NV(N, (hp_sweep_kernel<NV><<<row_grid(Q, 4096), 256, (size_t)na * nb * 4, (hipStream_t)stream>>>(
+                       d2i, d2t, labels, Q, N, ldd, alphas, one_minus_alphas, na, betas, nb, correct)));
+    return pclip_check_launch("hp_sweep");
+}

@@ -1,0 +1,61 @@
+// Shared device/host helpers for libpclip (gfx950 only: wave64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/pclip.h"
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+
+#define WAVE 64
+
+// ---- error plumbing (host) -------------------------------------------------------------------
+void pclip_set_error(const char* fmt, ...);
+int pclip_check_launch(const char* what);
+#define PCLIP_REQUIRE(cond, ...)              \
+    do {                                      \
+        if (!(cond)) {                        \
+            pclip_set_error(__VA_ARGS__);     \
+            return PCLIP_E_INVALID;           \
+        }                                     \
+    } while (0)
+
+// ---- device helpers ----------------------------------------------------------------------------
+// round fp32 -> fp16 -> fp32 (the r16() of SURVEY Appendix A; RNE like torch's .half())
+__device__ __forceinline__ float r16(float x) { return (float)(half_t)x; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, WAVE));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, WAVE));
+    return v;
+}
+// (value, index) argmax with lowest-index tie rule (torch CPU max, main.py:190)
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        float ov = __shfl_xor(v, off, WAVE);
+        int oi = __shfl_xor(i, off, WAVE);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+
+__device__ __forceinline__ half8_t ld_half8(const half_t* p) { return *reinterpret_cast<const half8_t*>(p); }
+__device__ __forceinline__ void st_half8(half_t* p, half8_t v) { *reinterpret_cast<half8_t*>(p) = v; }
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

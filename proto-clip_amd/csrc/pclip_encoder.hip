@@ -1,0 +1,445 @@
+// CLIP encoder building blocks: the fp16 transformer towers of
+// clip/model.py:169-238 and 341-354 as hand-written gfx950 kernels — MFMA linear layers with fused
+// bias / QuickGELU / residual epilogues, fp32-statistics LayerNorm, and a whole-sequence attention
+// kernel (the CLIP sequences, 50..257 tokens, fit one workgroup, so no online softmax is needed).
+#include "pclip_gemm.h"
+
+namespace {
+
+// ---- nn.Linear on MFMA ------------------------------------------------------------------------
+// Rounding points follow the reference's fp16 tensors: r16(acc + bias); QuickGELU as three fp16
+// elementwise ops (clip/model.py:166); residual add rounds once more (clip/model.py:188-189).
+struct LinearEpi {
+    const half_t* __restrict__ bias;
+    const half_t* __restrict__ residual;
+    half_t* __restrict__ C;
+    int ldc;
+    int act;
+    __device__ __forceinline__ void operator()(int row, int col, float acc) const {
+        float v = acc;
+        if (bias) v += (float)bias[col];
+        v = r16(v);
+        if (act == 1) {
+            const float t = r16(1.702f * v);
+            const float s = r16(1.f / (1.f + expf(-t)));
+            v = r16(v * s);
+        }
+        const size_t o = (size_t)row * ldc + col;
+        if (residual) v = (float)residual[o] + v;
+        C[o] = (half_t)v;
+    }
+};
+
+__global__ __launch_bounds__(256, 2) void linear_kernel(const half_t* __restrict__ A, int lda,
+                                                        const half_t* __restrict__ B, int ldb, int M, int N, int K,
+                                                        LinearEpi epi, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int swz = pgemm::xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = swz / tiles_n, tile_n = swz - tile_m * tiles_n;
+    pgemm::gemm_tile(A, lda, B, ldb, M, N, K, tile_m, tile_n, smem, epi);
+}
+
+// ---- LayerNorm, one wave per row ----------------------------------------------------------------
+// MODE 0: y = r16(LN(x))                                   (clip/model.py:155-161, model.py:86,88)
+// MODE 1: y = r16(r16(ratio*r16(LN(x))) + r16(omr*res))    (Adapter_FC blend, model.py:92-95)
+//         followed, if l2norm, by the row normalise of main.py:408-409.
+template <int NCH, typename PT, int MODE>
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, int ld_x,
+                                                        const PT* __restrict__ gamma, const PT* __restrict__ beta,
+                                                        float eps, half_t* __restrict__ y, int R, int D,
+                                                        const half_t* __restrict__ res, float ratio, float omr,
+                                                        int l2norm, float* __restrict__ sq_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
+        const half_t* xr = x + (size_t)row * ld_x;
+        float v[NCH][8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int d = c * 512 + lane * 8;
+            if (d < D) {
+                half8_t h = ld_half8(xr + d);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { v[c][j] = (float)h[j]; s += v[c][j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+            }
+        }
+        const float mean = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int d = c * 512 + lane * 8;
+            if (d < D) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float t = v[c][j] - mean; q += t * t; }
+            }
+        }
+        const float rstd = 1.f / sqrtf(wave_sum(q) / (float)D + eps);
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int d = c * 512 + lane * 8;
+            if (d < D) {
+                half8_t rh;
+                if (MODE == 1) rh = ld_half8(res + (size_t)row * D + d);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float o = (v[c][j] - mean) * rstd * (float)gamma[d + j] + (float)beta[d + j];
+                    o = r16(o);
+                    if (MODE == 1) o = r16(r16(ratio * o) + r16(omr * (float)rh[j]));
+                    v[c][j] = o;
+                    ss += o * o;
+                }
+            }
+        }
+        float n = 1.f;
+        if (MODE == 1 && l2norm) {
+            n = r16(sqrtf(wave_sum(ss)));
+            ss = 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int d = c * 512 + lane * 8;
+            if (d < D) {
+                half8_t o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    o[j] = (MODE == 1 && l2norm) ? (half_t)(v[c][j] / n) : (half_t)v[c][j];
+                    const float f = (float)o[j];
+                    if (MODE == 1 && l2norm) ss += f * f;
+                }
+                st_half8(y + (size_t)row * D + d, o);
+            }
+        }
+        if (MODE == 1 && sq_out) {
+            ss = wave_sum(ss);
+            if (lane == 0) sq_out[row] = ss;
+        }
+    }
+}
+
+// ---- attention: one workgroup per (image, head), whole sequence resident in LDS -------------------
+// S^T = K Q^T is computed (operands swapped) so that a lane owns ONE query row: its 16 accumulator
+// registers per 32-key tile are 16 different keys, the softmax max/sum are in-lane reductions plus one
+// cross-half shuffle, and the fp16 probabilities are already laid out as the A operand of the P.V MFMA
+// (k-order permuted identically for P and V, which a contraction does not care about).
+constexpr int ATT_DH = 64;
+constexpr int ATT_MAX_TILES = 9;   // L <= 288
+
+template <int NT>   // NT = ceil(L / 32) key tiles
+__global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
+                                                        int L, int H, int causal) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LP = NT * 32;
+    constexpr int LV = (LP / 4) % 2 ? LP : LP + 4;            // Vt row stride (halves): (LV/4) odd -> no ds_read_b64 conflicts
+    half_t* Ks = reinterpret_cast<half_t*>(smem);             // [LP][64], 16-byte chunks XOR-swizzled by (row & 7)
+    half_t* Vt = Ks + LP * ATT_DH;                            // [64][LV]
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int W = H * ATT_DH;
+    const half_t* base = qkv + (size_t)b * L * 3 * W + h * ATT_DH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // stage K (swizzled rows) and V (transposed); rows >= L are zero so padded keys contribute nothing
+    for (int i = tid; i < LP * 8; i += 256) {
+        const int r = i >> 3, c = i & 7;
+        half8_t kv, vv;
+        if (r < L) {
+            kv = ld_half8(base + (size_t)r * 3 * W + W + c * 8);
+            vv = ld_half8(base + (size_t)r * 3 * W + 2 * W + c * 8);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { kv[j] = (half_t)0.f; vv[j] = (half_t)0.f; }
+        }
+        *reinterpret_cast<half8_t*>(Ks + r * ATT_DH + ((c ^ (r & 7)) << 3)) = kv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * LV + r] = vv[j];
+    }
+    __syncthreads();
+
+    const int hi = lane >> 5, ql = lane & 31;
+    for (int qb = wave; qb < NT; qb += 4) {
+        const int q = qb * 32 + ql;                     // this lane's query row
+        const int qc = q < L ? q : L - 1;
+        half8_t qf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = ld_half8(base + (size_t)qc * 3 * W + s * 16 + hi * 8);
+
+        float16_t st[NT];
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) st[t][e] = 0.f;
+            const int kr = t * 32 + ql;                 // key row this lane feeds as A operand
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                half8_t kf = *reinterpret_cast<const half8_t*>(Ks + kr * ATT_DH + (((s * 2 + hi) ^ (kr & 7)) << 3));
+                st[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                const bool ok = k < L && (!causal || k <= q);
+                st[t][e] = ok ? st[t][e] * 0.125f : -__builtin_inff();   // 1/sqrt(64), exact
+                mx = fmaxf(mx, st[t][e]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { st[t][e] = expf(st[t][e] - mx); sum += st[t][e]; }
+        sum += __shfl_xor(sum, 32, WAVE);
+        const float inv = 1.f / sum;
+
+        float16_t o[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[j][e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                half8_t pf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[e] = (half_t)(st[t][s * 8 + e] * inv);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    // V^T fragment: column d = j*32 + ql, keys t*32 + 16s + 4hi + {0..3} and +8
+                    const half_t* vp = Vt + (j * 32 + ql) * LV + t * 32 + s * 16 + hi * 4;
+                    half4_t v0 = *reinterpret_cast<const half4_t*>(vp);
+                    half4_t v1 = *reinterpret_cast<const half4_t*>(vp + 8);
+                    half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf, vf, o[j], 0, 0, 0);
+                }
+            }
+        // O tile: col d = j*32 + (lane & 31), row q = qb*32 + (e&3) + 8*(e>>2) + 4*hi
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int qr = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                if (qr < L) out[((size_t)b * L + qr) * W + h * ATT_DH + j * 32 + ql] = (half_t)o[j][e];
+            }
+    }
+}
+
+// ---- ViT / text stems ------------------------------------------------------------------------------
+// conv1 (kernel = stride = P, no bias) == GEMM of im2col rows [B*G*G, ld >= 3*P*P] against weight
+// [W, 3*P*P]; columns >= 3*P*P are zero (K padded to the GEMM's BK for ViT-L/14, 3*14*14 = 588 -> 640).
+template <bool VEC>
+__global__ __launch_bounds__(256) void im2col_kernel(const half_t* __restrict__ img, int B, int R, int P, int G,
+                                                     int ld, half_t* __restrict__ cols) {
+    const int KP = 3 * P * P;
+    constexpr int V = VEC ? 8 : 1;
+    const int ldv = ld / V;
+    const size_t total = (size_t)B * G * G * ldv;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int k = (int)(i % ldv) * V;
+        const size_t pr = i / ldv;
+        half_t* dst = cols + pr * ld + k;
+        if (k >= KP) {
+            if (VEC) { half8_t z; for (int j = 0; j < 8; ++j) z[j] = (half_t)0.f; st_half8(dst, z); }
+            else *dst = (half_t)0.f;
+            continue;
+        }
+        const int gx = (int)(pr % G), gy = (int)((pr / G) % G), bb = (int)(pr / ((size_t)G * G));
+        const int c = k / (P * P), py = (k / P) % P, px = k % P;
+        const half_t* src = img + (((size_t)bb * 3 + c) * R + gy * P + py) * R + gx * P + px;
+        if (VEC) st_half8(dst, ld_half8(src)); else *dst = *src;
+    }
+}
+
+// tokens[b, 0] = r16(class + pos[0]); tokens[b, 1+g] = r16(patch[b, g] + pos[1+g])   (clip/model.py:225-226)
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const half_t* __restrict__ patch,
+                                                              const half_t* __restrict__ cls,
+                                                              const half_t* __restrict__ pos, int B, int G2, int W,
+                                                              half_t* __restrict__ tokens) {
+    const int L = G2 + 1, WV = W / 8;
+    const size_t nvec = (size_t)B * L * WV;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        const int d = (int)(i % WV) * 8;
+        const size_t row = i / WV;
+        const int l = (int)(row % L);
+        const size_t bb = row / L;
+        half8_t a = l == 0 ? ld_half8(cls + d) : ld_half8(patch + (bb * G2 + (l - 1)) * W + d);
+        half8_t p = ld_half8(pos + (size_t)l * W + d);
+        half8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)a[j] + (float)p[j]);
+        st_half8(tokens + row * W + d, o);
+    }
+}
+
+__global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restrict__ tokens,
+                                                         const half_t* __restrict__ emb,
+                                                         const half_t* __restrict__ pos, int B, int L, int W, int vocab,
+                                                         half_t* __restrict__ x) {
+    const int WV = W / 8;
+    const size_t nvec = (size_t)B * L * WV;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        const int d = (int)(i % WV) * 8;
+        const size_t row = i / WV;
+        const int l = (int)(row % L);
+        int64_t tk = tokens[row];
+        tk = tk < 0 ? 0 : (tk >= vocab ? vocab - 1 : tk);
+        half8_t a = ld_half8(emb + (size_t)tk * W + d), p = ld_half8(pos + (size_t)l * W + d), o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)a[j] + (float)p[j]);
+        st_half8(x + row * W + d, o);
+    }
+}
+
+// out[b] = x[b, argmax_l tokens[b, l]]  (first maximum, like torch.argmax)
+__global__ __launch_bounds__(64) void gather_eot_kernel(const half_t* __restrict__ x, const int64_t* __restrict__ tokens,
+                                                        int L, int W, half_t* __restrict__ out) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float bv = -1.f; int bi = 0x7fffffff;
+    for (int l = lane; l < L; l += 64) {
+        const float t = (float)tokens[(size_t)b * L + l];
+        if (t > bv) { bv = t; bi = l; }
+    }
+    wave_argmax(bv, bi);
+    for (int d = lane * 8; d < W; d += 512) st_half8(out + (size_t)b * W + d, ld_half8(x + ((size_t)b * L + bi) * W + d));
+}
+
+inline int row_grid(int R) { int g = ceil_div(R, 4); return g < 1 ? 1 : (g > 16384 ? 16384 : g); }
+inline int flat_grid(size_t n) { size_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g)); }
+
+}  // namespace
+
+extern "C" int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                              const void* bias, int act, const void* residual, pclip_stream_t stream) {
+    PCLIP_REQUIRE(A && B && C, "pclip_gemm_f16: null pointer");
+    PCLIP_REQUIRE(M >= 0 && N > 0 && K > 0, "pclip_gemm_f16: bad shape M=%d N=%d K=%d", M, N, K);
+    PCLIP_REQUIRE(K % pgemm::BK == 0, "pclip_gemm_f16: K=%d must be a multiple of %d", K, pgemm::BK);
+    PCLIP_REQUIRE(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0, "pclip_gemm_f16: bad leading dims");
+    PCLIP_REQUIRE(act == 0 || act == 1, "pclip_gemm_f16: unknown activation %d", act);
+    if (M == 0) return PCLIP_OK;
+    const int tiles_m = ceil_div(M, pgemm::BM), tiles_n = ceil_div(N, pgemm::BN);
+    LinearEpi epi{(const half_t*)bias, (const half_t*)residual, (half_t*)C, ldc, act};
+    linear_kernel<<<tiles_m * tiles_n, 256, pgemm::LDS_BYTES, (hipStream_t)stream>>>(
+        (const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, tiles_n);
+    return pclip_check_launch("gemm_f16");
+}
+
+#define DISPATCH_NCH(D, CALL)                                  \
+    do {                                                       \
+        if ((D) <= 512) { constexpr int NCH = 1; CALL; }       \
+        else if ((D) <= 1024) { constexpr int NCH = 2; CALL; } \
+        else if ((D) <= 2048) { constexpr int NCH = 4; CALL; } \
+        else { constexpr int NCH = 8; CALL; }                  \
+    } while (0)
+
+extern "C" int pclip_layernorm_f16(const void* x, int ld_x, const float* gamma, const float* beta, float eps, void* y,
+                                   int R, int D, pclip_stream_t stream) {
+    PCLIP_REQUIRE(x && gamma && beta && y, "pclip_layernorm_f16: null pointer");
+    PCLIP_REQUIRE(D > 0 && D % 8 == 0 && D <= 4096 && ld_x >= D && ld_x % 8 == 0 && R >= 0,
+                  "pclip_layernorm_f16: bad shape R=%d D=%d ld=%d", R, D, ld_x);
+    if (R == 0) return PCLIP_OK;
+    DISPATCH_NCH(D, (layernorm_kernel<NCH, float, 0><<<row_grid(R), 256, 0, (hipStream_t)stream>>>(
+                        (const half_t*)x, ld_x, gamma, beta, eps, (half_t*)y, R, D, nullptr, 0.f, 0.f, 0, nullptr)));
+    return pclip_check_launch("layernorm");
+}
+
+// internal (used by pclip_adapter.hip): LayerNorm with fp16 affine parameters, optional Adapter_FC blend
+int pclip_layernorm_f16p(const void* x, const void* gamma, const void* beta, float eps, void* y, int R, int D,
+                         const void* res, float ratio, float omr, int l2norm, float* sq_out, hipStream_t s) {
+    if (R == 0) return PCLIP_OK;
+    if (res) {
+        DISPATCH_NCH(D, (layernorm_kernel<NCH, half_t, 1><<<row_grid(R), 256, 0, s>>>(
+                            (const half_t*)x, D, (const half_t*)gamma, (const half_t*)beta, eps, (half_t*)y, R, D,
+                            (const half_t*)res, ratio, omr, l2norm, sq_out)));
+    } else {
+        DISPATCH_NCH(D, (layernorm_kernel<NCH, half_t, 0><<<row_grid(R), 256, 0, s>>>(
+                            (const half_t*)x, D, (const half_t*)gamma, (const half_t*)beta, eps, (half_t*)y, R, D,
+                            nullptr, 0.f, 0.f, 0, nullptr)));
+    }
+    return pclip_check_launch("layernorm_f16p");
+}
+
+template <int NT>
+static int launch_attention(const void* qkv, void* out, int B, int L, int H, int causal, hipStream_t s) {
+    constexpr int LP = NT * 32;
+    constexpr int LV = (LP / 4) % 2 ? LP : LP + 4;
+    const size_t lds = (size_t)LP * ATT_DH * 2 + (size_t)ATT_DH * LV * 2;
+    auto kern = attention_kernel<NT>;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            pclip_set_error("pclip_attention_f16: cannot raise dynamic LDS to %zu", lds);
+            return PCLIP_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    kern<<<B * H, 256, lds, s>>>((const half_t*)qkv, (half_t*)out, L, H, causal);
+    return pclip_check_launch("attention");
+}
+
+extern "C" int pclip_attention_f16(const void* qkv, void* out, int B, int L, int H, int dh, int causal,
+                                   pclip_stream_t stream) {
+    PCLIP_REQUIRE(qkv && out, "pclip_attention_f16: null pointer");
+    PCLIP_REQUIRE(dh == ATT_DH, "pclip_attention_f16: head dim %d unsupported (must be 64)", dh);
+    PCLIP_REQUIRE(B >= 0 && H > 0 && L > 0 && L <= ATT_MAX_TILES * 32, "pclip_attention_f16: bad B=%d H=%d L=%d (L <= %d)",
+                  B, H, L, ATT_MAX_TILES * 32);
+    if (B == 0) return PCLIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    switch (ceil_div(L, 32)) {
+        case 1: return launch_attention<1>(qkv, out, B, L, H, causal, s);
+        case 2: return launch_attention<2>(qkv, out, B, L, H, causal, s);
+        case 3: return launch_attention<3>(qkv, out, B, L, H, causal, s);
+        case 4: return launch_attention<4>(qkv, out, B, L, H, causal, s);
+        case 5: return launch_attention<5>(qkv, out, B, L, H, causal, s);
+        case 6: return launch_attention<6>(qkv, out, B, L, H, causal, s);
+        case 7: return launch_attention<7>(qkv, out, B, L, H, causal, s);
+        case 8: return launch_attention<8>(qkv, out, B, L, H, causal, s);
+        default: return launch_attention<9>(qkv, out, B, L, H, causal, s);
+    }
+}
+
+extern "C" int pclip_im2col_patches_f16(const void* img, int B, int R, int P, void* cols, int ld,
+                                        pclip_stream_t stream) {
+    PCLIP_REQUIRE(img && cols, "pclip_im2col_patches_f16: null pointer");
+    PCLIP_REQUIRE(B >= 0 && P > 0 && R > 0 && R % P == 0, "pclip_im2col_patches_f16: bad B=%d R=%d P=%d", B, R, P);
+    PCLIP_REQUIRE(ld >= 3 * P * P, "pclip_im2col_patches_f16: ld=%d < 3*P*P", ld);
+    if (B == 0) return PCLIP_OK;
+    const int G = R / P;
+    const bool vec = P % 8 == 0 && R % 8 == 0 && ld % 8 == 0;
+    const size_t total = (size_t)B * G * G * (vec ? ld / 8 : ld);
+    if (vec) im2col_kernel<true><<<flat_grid(total), 256, 0, (hipStream_t)stream>>>((const half_t*)img, B, R, P, G, ld, (half_t*)cols);
+    else im2col_kernel<false><<<flat_grid(total), 256, 0, (hipStream_t)stream>>>((const half_t*)img, B, R, P, G, ld, (half_t*)cols);
+    return pclip_check_launch("im2col");
+}
+
+extern "C" int pclip_vit_assemble_tokens_f16(const void* patch_emb, const void* class_emb, const void* pos_emb, int B,
+                                             int G2, int W, void* tokens, pclip_stream_t stream) {
+    PCLIP_REQUIRE(patch_emb && class_emb && pos_emb && tokens, "pclip_vit_assemble_tokens_f16: null pointer");
+    PCLIP_REQUIRE(B >= 0 && G2 > 0 && W > 0 && W % 8 == 0, "pclip_vit_assemble_tokens_f16: bad shape");
+    if (B == 0) return PCLIP_OK;
+    assemble_tokens_kernel<<<flat_grid((size_t)B * (G2 + 1) * (W / 8)), 256, 0, (hipStream_t)stream>>>(
+        (const half_t*)patch_emb, (const half_t*)class_emb, (const half_t*)pos_emb, B, G2, W, (half_t*)tokens);
+    return pclip_check_launch("assemble_tokens");
+}
+
+extern "C" int pclip_text_embed_f16(const int64_t* tokens, const void* tok_emb, const void* pos_emb, int B, int L, int W,
+                                    int vocab, void* x, pclip_stream_t stream) {
+    PCLIP_REQUIRE(tokens && tok_emb && pos_emb && x, "pclip_text_embed_f16: null pointer");
+    PCLIP_REQUIRE(B >= 0 && L > 0 && W > 0 && W % 8 == 0 && vocab > 0, "pclip_text_embed_f16: bad shape");
+    if (B == 0) return PCLIP_OK;
+    text_embed_kernel<<<flat_grid((size_t)B * L * (W / 8)), 256, 0, (hipStream_t)stream>>>(
+        tokens, (const half_t*)tok_emb, (const half_t*)pos_emb, B, L, W, vocab, (half_t*)x);
+    return pclip_check_launch("text_embed");
+}
+
+extern "C" int pclip_gather_eot_f16(const void* x, const int64_t* tokens, int B, int L, int W, void* out,
+                                    pclip_stream_t stream) {
+    PCLIP_REQUIRE(x && tokens && out, "pclip_gather_eot_f16: null pointer");
+    PCLIP_REQUIRE(B >= 0 && L > 0 && W > 0 && W % 8 == 0, "pclip_gather_eot_f16: bad shape");
+    if (B == 0) return PCLIP_OK;
+    gather_eot_kernel<<<B, 64, 0, (hipStream_t)stream>>>((const half_t*)x, tokens, L, W, (half_t*)out);
+    return pclip_check_launch("gather_eot");
+}

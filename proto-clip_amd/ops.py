@@ -1,0 +1,304 @@
+"""Tensor-level wrappers over the C ABI (include/pclip.h).  PyTorch is used only to own device memory
+and streams; every arithmetic step below is a libpclip kernel.  All functions require CUDA (ROCm)
+tensors and raise PclipError otherwise — there is deliberately no CPU path."""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr, require_cuda, stream
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only per-(device, stream) scratch buffer (the C ABI never allocates)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _f16c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float16:
+        raise _lib.PclipError(f"expected a float16 tensor, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def l2norm_rows(x: torch.Tensor, out: torch.Tensor = None, want_sq: bool = False):
+    """r16(x / r16(||x||)) per row — utils.py:352, main.py:182-185, 408-409."""
+    require_cuda(x)
+    x = _f16c(x)
+    R, D = x.shape
+    y = torch.empty_like(x) if out is None else out
+    sq = torch.empty(R, dtype=torch.float32, device=x.device) if want_sq else None
+    check(_lib.load().pclip_l2norm_rows_f16(ptr(x), ptr(y), R, D, ptr(sq), stream()), "pclip_l2norm_rows_f16")
+    return (y, sq) if want_sq else y
+
+
+def row_sqnorm(x: torch.Tensor) -> torch.Tensor:
+    require_cuda(x)
+    x = _f16c(x)
+    sq = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    check(_lib.load().pclip_row_sqnorm_f16(ptr(x), x.shape[0], x.shape[1], ptr(sq), stream()), "pclip_row_sqnorm_f16")
+    return sq
+
+
+def transpose(x: torch.Tensor) -> torch.Tensor:
+    """Materialised fp16 transpose (bank layout [D, N*K] <-> [N*K, D], utils.py:320)."""
+    require_cuda(x)
+    x = _f16c(x)
+    R, C = x.shape
+    y = torch.empty(C, R, dtype=torch.float16, device=x.device)
+    check(_lib.load().pclip_transpose_f16(ptr(x), R, C, ptr(y), stream()), "pclip_transpose_f16")
+    return y
+
+
+def proto_build(mem: torch.Tensor, N: int, K: int, per_shot_norm: bool = True, fp32_out: bool = False,
+                want_sq: bool = False):
+    """Prototype reduction (main.py:399-402 eval / 260-264 train / 173-176 zero-shot init).
+    mem [N*K, D] fp16 -> proto [N, D] (fp16, or fp32 un-rounded for the train path)."""
+    require_cuda(mem)
+    mem = _f16c(mem)
+    if mem.shape[0] != N * K:
+        raise _lib.PclipError(f"memory bank has {mem.shape[0]} rows, expected N*K={N * K}")
+    D = mem.shape[1]
+    p16 = None if fp32_out else torch.empty(N, D, dtype=torch.float16, device=mem.device)
+    p32 = torch.empty(N, D, dtype=torch.float32, device=mem.device) if fp32_out else None
+    sq = torch.empty(N, dtype=torch.float32, device=mem.device) if want_sq else None
+    check(_lib.load().pclip_proto_build_f16(ptr(mem), N, K, D, int(per_shot_norm), ptr(p16), ptr(p32), ptr(sq),
+                                            stream()), "pclip_proto_build_f16")
+    out = p32 if fp32_out else p16
+    return (out, sq) if want_sq else out
+
+
+def bank_reduce(feats: torch.Tensor, perm: torch.Tensor = None) -> torch.Tensor:
+    """feats [A, R, D] fp16 -> normalise(r16(mean_A)) rows, optionally gathered by perm (utils.py:318-326)."""
+    require_cuda(feats, perm)
+    feats = _f16c(feats)
+    A, R, D = feats.shape
+    if perm is not None:
+        perm = perm.to(torch.int32).contiguous()
+    keys = torch.empty(R, D, dtype=torch.float16, device=feats.device)
+    check(_lib.load().pclip_bank_reduce_f16(ptr(feats), A, R, D, ptr(perm), ptr(keys), stream()),
+          "pclip_bank_reduce_f16")
+    return keys
+
+
+def partial_sums(mem: torch.Tensor, labels: torch.Tensor, N: int, per_shot_norm: bool = True):
+    """This rank's fp32 per-class sums [N, D] + int32 counts [N] (labels must be non-decreasing)."""
+    require_cuda(mem, labels)
+    mem = _f16c(mem)
+    labels = labels.to(torch.int32).contiguous()
+    R, D = mem.shape
+    sums = torch.empty(N, D, dtype=torch.float32, device=mem.device)
+    counts = torch.empty(N, dtype=torch.int32, device=mem.device)
+    check(_lib.load().pclip_partial_sums_f16(ptr(mem), ptr(labels), R, N, D, int(per_shot_norm), ptr(sums),
+                                             ptr(counts), stream()), "pclip_partial_sums_f16")
+    return sums, counts
+
+
+def proto_finalize(sums: torch.Tensor, counts: torch.Tensor, fp32_out: bool = False, want_sq: bool = False):
+    """sums [W, N, D] fp32, counts [W, N] int32 (rank-major) -> prototypes as proto_build."""
+    require_cuda(sums, counts)
+    if sums.dim() == 2:
+        sums, counts = sums[None], counts[None]
+    sums, counts = sums.contiguous(), counts.contiguous()
+    W, N, D = sums.shape
+    p16 = None if fp32_out else torch.empty(N, D, dtype=torch.float16, device=sums.device)
+    p32 = torch.empty(N, D, dtype=torch.float32, device=sums.device) if fp32_out else None
+    sq = torch.empty(N, dtype=torch.float32, device=sums.device) if want_sq else None
+    check(_lib.load().pclip_proto_finalize(ptr(sums), ptr(counts), W, N, D, ptr(p16), ptr(p32), ptr(sq), stream()),
+          "pclip_proto_finalize")
+    out = p32 if fp32_out else p16
+    return (out, sq) if want_sq else out
+
+
+def padded_ld(N: int) -> int:
+    return (N + 63) // 64 * 64
+
+
+def sqdist(q: torch.Tensor, zi: torch.Tensor, zt: torch.Tensor = None, q_sq=None, zi_sq=None, zt_sq=None):
+    """Squared distances of fp16 queries to both prototype banks: fp32 [Q, ldd] each (cdist(...)**2 of
+    utils.py:230-233).  Returns (d2i, d2t, ldd); columns >= N are unspecified padding."""
+    require_cuda(q, zi, zt)
+    q, zi = _f16c(q), _f16c(zi)
+    zt = None if zt is None else _f16c(zt)
+    Q, D = q.shape
+    N = zi.shape[0]
+    ldd = padded_ld(N)
+    d2i = torch.empty(Q, ldd, dtype=torch.float32, device=q.device)
+    d2t = torch.empty(Q, ldd, dtype=torch.float32, device=q.device) if zt is not None else None
+    nws = _lib.workspace_bytes(_lib.OP_SQDIST, Q, N, D)
+    ws = _workspace(nws, q.device)
+    check(_lib.load().pclip_sqdist_f16(ptr(q), ptr(zi), ptr(zt), Q, N, D, ptr(q_sq), ptr(zi_sq), ptr(zt_sq),
+                                       ptr(d2i), ptr(d2t), ldd, ptr(ws), ws.numel(), stream()), "pclip_sqdist_f16")
+    return d2i, d2t, ldd
+
+
+def fuse_probs(d2i, d2t, N: int, alpha: float, beta: float, want_p=True, want_argmax=False, topk: int = 0):
+    """alpha*softmax(-beta*d2i) + (1-alpha)*softmax(-beta*d2t) (utils.py:236-242) + argmax / top-k."""
+    require_cuda(d2i, d2t)
+    Q, ldd = d2i.shape
+    dev = d2i.device
+    p = torch.empty(Q, N, dtype=torch.float32, device=dev) if want_p else None
+    am = torch.empty(Q, dtype=torch.int32, device=dev) if want_argmax else None
+    tp = torch.empty(Q, topk, dtype=torch.float32, device=dev) if topk else None
+    ti = torch.empty(Q, topk, dtype=torch.int32, device=dev) if topk else None
+    # the reference forms (1 - alpha) in Python double precision and lets torch cast it to fp32
+    a32, oma32 = float(np.float32(alpha)), float(np.float32(1 - float(alpha)))
+    check(_lib.load().pclip_fuse_probs(ptr(d2i), ptr(d2t), Q, N, ldd, a32, oma32, float(np.float32(beta)), ptr(p),
+                                       ptr(am), ptr(tp), ptr(ti), topk, stream()), "pclip_fuse_probs")
+    return p, am, tp, ti
+
+
+def classify(q, zi, zt, alpha: float, beta: float, want_p=False, want_argmax=True, topk: int = 0,
+             q_sq=None, zi_sq=None, zt_sq=None):
+    """One-call classification (sqdist + fuse) with distances kept in scratch."""
+    require_cuda(q, zi, zt)
+    q, zi, zt = _f16c(q), _f16c(zi), _f16c(zt)
+    Q, D = q.shape
+    N = zi.shape[0]
+    dev = q.device
+    p = torch.empty(Q, N, dtype=torch.float32, device=dev) if want_p else None
+    am = torch.empty(Q, dtype=torch.int32, device=dev) if want_argmax else None
+    tp = torch.empty(Q, topk, dtype=torch.float32, device=dev) if topk else None
+    ti = torch.empty(Q, topk, dtype=torch.int32, device=dev) if topk else None
+    ws = _workspace(_lib.workspace_bytes(_lib.OP_CLASSIFY, Q, N, D), dev)
+    a32, oma32 = float(np.float32(alpha)), float(np.float32(1 - float(alpha)))
+    check(_lib.load().pclip_classify_f16(ptr(q), ptr(zi), ptr(zt), Q, N, D, ptr(q_sq), ptr(zi_sq), ptr(zt_sq), a32,
+                                         oma32, float(np.float32(beta)), ptr(p), ptr(am), ptr(tp), ptr(ti), topk,
+                                         ptr(ws), ws.numel(), stream()), "pclip_classify_f16")
+    return p, am, tp, ti
+
+
+def hp_sweep(d2i, d2t, N: int, labels, alphas, betas) -> torch.Tensor:
+    """Correct-counts int32 [na, nb] for every (alpha, beta) pair (main.py:187-199 / 419-430)."""
+    require_cuda(d2i, d2t, labels)
+    Q, ldd = d2i.shape
+    dev = d2i.device
+    a = np.asarray(alphas, dtype=np.float64)
+    a32 = torch.tensor(a.astype(np.float32), device=dev)
+    oma32 = torch.tensor((1 - a).astype(np.float32), device=dev)
+    b32 = torch.tensor(np.asarray(betas, dtype=np.float64).astype(np.float32), device=dev)
+    labels = labels.to(torch.int32).contiguous()
+    correct = torch.zeros(len(a), len(b32), dtype=torch.int32, device=dev)
+    check(_lib.load().pclip_hp_sweep(ptr(d2i), ptr(d2t), ptr(labels), Q, N, ldd, ptr(a32), ptr(oma32), len(a),
+                                     ptr(b32), len(b32), ptr(correct), stream()), "pclip_hp_sweep")
+    return correct
+
+
+def adapter_fc(x, w1, g1, b1, w2, g2, b2, ratio: float = 0.2, l2norm_out: bool = False, want_sq: bool = False):
+    """Adapter_FC.forward (model.py:91-95), optionally fused with the following row normalise."""
+    require_cuda(x, w1, w2)
+    x = _f16c(x)
+    B, D = x.shape
+    H = w1.shape[0]
+    y = torch.empty_like(x)
+    sq = torch.empty(B, dtype=torch.float32, device=x.device) if want_sq else None
+    ws = _workspace(_lib.workspace_bytes(_lib.OP_ADAPTER_FC, B, H, D), x.device)
+    r32, omr32 = float(np.float32(ratio)), float(np.float32(1 - ratio))
+    check(_lib.load().pclip_adapter_fc_f16(ptr(x), B, D, H, ptr(_f16c(w1)), ptr(_f16c(g1)), ptr(_f16c(b1)),
+                                           ptr(_f16c(w2)), ptr(_f16c(g2)), ptr(_f16c(b2)), r32, omr32,
+                                           int(l2norm_out), ptr(y), ptr(sq), ptr(ws), ws.numel(), stream()),
+          "pclip_adapter_fc_f16")
+    return (y, sq) if want_sq else y
+
+
+def adapter_conv(x, three_x: bool, conv1, ln1w, ln1b, conv2, ln2w, ln2b, conv3, ln3w, ln3b,
+                 l2norm_out: bool = False, want_sq: bool = False):
+    """Adapter.forward (model.py:49-78): conv-2x / conv-3x feature adapter, whole pipeline in one kernel."""
+    require_cuda(x, conv1)
+    x = _f16c(x)
+    B, D = x.shape
+    y = torch.empty_like(x)
+    sq = torch.empty(B, dtype=torch.float32, device=x.device) if want_sq else None
+    f = lambda t: None if t is None else ptr(_f16c(t))
+    check(_lib.load().pclip_adapter_conv_f16(ptr(x), B, D, int(three_x), f(conv1), f(ln1w), f(ln1b), f(conv2),
+                                             f(ln2w), f(ln2b), f(conv3), f(ln3w), f(ln3b), int(l2norm_out), ptr(y),
+                                             ptr(sq), stream()), "pclip_adapter_conv_f16")
+    return (y, sq) if want_sq else y
+
+
+# ---- encoder building blocks -------------------------------------------------------------------
+
+def gemm(a, w, bias=None, act: int = 0, residual=None, out=None):
+    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T) — nn.Linear with fused bias/QuickGELU/residual."""
+    require_cuda(a, w)
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float16, device=a.device)
+    check(_lib.load().pclip_gemm_f16(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(out), out.stride(0), M, N, K,
+                                     ptr(bias), act, ptr(residual), stream()), "pclip_gemm_f16")
+    return out
+
+
+def layernorm(x, gamma, beta, eps: float = 1e-5, out=None, rows: int = None, ld: int = None):
+    """fp16 in/out LayerNorm with fp32 statistics and fp32 affine (clip/model.py:155-161)."""
+    require_cuda(x, gamma, beta)
+    D = x.shape[-1]
+    R = x.numel() // D if rows is None else rows
+    ld = D if ld is None else ld
+    if out is None:
+        out = torch.empty(R, D, dtype=torch.float16, device=x.device)
+    check(_lib.load().pclip_layernorm_f16(ptr(x), ld, ptr(gamma), ptr(beta), eps, ptr(out), R, D, stream()),
+          "pclip_layernorm_f16")
+    return out
+
+
+def attention(qkv, B: int, L: int, H: int, causal: bool = False, out=None):
+    require_cuda(qkv)
+    W = H * 64
+    if out is None:
+        out = torch.empty(B * L, W, dtype=torch.float16, device=qkv.device)
+    check(_lib.load().pclip_attention_f16(ptr(qkv), ptr(out), B, L, H, 64, int(causal), stream()),
+          "pclip_attention_f16")
+    return out
+
+
+def cast_f16(x: torch.Tensor) -> torch.Tensor:
+    require_cuda(x)
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    check(_lib.load().pclip_cast_f32_f16(ptr(x), ptr(y), x.numel(), stream()), "pclip_cast_f32_f16")
+    return y
+
+
+def im2col_patches(img: torch.Tensor, P: int) -> torch.Tensor:
+    require_cuda(img)
+    B, C, R, _ = img.shape
+    G = R // P
+    ld = (3 * P * P + 63) // 64 * 64        # K padded to the GEMM's K-tile (ViT-L/14: 588 -> 640)
+    cols = torch.empty(B * G * G, ld, dtype=torch.float16, device=img.device)
+    check(_lib.load().pclip_im2col_patches_f16(ptr(img), B, R, P, ptr(cols), ld, stream()),
+          "pclip_im2col_patches_f16")
+    return cols
+
+
+def vit_assemble_tokens(patch_emb, class_emb, pos_emb, B: int, G2: int, W: int) -> torch.Tensor:
+    tokens = torch.empty(B * (G2 + 1), W, dtype=torch.float16, device=patch_emb.device)
+    check(_lib.load().pclip_vit_assemble_tokens_f16(ptr(patch_emb), ptr(class_emb), ptr(pos_emb), B, G2, W,
+                                                    ptr(tokens), stream()), "pclip_vit_assemble_tokens_f16")
+    return tokens
+
+
+def text_embed(tokens, tok_emb, pos_emb) -> torch.Tensor:
+    require_cuda(tokens, tok_emb)
+    B, L = tokens.shape
+    vocab, W = tok_emb.shape
+    tokens = tokens.to(torch.int64).contiguous()
+    x = torch.empty(B * L, W, dtype=torch.float16, device=tok_emb.device)
+    check(_lib.load().pclip_text_embed_f16(ptr(tokens), ptr(tok_emb), ptr(pos_emb), B, L, W, vocab, ptr(x),
+                                           stream()), "pclip_text_embed_f16")
+    return x
+
+
+def gather_eot(x, tokens, B: int, L: int, W: int) -> torch.Tensor:
+    tokens = tokens.to(torch.int64).contiguous()
+    out = torch.empty(B, W, dtype=torch.float16, device=x.device)
+    check(_lib.load().pclip_gather_eot_f16(ptr(x), ptr(tokens), B, L, W, ptr(out), stream()), "pclip_gather_eot_f16")
+    return out

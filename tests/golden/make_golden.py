@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures by RUNNING THE REFERENCE ITSELF (imported read-only from
+/root/reference under the SURVEY Appendix-B shim) on seeded synthetic inputs.  Runs only in the build
+container; nothing of the reference (source, bytecode, pickled modules) is written to this repo —
+fixtures hold input seeds/shapes and the reference's OUTPUT tensors only.
+
+    python tests/golden/make_golden.py            # all fixtures
+    python tests/golden/make_golden.py C2 tiny    # a subset
+
+Inputs are regenerated in the tests from proto_clip_amd.synth / clip.model.random_state_dict with the
+same seeds, so they are not stored (except the small random adapter state dicts).
+"""
+import io
+import os
+import sys
+import tempfile
+import types
+import contextlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from proto_clip_amd import synth                                   # noqa: E402
+from proto_clip_amd.clip.model import random_state_dict            # noqa: E402
+
+
+# ---------------------------------------------------------------- Appendix-B shim -----------------
+def install_shim():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    ident = lambda *a, **k: (lambda x: x)
+
+    class _Interp:
+        BICUBIC = 3
+
+    tv = mod("torchvision")
+    tf = mod("torchvision.transforms", Compose=ident, Resize=ident, CenterCrop=ident, ToTensor=ident, Normalize=ident,
+             RandomResizedCrop=ident, RandomHorizontalFlip=ident, InterpolationMode=_Interp)
+    tff = mod("torchvision.transforms.functional", to_tensor=lambda x: torch.zeros(3, 4, 4))
+    tv.transforms, tf.functional = tf, tff
+    tv.datasets = mod("torchvision.datasets")
+    mod("ftfy", fix_text=lambda s: s)
+    mod("gdown")
+
+    class SummaryWriter:
+        def __init__(self, *a, **k): pass
+        def add_scalar(self, *a, **k): pass
+        def add_image(self, *a, **k): pass
+        def close(self): pass
+
+    mod("torch.utils.tensorboard", SummaryWriter=SummaryWriter)
+
+    class InfoNCE(torch.nn.Module):       # PyPI info-nce-pytorch defaults (absent here; training only)
+        def forward(self, q, k):
+            q, k = torch.nn.functional.normalize(q, dim=-1), torch.nn.functional.normalize(k, dim=-1)
+            return torch.nn.functional.cross_entropy(q @ k.t() / 0.1, torch.arange(len(q)))
+
+    mod("info_nce", InfoNCE=InfoNCE)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.cuda.manual_seed_all = lambda *a, **k: None
+    import matplotlib
+    matplotlib.use("Agg")
+    sys.path.insert(0, REF)
+
+
+def import_reference():
+    install_shim()
+    scratch = tempfile.mkdtemp(prefix="pclip_golden_")
+    os.chdir(scratch)                       # the reference writes ./caches and ./plots
+    import main as ref_main                 # noqa
+    import utils as ref_utils               # noqa
+    import model as ref_model               # noqa
+    import clip as ref_clip                 # noqa
+    import clip.model as ref_clip_model     # noqa
+    ref_main.plot_tsne = lambda *a, **k: None       # visualisation, off the hot path
+    return ref_main, ref_utils, ref_model, ref_clip, ref_clip_model, scratch
+
+
+def savez(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()})
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+# ---------------------------------------------------------------- few-shot configs ------------------
+# name -> (N, K, D, Q_val, Q_test, alpha, beta, adapter, unnormalised learned text bank)
+FEWSHOT = {
+    "C1": (100, 1, 1024, 160, 256, 0.8, 9.0, "conv-3x", False),     # Caltech-101 1-shot RN50 shapes
+    "C2": (10, 16, 512, 300, 512, 1.0, 0.7, "fc", False),           # EuroSAT 16-shot ViT-B/32 shapes
+    "C3": (1000, 16, 512, 256, 512, 0.5, 12.0, "conv-3x", False),   # ImageNet 16-shot ViT-B/16 (Q sub-sampled)
+    "C5": (198, 16, 768, 666, 32, 0.2, 12.0, "fc", True),           # FewSOL-198 ViT-L/14
+    "C6": (37, 4, 512, 130, 200, 0.3, 5.0, "conv-2x", False),       # odd sizes, conv-2x
+}
+
+
+def adapter_state(ref_model, kind, D, seed):
+    torch.manual_seed(seed)
+    if kind == "fc":
+        ad = ref_model.Adapter_FC(D, dtype=torch.half)
+    else:
+        ad = ref_model.Adapter(D, c_type=kind, dtype=torch.half)
+    # make LayerNorm affine parameters non-trivial so the [C,s,s]-shaped affine is exercised
+    with torch.no_grad():
+        for n, p in ad.named_parameters():
+            if n.endswith(".bias") or ".bn" in n or "fc.1" in n or "fc.3" in n:
+                p.add_((torch.randn(p.shape) * 0.1).half())
+    return ad
+
+
+def learned_banks(split, seed, unnorm_text):
+    """Banks 'after training': perturbed, un-normalised rows [N*K, D] / [N, D] fp16 (main.py:367-368 layout)."""
+    rows = split.visual_memory_keys.t().float()
+    emb_v = (rows * 1.3 + 0.02 * torch.from_numpy(synth.normal(tuple(rows.shape), seed, 20)).float()).half()
+    t = split.textual_memory_bank.t().float()
+    emb_t = (t * (1.45 if unnorm_text else 1.1) + 0.02 * torch.from_numpy(synth.normal(tuple(t.shape), seed, 21)).float()).half()
+    return emb_v, emb_t
+
+
+def make_fewshot(name, ref_main, ref_utils, ref_model, scratch):
+    N, K, D, Qv, Qt, alpha, beta, kind, unnorm = FEWSHOT[name]
+    split = synth.make_split(N, K, D, Qv, Qt, seed=1, unnormalized_text=False)
+    cfg = dict(shots=K, backbone="ViT-B/16", dataset="synthetic_" + name, only_test=True, lr=0.0001, augment_epoch=10,
+               train_epoch=1, alpha=alpha, beta=beta, adapter=kind, train_vis_mem_only=True, losses=["L1"],
+               cache_dir=os.path.join(scratch, "caches", name), logs_dir_path="logs")
+    ad = adapter_state(ref_model, kind, D, seed=7)
+    emb_v, emb_t = learned_banks(split, 1, unnorm)
+    model_dir = f"{ref_utils.get_model_dir_root(cfg)}/alpha-beta/{alpha}-{beta}"
+    os.makedirs(model_dir, exist_ok=True)
+    prefix = f"{model_dir}/best_lr_{cfg['lr']}_aug_{cfg['augment_epoch']}_epochs_{cfg['train_epoch']}"
+    torch.save(torch.nn.Parameter(emb_v), prefix + "_v.pt")
+    torch.save(torch.nn.Parameter(emb_t), prefix + "_t.pt")
+    torch.save(ad.state_dict(), prefix + "_a.pt")
+
+    calls = []
+    real_P = ref_utils.P
+
+    n_grid = 319 * 3
+
+    def spy_P(zq, zi, zt, a, b):
+        p = real_P(zq, zi, zt, a, b)
+        keep_p = len(calls) >= 2 * n_grid               # only the two single calls after the grids keep p
+        calls.append((zq, zi, zt, float(a), float(b), p if keep_p else None, p.max(1)[1].to(torch.int16)))
+        return p
+
+    ref_main.P = spy_P
+    clip_stub = types.SimpleNamespace(dtype=torch.float16)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        ref_main.run_proto_clip(cfg, split.visual_memory_keys, split.visual_memory_values, split.val_features,
+                                split.val_labels, split.test_features, split.test_labels, split.textual_memory_bank,
+                                clip_stub, [str(i) for i in range(N)])
+    ref_main.P = real_P
+    log = buf.getvalue()
+    assert len(calls) == 2 * n_grid + 2, len(calls)
+    zs_calls, test_calls = calls[:n_grid], calls[n_grid:2 * n_grid]
+    fixed_call, hp_call = calls[2 * n_grid], calls[2 * n_grid + 1]
+
+    def grid(cs, off):
+        # rebuild accuracy the way the reference does (main.py:190-199) from the recorded p tensors
+        return cs[off::3]
+
+    def acc_rows(cs, labels):
+        return np.array([[a, b, (am.long() == labels).float().mean().item()] for (_, _, _, a, b, _, am) in cs])
+
+    train_labels = split.visual_memory_values.argmax(1)
+    sel = torch.from_numpy(synth.randint(16, Qt, 1, 900))
+    zq_fixed, zi_test, zt_test, a_f, b_f, p_fixed, _ = fixed_call
+    adapted_val = test_calls[0][0]          # adapter(val) un-normalised (main.py:415)
+    savez(
+        "fewshot_" + name,
+        meta=np.array([N, K, D, Qv, Qt]), alpha=alpha, beta=beta,
+        adapter_keys=np.array(list(ad.state_dict().keys())),
+        **{"adapter__" + k: v for k, v in ad.state_dict().items()},
+        zs_proto_img=zs_calls[0][1], zs_proto_txt=zs_calls[0][2],
+        zs_val=acc_rows(grid(zs_calls, 0), split.val_labels), zs_test=acc_rows(grid(zs_calls, 1), split.test_labels),
+        zs_train=acc_rows(grid(zs_calls, 2), train_labels),
+        test_proto_img=zi_test, test_proto_txt=zt_test,
+        test_val=acc_rows(grid(test_calls, 0), split.val_labels), test_test=acc_rows(grid(test_calls, 1), split.test_labels),
+        test_train=acc_rows(grid(test_calls, 2), train_labels),
+        adapted_test_norm=zq_fixed[:64], adapted_val_raw=adapted_val[:64],
+        fixed_argmax=p_fixed.max(1)[1].to(torch.int16), fixed_acc=(p_fixed.max(1)[1] == split.test_labels).float().mean().item(),
+        p_rows_idx=sel, p_rows=p_fixed[sel],
+        hp_alpha=hp_call[3], hp_beta=hp_call[4],
+        hp_acc=(hp_call[5].max(1)[1] == split.test_labels).float().mean().item(),
+    )
+    assert "Fixed-alp-beta" in log
+
+
+# ---------------------------------------------------------------- shipped checkpoints ---------------
+def make_shipped(ref_model):
+    """The two adapter checkpoints the reference ships on seeded inputs: real trained weights."""
+    for tag, sub, kind, D in (("imagenetF", "imagenet-F", "conv-2x", 1024), ("fewsol198F", "fewsol-198-F", "fc", 768)):
+        sd = torch.load(os.path.join(REF, "pretrained_ckpt", sub, "query_adapter.pt"), map_location="cpu")
+        ad = ref_model.Adapter_FC(D, dtype=torch.half) if kind == "fc" else ref_model.Adapter(D, c_type=kind, dtype=torch.half)
+        ad.load_state_dict(sd)
+        x = synth.make_split(8, 8, D, 8, 8, seed=3).visual_memory_keys.t().contiguous()     # 64 unit rows
+        with torch.no_grad():
+            y = ad(x)
+        tb = torch.load(os.path.join(REF, "pretrained_ckpt", sub, "memory_bank_t.pt"), map_location="cpu").detach()
+        zt = tb / tb.norm(dim=-1, keepdim=True)                                             # main.py:404-405 on the real bank
+        savez("shipped_" + tag, y=y, text_rows_head=tb[:32], text_proto_head=zt[:32], n_text=np.array(tb.shape))
+
+
+# ---------------------------------------------------------------- encoders --------------------------
+TINY = dict(embed_dim=64, image_resolution=32, vision_layers=2, vision_width=128, vision_patch_size=8, context_length=77,
+            vocab_size=512, transformer_width=64, transformer_heads=1, transformer_layers=2)
+SMALL = dict(embed_dim=128, image_resolution=64, vision_layers=3, vision_width=256, vision_patch_size=16, context_length=77,
+             vocab_size=1000, transformer_width=128, transformer_heads=2, transformer_layers=3)
+ODD = dict(embed_dim=64, image_resolution=70, vision_layers=2, vision_width=192, vision_patch_size=14, context_length=77,
+           vocab_size=300, transformer_width=64, transformer_heads=1, transformer_layers=1)   # L=26, K=588 (ViT-L/14-like pad)
+
+
+def synth_tokens(n, vocab, seed):
+    """SOT, random body, EOT (= highest id, as the reference's argmax gather requires), zero padding."""
+    t = torch.zeros(n, 77, dtype=torch.long)
+    lens = synth.randint(n, 20, seed, 300) + 3
+    body = synth.randint(n * 77, vocab - 2, seed, 301).reshape(n, 77)
+    for i in range(n):
+        t[i, 0] = vocab - 2
+        t[i, 1:lens[i]] = torch.from_numpy(body[i, 1:lens[i]])
+        t[i, lens[i]] = vocab - 1
+    return t
+
+
+def make_encoder(tag, kw, ref_clip_model, ref_utils):
+    sd = random_state_dict(seed=11, **kw)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m16 = ref_clip_model.build_model({k: v.clone() for k, v in sd.items()})      # fp16 weights (GPU-path precision)
+        m32 = ref_clip_model.build_model({k: v.clone() for k, v in sd.items()}).float()   # clip.load(device='cpu')
+    res = kw["image_resolution"]
+    imgs = synth.make_images(24, res, seed=5, n_class=6)
+    toks = synth_tokens(12, kw["vocab_size"], seed=5)
+    with torch.no_grad():
+        f16, f32 = m16.encode_image(imgs), m32.encode_image(imgs)
+        t16, t32 = m16.encode_text(toks), m32.encode_text(toks)
+        # hot-path callers on top of the fp16 model (utils.py:284-361), list-of-batches loaders
+        labels = torch.from_numpy(synth.randint(24, 6, 5, 51))
+        loader = [(imgs[:10], labels[:10]), (imgs[10:], labels[10:])]
+        cfg = dict(cache_dir=os.path.join(os.getcwd(), "enc_" + tag), backbone="tiny", shots=4, augment_epoch=2)
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            keys, values = ref_utils.build_cache_model(cfg, m16, loader)
+            feats, flabels = ref_utils.pre_load_features(cfg, "val", m16, loader)
+    savez("encoder_" + tag, img_f16=f16, img_f32=f32, txt_f16=t16, txt_f32=t32, tokens=toks, cache_keys=keys,
+          cache_values=values.to(torch.int16), cache_labels=labels, pre_features=feats, pre_labels=flabels)
+
+
+def make_tokenizer(ref_clip):
+    prompts = ["a photo of a dog.", "a centered satellite photo of annual crop land.", "itap of a forest.",
+               "a bad photo of the tench, tinca tinca.", "A Photo Of The Large golden_retriever!!", "art of the 3-d   printer's nozzle"]
+    ids = ref_clip.tokenize(prompts)
+    savez("tokenizer", prompts=np.array(prompts), ids=ids.to(torch.int32))
+
+
+def main():
+    want = set(sys.argv[1:])
+    ref_main, ref_utils, ref_model, ref_clip, ref_clip_model, scratch = import_reference()
+    todo = lambda k: not want or k in want
+    for name in FEWSHOT:
+        if todo(name):
+            make_fewshot(name, ref_main, ref_utils, ref_model, scratch)
+    if todo("shipped"):
+        make_shipped(ref_model)
+    for tag, kw in (("tiny", TINY), ("small", SMALL), ("odd", ODD)):
+        if todo(tag):
+            make_encoder(tag, kw, ref_clip_model, ref_utils)
+    if todo("tokenizer"):
+        make_tokenizer(ref_clip)
+
+
+if __name__ == "__main__":
+    main()
