@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): query images/sec on the ImageNet 16-shot ViT-B/16 configuration
+(configs[2]: full encoder + conv-3x adapter + dual-bank classification), synthetic data, random-init
+weights of the named architecture.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch of B=1024 pre-processed query images per GPU
+(the reference's loader batch, main.py:505): prototype reduction from the (rank-sharded) 16 000-row
+support bank [+ RCCL all-gather of the fp32 class sums when N>1], fp32->fp16 image cast, ViT-B/16
+encode_image, row normalise, conv-3x adapter + normalise, distance GEMM against both 1000-class banks,
+softmax fusion + argmax.  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+N_CLASS, SHOTS, DIM, BATCH = 1000, 16, 512, 1024
+ALPHA, BETA = 0.5, 12.0                       # configs/imagenet.yml:14-15
+GFLOP_PER_IMG_ENCODER = 35.13                 # SURVEY §6 (torch flop counter on the reference module)
+MFMA_PEAK_TFLOPS = 2500.0                     # fp16 dense, MI355X_MICROARCH.md
+
+
+def gemm_flops(M, N, K):
+    return 2.0 * M * N * K
+
+
+def build_state(device, rank, world):
+    from proto_clip_amd import ops, synth
+    from proto_clip_amd.clip.model import BACKBONES, build_model, random_state_dict
+    from proto_clip_amd.dist import shard_bounds
+    from proto_clip_amd.model import Adapter
+    model = build_model(random_state_dict(seed=1, **BACKBONES["ViT-B/16"])).to(device)
+    torch.manual_seed(1)
+    adapter = Adapter(DIM, "conv-3x", dtype=torch.half)
+    with torch.no_grad():
+        for n_, p_ in adapter.named_parameters():
+            if "bn" in n_:
+                p_.add_((torch.randn(p_.shape) * 0.1).half())
+    adapter = adapter.to(device)
+    split = synth.make_split(N_CLASS, SHOTS, DIM, 8, 8, seed=1)
+    bank_rows = split.visual_memory_keys.t().contiguous()                 # [16000, 512] fp16, sorted by class
+    labels = torch.arange(N_CLASS).repeat_interleave(SHOTS).int()
+    lo, hi = shard_bounds(N_CLASS * SHOTS, rank, world)                   # this rank's slab of the support set
+    st = dict(model=model, adapter=adapter, bank=bank_rows[lo:hi].to(device), bank_labels=labels[lo:hi].to(device),
+              text=ops.l2norm_rows(split.textual_memory_bank.t().contiguous().to(device)))
+    # synthetic pre-processed images, fp32 like the reference's loader output; distinct seed per rank
+    imgs = synth.make_images(64, 224, seed=100 + rank, n_class=N_CLASS)
+    st["images"] = imgs.repeat(BATCH // 64, 1, 1, 1).to(device).contiguous()
+    return st
+
+
+def step(st):
+    from proto_clip_amd import ops
+    from proto_clip_amd.dist import sharded_prototypes
+    with torch.no_grad():
+        zi = sharded_prototypes(st["bank"], st["bank_labels"], N_CLASS)          # main.py:399-402 (+ all-gather)
+        f = st["model"].encode_image(st["images"])                               # clip/model.py:338
+        f = ops.l2norm_rows(f, out=f)                                            # utils.py:352
+        a = st["adapter"](f, l2norm_out=True)                                    # model.py:49-78 + main.py:408-409
+        _, am, _, _ = ops.classify(a, zi, st["text"], ALPHA, BETA, want_p=False, want_argmax=True)   # utils.py:225
+    return am
+
+
+def measure_gemm(st):
+    """Instrumented extra step (outside the timed region): HIP events on the launch stream around every
+    MFMA-GEMM launch -> total algorithmic FLOPs / total duration of that kernel."""
+    from proto_clip_amd import ops
+    real = ops.gemm
+    rec = []
+
+    def timed(a, w, bias=None, act=0, residual=None, out=None):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = real(a, w, bias, act, residual, out)
+        e1.record()
+        rec.append((e0, e1, gemm_flops(a.shape[0], w.shape[0], a.shape[1])))
+        return y
+
+    ops.gemm = timed
+    try:
+        step(st)
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm = real
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
+    fl = sum(f for _, _, f in rec)
+    return dict(launches=len(rec), total_ms=ms, avg_us=1e3 * ms / max(len(rec), 1), tflops=fl / (ms * 1e-3) / 1e12, flops=fl)
+
+
+def cpu_baseline(n_img=32):
+    """The ORACLE (CPU restatement of the reference path, fp32 model as clip.load(device='cpu') yields)
+    timed on the host cores on a bounded sample of the same workload."""
+    from oracle import clip_oracle, proto_oracle as po
+    from proto_clip_amd import synth
+    from proto_clip_amd.clip.model import BACKBONES, random_state_dict
+    sd = random_state_dict(seed=1, **BACKBONES["ViT-B/16"])
+    torch.manual_seed(1)
+    import math
+    s = int(math.ceil(math.sqrt(DIM)))
+    g = torch.Generator().manual_seed(2)
+    ad = {"conv1.weight": torch.randn(16, 1, 1, 1, generator=g).half(), "conv2.weight": (torch.randn(16, 16, 3, 3, generator=g) / 12).half(),
+          "conv3.weight": (torch.randn(1, 16, 1, 1, generator=g) / 4).half()}
+    for i, c in ((1, 16), (2, 16), (3, 1)):
+        ad[f"bn{i}.weight"] = torch.ones(c, s, s).half()
+        ad[f"bn{i}.bias"] = torch.zeros(c, s, s).half()
+    split = synth.make_split(N_CLASS, SHOTS, DIM, 8, 8, seed=1)
+    zi = po.proto_build(split.visual_memory_keys.t().contiguous(), N_CLASS, SHOTS)
+    zt = po.l2norm_rows(split.textual_memory_bank.t().contiguous())
+    imgs = synth.make_images(8, 224, seed=100, n_class=N_CLASS)
+
+    def run(x):
+        f = clip_oracle.encode_image(sd, x, half=False).half()
+        a = po.l2norm_rows(po.adapter_conv(po.l2norm_rows(f), ad, "conv-3x"))
+        return po.P(a, zi, zt, ALPHA, BETA).max(1)[1]
+
+    run(imgs[:2])                                    # warm-up
+    t0 = time.perf_counter()
+    done = 0
+    while done < n_img:
+        run(imgs)
+        done += imgs.shape[0]
+    dt = time.perf_counter() - t0
+    return dict(value=done / dt, unit="query images/sec", cores=torch.get_num_threads(), kind="port",
+                sample=f"{done} images (batches of 8) through the oracle: fp32 ViT-B/16 encode_image + conv-3x adapter + P, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    st = build_state(device, rank, world)
+    for _ in range(args.warmup):
+        step(st)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(st)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    if rank == 0:
+        gm = measure_gemm(st)
+        imgs_per_s = args.steps * BATCH * world / dt
+        line = {
+            "metric": "query images/sec, ImageNet 16-shot ViT-B/16 (few-shot top-1 parity: tests/)",
+            "value": imgs_per_s, "unit": "query images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "C3 ImageNet 16-shot ViT-B/16 conv-3x: prototype reduce + encode_image + adapter + dual-bank classify",
+                       "batch_per_gpu": BATCH, "global_batch": BATCH * world, "classes": N_CLASS, "shots": SHOTS, "embed_dim": DIM,
+                       "alpha": ALPHA, "beta": BETA, "parallelism": f"dp{world} (support rows and queries sharded; all-gather of class sums)"},
+            "roofline": {"bound": "mfma", "kernel": "linear_kernel (fp16 MFMA GEMM, all encoder + adapter linears)",
+                         "achieved": gm["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gm["tflops"] / MFMA_PEAK_TFLOPS,
+                         "traffic": None, "launches_per_step": gm["launches"], "avg_launch_us": gm["avg_us"],
+                         "gemm_ms_per_step": gm["total_ms"], "algorithmic_gflop_per_step": gm["flops"] / 1e9},
+            "whole_path": {"gflop_per_image": GFLOP_PER_IMG_ENCODER + 0.00452, "achieved_tflops": imgs_per_s / world * (GFLOP_PER_IMG_ENCODER + 0.00452) / 1e3,
+                           "frac_of_mfma_peak": imgs_per_s / world * (GFLOP_PER_IMG_ENCODER + 0.00452) / 1e3 / MFMA_PEAK_TFLOPS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

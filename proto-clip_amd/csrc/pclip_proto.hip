@@ -338,7 +338,7 @@ inline int row_grid(int R) { int g = ceil_div(R, 4); return g < 1 ? 1 : (g > 819
     } while (0)
 
 static int check_rows(const char* fn, const void* x, int R, int D) {
-    PCLIP_REQUIRE(x != nullptr, "%s: null pointer", fn);
+    PCLIP_REQUIRE(x != nullptr || R == 0, "%s: null pointer", fn);
     PCLIP_REQUIRE(R >= 0, "%s: negative row count %d", fn, R);
     PCLIP_REQUIRE(D > 0 && D % 8 == 0 && D <= 4096, "%s: D=%d must be a positive multiple of 8, <= 4096", fn, D);
     return 0;
@@ -346,7 +346,7 @@ static int check_rows(const char* fn, const void* x, int R, int D) {
 
 extern "C" int pclip_l2norm_rows_f16(const void* x, void* y, int R, int D, float* sq_out, pclip_stream_t stream) {
     if (int e = check_rows("pclip_l2norm_rows_f16", x, R, D)) return e;
-    PCLIP_REQUIRE(y != nullptr, "pclip_l2norm_rows_f16: null output");
+    PCLIP_REQUIRE(y != nullptr || R == 0, "pclip_l2norm_rows_f16: null output");
     if (R == 0) return PCLIP_OK;
     DISPATCH_NCH(D, (l2norm_rows_kernel<NCH><<<row_grid(R), 256, 0, (hipStream_t)stream>>>(
                         (const half_t*)x, (half_t*)y, R, D, sq_out)));

@@ -27,6 +27,8 @@ sys.path.insert(0, REPO)
 
 from proto_clip_amd import synth                                   # noqa: E402
 from proto_clip_amd.clip.model import random_state_dict            # noqa: E402
+sys.path.insert(0, HERE)
+from spec import ENCODERS, FEWSHOT, fewshot_inputs, randomize_adapter_   # noqa: E402
 
 
 # ---------------------------------------------------------------- Appendix-B shim -----------------
@@ -93,47 +95,17 @@ def savez(name, **arrays):
 
 
 # ---------------------------------------------------------------- few-shot configs ------------------
-# name -> (N, K, D, Q_val, Q_test, alpha, beta, adapter, unnormalised learned text bank)
-FEWSHOT = {
-    "C1": (100, 1, 1024, 160, 256, 0.8, 9.0, "conv-3x", False),     # Caltech-101 1-shot RN50 shapes
-    "C2": (10, 16, 512, 300, 512, 1.0, 0.7, "fc", False),           # EuroSAT 16-shot ViT-B/32 shapes
-    "C3": (1000, 16, 512, 256, 512, 0.5, 12.0, "conv-3x", False),   # ImageNet 16-shot ViT-B/16 (Q sub-sampled)
-    "C5": (198, 16, 768, 666, 32, 0.2, 12.0, "fc", True),           # FewSOL-198 ViT-L/14
-    "C6": (37, 4, 512, 130, 200, 0.3, 5.0, "conv-2x", False),       # odd sizes, conv-2x
-}
-
-
 def adapter_state(ref_model, kind, D, seed):
     torch.manual_seed(seed)
-    if kind == "fc":
-        ad = ref_model.Adapter_FC(D, dtype=torch.half)
-    else:
-        ad = ref_model.Adapter(D, c_type=kind, dtype=torch.half)
-    # make LayerNorm affine parameters non-trivial so the [C,s,s]-shaped affine is exercised
-    with torch.no_grad():
-        for n, p in ad.named_parameters():
-            if n.endswith(".bias") or ".bn" in n or "fc.1" in n or "fc.3" in n:
-                p.add_((torch.randn(p.shape) * 0.1).half())
-    return ad
-
-
-def learned_banks(split, seed, unnorm_text):
-    """Banks 'after training': perturbed, un-normalised rows [N*K, D] / [N, D] fp16 (main.py:367-368 layout)."""
-    rows = split.visual_memory_keys.t().float()
-    emb_v = (rows * 1.3 + 0.02 * torch.from_numpy(synth.normal(tuple(rows.shape), seed, 20)).float()).half()
-    t = split.textual_memory_bank.t().float()
-    emb_t = (t * (1.45 if unnorm_text else 1.1) + 0.02 * torch.from_numpy(synth.normal(tuple(t.shape), seed, 21)).float()).half()
-    return emb_v, emb_t
+    ad = ref_model.Adapter_FC(D, dtype=torch.half) if kind == "fc" else ref_model.Adapter(D, c_type=kind, dtype=torch.half)
+    return randomize_adapter_(ad, seed)
 
 
 def make_fewshot(name, ref_main, ref_utils, ref_model, scratch):
-    N, K, D, Qv, Qt, alpha, beta, kind, unnorm = FEWSHOT[name]
-    split = synth.make_split(N, K, D, Qv, Qt, seed=1, unnormalized_text=False)
-    cfg = dict(shots=K, backbone="ViT-B/16", dataset="synthetic_" + name, only_test=True, lr=0.0001, augment_epoch=10,
-               train_epoch=1, alpha=alpha, beta=beta, adapter=kind, train_vis_mem_only=True, losses=["L1"],
-               cache_dir=os.path.join(scratch, "caches", name), logs_dir_path="logs")
+    N, K, D, Qv, Qt, alpha, beta, kind, unnorm, sigma = FEWSHOT[name]
+    split, emb_v, emb_t, cfg = fewshot_inputs(name)
+    cfg.update(cache_dir=os.path.join(scratch, "caches", name), logs_dir_path="logs")
     ad = adapter_state(ref_model, kind, D, seed=7)
-    emb_v, emb_t = learned_banks(split, 1, unnorm)
     model_dir = f"{ref_utils.get_model_dir_root(cfg)}/alpha-beta/{alpha}-{beta}"
     os.makedirs(model_dir, exist_ok=True)
     prefix = f"{model_dir}/best_lr_{cfg['lr']}_aug_{cfg['augment_epoch']}_epochs_{cfg['train_epoch']}"
@@ -212,14 +184,6 @@ def make_shipped(ref_model):
 
 
 # ---------------------------------------------------------------- encoders --------------------------
-TINY = dict(embed_dim=64, image_resolution=32, vision_layers=2, vision_width=128, vision_patch_size=8, context_length=77,
-            vocab_size=512, transformer_width=64, transformer_heads=1, transformer_layers=2)
-SMALL = dict(embed_dim=128, image_resolution=64, vision_layers=3, vision_width=256, vision_patch_size=16, context_length=77,
-             vocab_size=1000, transformer_width=128, transformer_heads=2, transformer_layers=3)
-ODD = dict(embed_dim=64, image_resolution=70, vision_layers=2, vision_width=192, vision_patch_size=14, context_length=77,
-           vocab_size=300, transformer_width=64, transformer_heads=1, transformer_layers=1)   # L=26, K=588 (ViT-L/14-like pad)
-
-
 def synth_tokens(n, vocab, seed):
     """SOT, random body, EOT (= highest id, as the reference's argmax gather requires), zero padding."""
     t = torch.zeros(n, 77, dtype=torch.long)
@@ -270,7 +234,7 @@ def main():
             make_fewshot(name, ref_main, ref_utils, ref_model, scratch)
     if todo("shipped"):
         make_shipped(ref_model)
-    for tag, kw in (("tiny", TINY), ("small", SMALL), ("odd", ODD)):
+    for tag, kw in ENCODERS.items():
         if todo(tag):
             make_encoder(tag, kw, ref_clip_model, ref_utils)
     if todo("tokenizer"):

@@ -1,0 +1,50 @@
+"""Shared definition of the golden cases: imported by make_golden.py (which feeds these inputs to the
+reference) and by tests/conftest.py (which regenerates the same inputs for the oracle / the HIP path)."""
+import torch
+
+# name -> (N, K, D, Q_val, Q_test, alpha, beta, adapter, unnormalised learned text bank, sigma)
+# sigma (per-dimension noise around unit-variance class centres) is chosen so that accuracies are
+# non-trivial (0.3 .. 0.95) and vary across the (alpha, beta) grid.
+FEWSHOT = {
+    "C1": (100, 1, 1024, 160, 256, 0.8, 9.0, "conv-3x", False, 4.0),     # Caltech-101 1-shot RN50 shapes
+    "C2": (10, 16, 512, 300, 512, 1.0, 0.7, "fc", False, 5.0),           # EuroSAT 16-shot ViT-B/32 shapes
+    "C3": (1000, 16, 512, 256, 512, 0.5, 12.0, "conv-3x", False, 4.0),   # ImageNet 16-shot ViT-B/16 (Q sub-sampled)
+    "C5": (198, 16, 768, 666, 32, 0.2, 12.0, "fc", True, 5.0),           # FewSOL-198 ViT-L/14 (val 666 / test 32)
+    "C6": (37, 4, 512, 130, 200, 0.3, 5.0, "conv-2x", False, 4.5),       # odd sizes, conv-2x
+}
+TINY = dict(embed_dim=64, image_resolution=32, vision_layers=2, vision_width=128, vision_patch_size=8, context_length=77,
+            vocab_size=512, transformer_width=64, transformer_heads=1, transformer_layers=2)
+SMALL = dict(embed_dim=128, image_resolution=64, vision_layers=3, vision_width=256, vision_patch_size=16, context_length=77,
+             vocab_size=1000, transformer_width=128, transformer_heads=2, transformer_layers=3)
+ODD = dict(embed_dim=64, image_resolution=70, vision_layers=2, vision_width=192, vision_patch_size=14, context_length=77,
+           vocab_size=300, transformer_width=64, transformer_heads=1, transformer_layers=1)   # L=26, K=588 (ViT-L/14-like pad)
+ENCODERS = {"tiny": TINY, "small": SMALL, "odd": ODD}
+
+
+def fewshot_inputs(name):
+    """Seeded inputs of case `name`: synthetic split, 'learned' banks (perturbed, un-normalised rows in the
+    [N*K, D] / [N, D] layout of main.py:367-368) and the cfg dict run_proto_clip receives."""
+    from proto_clip_amd import synth
+    N, K, D, Qv, Qt, alpha, beta, kind, unnorm, sigma = FEWSHOT[name]
+    split = synth.make_split(N, K, D, Qv, Qt, seed=1, sigma=sigma, sigma_text=0.6 * sigma)
+    rows = split.visual_memory_keys.t().float()
+    emb_v = (rows * 1.3 + 0.02 * torch.from_numpy(synth.normal(tuple(rows.shape), 1, 20)).float()).half()
+    t = split.textual_memory_bank.t().float()
+    emb_t = (t * (1.45 if unnorm else 1.1) + 0.02 * torch.from_numpy(synth.normal(tuple(t.shape), 1, 21)).float()).half()
+    cfg = dict(shots=K, backbone="ViT-B/16", dataset="synthetic_" + name, only_test=True, lr=0.0001, augment_epoch=10,
+               train_epoch=1, alpha=alpha, beta=beta, adapter=kind, train_vis_mem_only=True, losses=["L1"])
+    return split, emb_v, emb_t, cfg
+
+
+def randomize_adapter_(ad, seed):
+    """In-place: non-trivial LayerNorm affines (so the [C,s,s]-shaped affine is exercised) with a SMALL final
+    LayerNorm scale, as in a trained adapter: the output stays a perturbation of the input features instead
+    of unit-variance noise, so accuracies behind the adapter are meaningful."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in ad.named_parameters():
+            if "bn" in n or "fc.1" in n or "fc.3" in n:
+                p.add_((torch.randn(p.shape, generator=g) * 0.1).to(p.dtype))
+            if n.startswith("bn3.") or n.startswith("fc.3."):
+                p.mul_(0.04)
+    return ad

@@ -1,0 +1,181 @@
+"""CLIP towers on the GPU against the reference's own encoder outputs
+(tests/golden/encoder_*.npz: fp16-weight model = the reference's GPU precision, and the fp32 CPU model)
+and against the oracle.  Tolerances are stated relative to the fp16<->fp32 gap of the reference itself."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import ENCODERS, golden, ulp_diff
+from oracle import clip_oracle, proto_oracle as po
+from proto_clip_amd import synth
+from proto_clip_amd.clip.model import build_model, random_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm(dim=-1) / b.norm(dim=-1)).max().item()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from proto_clip_amd import _lib, ops as _ops
+    _lib.load()
+    return _ops
+
+
+# ---------------------------------------------------------------- building blocks --------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1, 64, 64), (197, 2304, 768), (1000, 512, 3072), (257, 100, 128), (4096, 768, 768)])
+def test_gemm_epilogues(ops, M, N, K):
+    a = (torch.from_numpy(synth.normal((M, K), 21, 0)).float() * 0.5).half()
+    w = (torch.from_numpy(synth.normal((N, K), 21, 1)).float() * K ** -0.5).half()
+    bias = (torch.from_numpy(synth.normal((N,), 21, 2)).float() * 0.1).half()
+    res = torch.from_numpy(synth.normal((M, N), 21, 3)).half()
+    acc = a.float() @ w.float().t()
+    y = ops.gemm(a.cuda(), w.cuda()).cpu()
+    assert ulp_diff(y, acc.half()) <= 1
+    y = ops.gemm(a.cuda(), w.cuda(), bias.cuda()).cpu()
+    assert ulp_diff(y, (acc + bias.float()).half()) <= 1
+    h = po.r16(acc + bias.float())
+    gelu = po.r16(h * po.r16(torch.sigmoid(po.r16(1.702 * h))))
+    y = ops.gemm(a.cuda(), w.cuda(), bias.cuda(), act=1).cpu()
+    assert ulp_diff(y, gelu.half()) <= 2
+    y = ops.gemm(a.cuda(), w.cuda(), bias.cuda(), residual=res.cuda()).cpu()
+    assert ulp_diff(y, (res.float() + h).half()) <= 2      # 1-ulp h (summation order) re-rounded after the add
+    # asymmetric integer-valued operands: exact, catches any transposed / permuted fragment layout
+    ai = (torch.arange(M * K).reshape(M, K) % 5 - 2).half()
+    wi = (torch.arange(N * K).reshape(N, K) % 3 - 1).half()
+    assert torch.equal(ops.gemm(ai.cuda(), wi.cuda()).cpu().float(), (ai.float() @ wi.float().t()).half().float())
+
+
+@pytest.mark.parametrize("R,D", [(7, 64), (500, 768), (197, 1024), (3, 512)])
+def test_layernorm(ops, R, D):
+    x = (torch.from_numpy(synth.normal((R, D), 22, 0)).float() * 2 + 0.3).half()
+    g = 1 + 0.1 * torch.from_numpy(synth.normal((D,), 22, 1)).float()
+    b = 0.1 * torch.from_numpy(synth.normal((D,), 22, 2)).float()
+    y = ops.layernorm(x.cuda(), g.cuda(), b.cuda()).cpu()
+    ref = torch.nn.functional.layer_norm(x.float(), [D], g, b).half()
+    assert ulp_diff(y, ref) <= 1
+    # strided rows (ln_post on the CLS rows only, clip/model.py:233)
+    if R < 3:
+        return
+    xs = x[: (R // 3) * 3].reshape(-1, 3 * D).contiguous()
+    y2 = ops.layernorm(xs.cuda(), g.cuda(), b.cuda(), rows=xs.shape[0], ld=3 * D).cpu()
+    assert ulp_diff(y2, torch.nn.functional.layer_norm(xs[:, :D].float(), [D], g, b).half()) <= 1
+
+
+@pytest.mark.parametrize("B,L,H,causal", [(2, 50, 2, False), (3, 197, 12, False), (2, 77, 8, True), (1, 257, 16, False),
+                                          (4, 26, 3, False), (1, 1, 1, False), (2, 33, 1, True)])
+def test_attention(ops, B, L, H, causal):
+    W = H * 64
+    qkv = (torch.from_numpy(synth.normal((B, L, 3 * W), 23, 0)).float() * 1.5).half()
+    out = ops.attention(qkv.cuda().reshape(B * L, 3 * W), B, L, H, causal=causal).cpu().view(B, L, W)
+    q, k, v = (t.view(B, L, H, 64).transpose(1, 2).float() for t in qkv.split(W, dim=-1))
+    s = q @ k.transpose(-1, -2) * 0.125
+    if causal:
+        s = s + torch.full((L, L), float("-inf")).triu_(1)
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, L, W)
+    # probabilities are rounded to fp16 before P.V (as the reference's fp16 attention does): ~1e-3 relative
+    assert (out.float() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
+    assert rel_err(out.reshape(-1, W), ref.reshape(-1, W)) < 2e-3
+
+
+def test_stems(ops):
+    B, R, P, W = 3, 32, 8, 128
+    img = torch.from_numpy(synth.normal((B, 3, R, R), 24, 0)).half()
+    cols = ops.im2col_patches(img.cuda(), P).cpu()
+    ref = torch.nn.functional.unfold(img.float(), kernel_size=P, stride=P).transpose(1, 2).reshape(-1, 3 * P * P).half()
+    assert torch.equal(cols, ref)
+    img14 = torch.from_numpy(synth.normal((2, 3, 70, 70), 24, 1)).half()        # P=14: K=588 padded to 640 with zeros
+    cols = ops.im2col_patches(img14.cuda(), 14).cpu()
+    ref = torch.nn.functional.unfold(img14.float(), kernel_size=14, stride=14).transpose(1, 2).reshape(-1, 588).half()
+    assert cols.shape[1] == 640 and torch.equal(cols[:, :588], ref) and cols[:, 588:].abs().max().item() == 0
+    x32 = torch.from_numpy(synth.normal((1000,), 24, 2)).float()
+    assert torch.equal(ops.cast_f16(x32.cuda()).cpu(), x32.half())
+    toks = torch.tensor([[5, 9, 2, 11, 0, 0], [5, 11, 0, 0, 0, 0]])
+    emb = torch.from_numpy(synth.normal((12, 64), 24, 3)).half()
+    pos = torch.from_numpy(synth.normal((6, 64), 24, 4)).half()
+    x = ops.text_embed(toks.cuda(), emb.cuda(), pos.cuda())
+    assert torch.equal(x.cpu().view(2, 6, 64), (emb[toks].float() + pos.float()).half())
+    eot = ops.gather_eot(x, toks.cuda(), 2, 6, 64).cpu()
+    assert torch.equal(eot, x.cpu().view(2, 6, 64)[torch.arange(2), toks.argmax(-1)])
+
+
+# ---------------------------------------------------------------- whole towers ---------------------------
+@pytest.mark.parametrize("tag", list(ENCODERS))
+def test_towers_against_reference(ops, tag):
+    g = golden("encoder_" + tag)
+    kw = ENCODERS[tag]
+    sd = random_state_dict(seed=11, **kw)
+    model = build_model({k: v.clone() for k, v in sd.items()}).cuda()
+    assert list(model.state_dict().keys()) == [k for k in sd.keys()] or set(model.state_dict()) == set(sd)
+    imgs = synth.make_images(24, kw["image_resolution"], seed=5, n_class=6)
+    toks = torch.from_numpy(g["tokens"]).long()
+    fi, ft = model.encode_image(imgs.cuda()), model.encode_text(toks.cuda())
+    assert fi.dtype == torch.float16 and fi.shape == (24, kw["embed_dim"]) and ft.shape == (12, kw["embed_dim"])
+    for key in ("img", "txt"):
+        out = fi if key == "img" else ft
+        r16_, r32_ = torch.from_numpy(g[key + "_f16"]), torch.from_numpy(g[key + "_f32"])
+        gap = rel_err(r16_, r32_)                 # the reference's own fp16-vs-fp32 disagreement
+        assert rel_err(out, r32_) <= max(2.0 * gap, 3e-3), (tag, key, rel_err(out, r32_), gap)
+        assert rel_err(out, r16_) <= max(2.0 * gap, 3e-3), (tag, key, rel_err(out, r16_), gap)
+    # and against the oracle (same rounding points by construction)
+    oi = clip_oracle.encode_image(sd, imgs, half=True)
+    assert rel_err(fi, oi) <= 3e-3
+
+
+def test_bank_builders_against_reference(ops, tmp_path):
+    """utils.py:284-361 through proto_clip_amd.utils with the tiny tower and list-of-batches loaders."""
+    from proto_clip_amd.utils import build_cache_model, pre_load_features
+    g = golden("encoder_tiny")
+    kw = ENCODERS["tiny"]
+    model = build_model(random_state_dict(seed=11, **kw)).cuda()
+    imgs = synth.make_images(24, 32, seed=5, n_class=6)
+    labels = torch.from_numpy(g["cache_labels"]).long()
+    loader = [(imgs[:10], labels[:10]), (imgs[10:], labels[10:])]
+    cfg = dict(cache_dir=str(tmp_path), backbone="tiny", shots=4, augment_epoch=2)
+    keys, values = build_cache_model(cfg, model, loader)
+    feats, flabels = pre_load_features(cfg, "val", model, loader)
+    assert keys.shape == (64, 24) and values.shape == (24, 6) and values.dtype == torch.int64
+    assert torch.equal(values.cpu().argmax(1), torch.sort(labels, stable=True).values)
+    assert torch.equal(flabels.cpu(), labels)
+    # the reference's argsort is unstable: compare per-class column SETS via sorted order of a stable key
+    ref_keys, ref_vals = torch.from_numpy(g["cache_keys"]).float(), torch.from_numpy(g["cache_values"]).long().argmax(1)
+    ours = keys.cpu().float()
+    for c in range(6):
+        a, b = ours[:, values.cpu().argmax(1) == c], ref_keys[:, ref_vals == c]
+        assert a.shape == b.shape
+        # match columns greedily by cosine similarity
+        sim = a.t() @ b
+        assert sim.max(dim=1).values.min().item() > 0.9999
+    assert rel_err(feats, torch.from_numpy(g["pre_features"])) <= 5e-3
+    # caches were written with the reference's file names and are re-read on the second call
+    import os
+    assert os.path.exists(f"{tmp_path}/models/tiny/K-4/aug/visual_mb_keys_aug_2_4_shots.pt")
+    k2, v2 = build_cache_model(cfg, None, None)
+    assert torch.equal(k2.cpu(), keys.cpu())
+
+
+def test_clip_classifier_batched(ops):
+    """utils.py:256-273 with synthetic token ids: batched text tower + fused normalise/mean/normalise."""
+    from proto_clip_amd.utils import clip_classifier
+    kw = ENCODERS["tiny"]
+    sd = random_state_dict(seed=11, **kw)
+    model = build_model({k: v.clone() for k, v in sd.items()}).cuda()
+    names, templ = [f"c{i}" for i in range(5)], ["a {}.", "b {}.", "c {}."]
+    ids = {}
+
+    def fake_tokenize(texts):
+        t = torch.zeros(len(texts), 77, dtype=torch.long)
+        for i, s in enumerate(texts):
+            body = [(hash_ % 500) + 1 for hash_ in (sum(map(ord, s)), len(s) * 7, ord(s[0]) * 3)]
+            t[i, 0], t[i, 1:4], t[i, 4] = 510, torch.tensor(body), 511
+        return t
+
+    _, w = clip_classifier(names, templ, model, tokenize=fake_tokenize)
+    assert w.shape == (64, 5) and w.dtype == torch.float16
+    toks = fake_tokenize([t.format(c) for c in names for t in templ])
+    emb = clip_oracle.encode_text(sd, toks, half=True)
+    ref = po.proto_build(emb, 5, 3, per_shot_norm=True)               # normalise rows, mean over templates, normalise
+    assert rel_err(w.t(), ref) <= 5e-3

@@ -1,0 +1,311 @@
+"""GPU parity proper: the HIP path (through the C ABI / ctypes) against the ORACLE on seeded inputs, and
+against the committed reference outputs (tests/golden).  Bit-exact for index work (argmax, counts);
+floating point within the tolerances BASELINE.json's north_star states (p within 1e-3, top-1 identical),
+prototypes within 2 fp16 ulp."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import (FEWSHOT, adapter_sd, assert_adapter_close, assert_grid_close, fewshot_inputs, golden, ulp_diff)
+from oracle import proto_oracle as po
+from proto_clip_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from proto_clip_amd import _lib, ops as _ops
+    _lib.load()
+    return _ops
+
+
+def dev(t):
+    return t.cuda()
+
+
+# ---------------------------------------------------------------- row reductions -------------------
+@pytest.mark.parametrize("R,D", [(1, 512), (5, 64), (1000, 512), (333, 768), (4097, 1024), (7, 2048)])
+def test_l2norm_rows(ops, R, D):
+    x = torch.from_numpy(synth.normal((R, D), 3, 0)).half() * 3
+    y, sq = ops.l2norm_rows(dev(x), want_sq=True)
+    ref = po.l2norm_rows(x)
+    assert ulp_diff(y, ref) <= 1
+    assert (y.cpu() == ref).float().mean().item() > 0.995       # 1-ulp flips of the fp16 norm are rare
+    torch.testing.assert_close(sq.cpu(), y.cpu().float().pow(2).sum(-1), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ops.row_sqnorm(dev(x)).cpu(), x.float().pow(2).sum(-1), rtol=1e-5, atol=1e-5)
+
+
+def test_l2norm_inplace_and_empty(ops):
+    x = dev(torch.from_numpy(synth.normal((9, 512), 4, 0)).half())
+    ref = po.l2norm_rows(x.cpu())
+    out = ops.l2norm_rows(x, out=x)
+    assert out.data_ptr() == x.data_ptr() and ulp_diff(x, ref) <= 1
+    e = ops.l2norm_rows(torch.empty(0, 512, dtype=torch.float16, device="cuda"))
+    assert e.shape == (0, 512)
+
+
+@pytest.mark.parametrize("N,K,D", [(10, 16, 512), (100, 1, 1024), (198, 16, 768), (1000, 16, 512), (37, 3, 512), (5, 7, 64)])
+@pytest.mark.parametrize("per_shot", [True, False])
+def test_proto_build(ops, N, K, D, per_shot):
+    mem = (torch.from_numpy(synth.normal((N * K, D), 5, 1)).float() * 0.7).half()
+    ref16 = po.proto_build(mem, N, K, per_shot_norm=per_shot)
+    out16, sq = ops.proto_build(dev(mem), N, K, per_shot_norm=per_shot, want_sq=True)
+    assert ulp_diff(out16, ref16) <= 2
+    torch.testing.assert_close(sq.cpu(), out16.cpu().float().pow(2).sum(-1), rtol=1e-5, atol=1e-6)
+    ref32 = po.proto_build(mem, N, K, per_shot_norm=per_shot, fp32=True)
+    out32 = ops.proto_build(dev(mem), N, K, per_shot_norm=per_shot, fp32_out=True)
+    # z = r16(mean) can differ by one fp16 ulp (norm summation order); the fp32 quotient z/||z|| inherits it
+    torch.testing.assert_close(out32.cpu(), ref32, rtol=0, atol=3e-4)
+    assert (out32.cpu() - ref32).abs().gt(2e-5).float().mean().item() < 1e-3
+
+
+@pytest.mark.parametrize("A,R,D", [(10, 160, 512), (2, 24, 64), (3, 1000, 768)])
+def test_bank_reduce_and_transpose(ops, A, R, D):
+    feats = torch.from_numpy(synth.normal((A, R, D), 6, 2)).half()
+    labels = torch.from_numpy(synth.randint(R, 7, 6, 3))
+    perm = torch.argsort(labels, stable=True)
+    ref = po.bank_reduce(feats, perm)
+    out = ops.bank_reduce(dev(feats), perm=dev(perm))
+    assert ulp_diff(out, ref) <= 2
+    assert ulp_diff(ops.bank_reduce(dev(feats)), po.bank_reduce(feats)) <= 2
+    t = ops.transpose(out)
+    assert torch.equal(t.cpu(), out.cpu().t())           # byte-exact data movement
+    assert torch.equal(ops.transpose(t).cpu(), out.cpu())
+
+
+def test_transpose_ragged(ops):
+    for R, C in [(1, 1), (3, 130), (65, 63), (512, 16000)]:
+        x = torch.from_numpy(synth.normal((R, C), 8, 0)).half()
+        assert torch.equal(ops.transpose(dev(x)).cpu(), x.t().contiguous())
+
+
+@pytest.mark.parametrize("W", [1, 2, 8])
+def test_partial_sums_and_finalize(ops, W):
+    """Sharded prototype mean == single-GPU prototype build, bit for bit."""
+    from proto_clip_amd.dist import shard_bounds
+    N, K, D = 50, 16, 512
+    mem = (torch.from_numpy(synth.normal((N * K, D), 9, 0)).float()).half()
+    labels = torch.arange(N).repeat_interleave(K).int()
+    sums, counts = [], []
+    for r in range(W):
+        lo, hi = shard_bounds(N * K, r, W)
+        s, c = ops.partial_sums(dev(mem[lo:hi]), dev(labels[lo:hi]), N)
+        so, co = po.partial_sums(mem[lo:hi], labels[lo:hi], N)
+        torch.testing.assert_close(s.cpu(), so, rtol=0, atol=1e-5)
+        assert torch.equal(c.cpu(), co)
+        sums.append(s)
+        counts.append(c)
+    out = ops.proto_finalize(torch.stack(sums), torch.stack(counts))
+    single = ops.proto_build(dev(mem), N, K)
+    assert torch.equal(out.cpu(), single.cpu())
+    assert ulp_diff(out, po.proto_finalize(torch.stack([s.cpu() for s in sums]), torch.stack([c.cpu() for c in counts]))) <= 2
+
+
+def test_partial_sums_missing_classes(ops):
+    N, D = 12, 64
+    mem = torch.from_numpy(synth.normal((20, D), 10, 0)).half()
+    labels = torch.tensor([2] * 5 + [3] * 1 + [9] * 14).int()
+    s, c = ops.partial_sums(dev(mem), dev(labels), N)
+    so, co = po.partial_sums(mem, labels, N)
+    assert torch.equal(c.cpu(), co)
+    torch.testing.assert_close(s.cpu(), so, rtol=0, atol=1e-5)
+    assert s.cpu()[[0, 1, 4, 11]].abs().max().item() == 0
+
+
+# ---------------------------------------------------------------- classification ---------------------
+@pytest.mark.parametrize("Q,N,D", [(1, 10, 512), (300, 10, 512), (129, 1000, 512), (2048, 1000, 512), (32, 198, 768),
+                                   (257, 100, 1024), (1000, 37, 64), (128, 128, 128)])
+def test_sqdist(ops, Q, N, D):
+    q = po.l2norm_rows(torch.from_numpy(synth.normal((Q, D), 11, 0)).half())
+    zi = po.l2norm_rows(torch.from_numpy(synth.normal((N, D), 11, 1)).half())
+    zt = (po.l2norm_rows(torch.from_numpy(synth.normal((N, D), 11, 2)).half()).float() * 1.45).half()   # non-unit bank
+    d2i, d2t, ldd = ops.sqdist(dev(q), dev(zi), dev(zt))
+    assert (d2i.cpu()[:, :N] - po.sqdist(q, zi)).abs().max().item() <= 2e-6 * 4
+    assert (d2t.cpu()[:, :N] - po.sqdist(q, zt)).abs().max().item() <= 2e-5
+    # asymmetric operands: a transposed / permuted accumulator layout cannot pass
+    q2 = (torch.arange(Q * D).reshape(Q, D).float() % 13 / 16).half()
+    z2 = (torch.arange(N * D).reshape(N, D).float() % 7 / 8).half()
+    d, _, _ = ops.sqdist(dev(q2), dev(z2))
+    torch.testing.assert_close(d.cpu()[:, :N], po.sqdist(q2, z2), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("name", list(FEWSHOT))
+def test_P_against_reference_fixture(ops, name):
+    """utils.py:225-244 on the reference's own prototypes and adapted queries (first 64 rows are the
+    reference's; the rest come from the oracle's adapter, which only feeds rows not compared to p_rows)."""
+    from proto_clip_amd.utils import P, P_argmax, P_topk
+    g = golden("fewshot_" + name)
+    split, emb_v, emb_t, cfg = fewshot_inputs(name)
+    sd = adapter_sd(g)
+    ad = (lambda x: po.adapter_fc(x, sd)) if cfg["adapter"] == "fc" else (lambda x: po.adapter_conv(x, sd, cfg["adapter"]))
+    zq = torch.cat([torch.from_numpy(g["adapted_test_norm"]), po.l2norm_rows(ad(split.test_features))[64:]])
+    zi, zt = torch.from_numpy(g["test_proto_img"]), torch.from_numpy(g["test_proto_txt"])
+    p = P(dev(zq), dev(zi), dev(zt), cfg["alpha"], cfg["beta"]).cpu()
+    p_or = po.P(zq, zi, zt, cfg["alpha"], cfg["beta"])
+    assert (p - p_or).abs().max().item() <= 1e-5                       # vs oracle: summation order only
+    idx = torch.from_numpy(g["p_rows_idx"]).long()
+    sel = idx < 64                                                        # rows whose inputs are the reference's own
+    assert (p[idx][sel] - torch.from_numpy(g["p_rows"])[sel]).abs().max().item() <= 1e-3
+    am = P_argmax(dev(zq), dev(zi), dev(zt), cfg["alpha"], cfg["beta"]).cpu()
+    assert torch.equal(am, p_or.max(1)[1])                                # top-1 identical to the oracle
+    assert torch.equal(am[:64], torch.from_numpy(g["fixed_argmax"]).long()[:64])   # ... and to the reference
+    k = min(5, split.N)
+    tv, ti = P_topk(dev(zq), dev(zi), dev(zt), cfg["alpha"], cfg["beta"], k)
+    rv, ri = p_or.topk(k, dim=1)
+    torch.testing.assert_close(tv.cpu(), rv, rtol=0, atol=1e-5)
+    assert (ti.cpu() == ri).float().mean().item() > 0.999                 # ties between ~0 probabilities may reorder
+
+
+def test_fuse_probs_edge_cases(ops):
+    Q, N = 70, 130
+    d2i = torch.from_numpy(synth.uniform(Q * N, 12, 0).reshape(Q, N)).float() * 4
+    d2t = torch.from_numpy(synth.uniform(Q * N, 12, 1).reshape(Q, N)).float() * 4
+    d2i[3, 5] = d2i[3, 77] = 0.0          # exact tie: lowest index wins (main.py:190 on CPU)
+    d2t[3, 5] = d2t[3, 77] = 0.0
+    ldd = ops.padded_ld(N)
+    pad = lambda d: torch.nn.functional.pad(d, (0, ldd - N), value=float("nan"))   # padding must never be read
+    for alpha, beta in [(0.0, 1.0), (1.0, 0.1), (0.5, 20.0), (0.3, 0.0), (0.7, 5.5)]:
+        p, am, _, _ = ops.fuse_probs(dev(pad(d2i)), dev(pad(d2t)), N, alpha, beta, want_p=True, want_argmax=True)
+        ref = po.P_from_dists(d2i, d2t, alpha, beta)
+        torch.testing.assert_close(p.cpu(), ref, rtol=1e-5, atol=1e-7)
+        assert torch.equal(am.cpu().long(), ref.max(1)[1]) or beta == 0.0
+        torch.testing.assert_close(p.cpu().sum(1), torch.ones(Q), rtol=0, atol=1e-5)
+    assert am is not None and ops.fuse_probs(dev(pad(d2i)), dev(pad(d2t)), N, 0.5, 20.0, want_p=False, want_argmax=True)[1][3].item() == 5
+
+
+@pytest.mark.parametrize("name", ["C2", "C6", "C5", "C1", "C3"])
+def test_zero_shot_grid_identical_to_reference(ops, name, tmp_path):
+    """main.py:172-199: all three [319, 3] grids of the zero-shot search, identical to the reference's."""
+    from proto_clip_amd import main as pm
+    g = golden("fewshot_" + name)
+    split, emb_v, emb_t, cfg = fewshot_inputs(name)
+    N, K = split.N, split.K
+    rows = dev(split.visual_memory_keys.t().contiguous())
+    zi = ops.proto_build(rows, N, K, per_shot_norm=False)
+    zt = ops.l2norm_rows(dev(split.textual_memory_bank.t().contiguous()))
+    assert ulp_diff(zi, torch.from_numpy(g["zs_proto_img"])) <= 2 and ulp_diff(zt, torch.from_numpy(g["zs_proto_txt"])) <= 2
+    al, bl = pm.hp_grid()
+    train_y = split.visual_memory_values.argmax(1)
+    for s, f, y in (("val", split.val_features, split.val_labels), ("test", split.test_features, split.test_labels),
+                    ("train", split.visual_memory_keys.t().contiguous(), train_y)):
+        got = pm.grid_accuracy(ops.l2norm_rows(dev(f)), dev(y), zi, zt, al, bl)
+        np.testing.assert_array_equal(got[:, :2], g["zs_" + s][:, :2])
+        assert_grid_close(got[:, 2], g["zs_" + s][:, 2], len(y), exact=True)
+
+
+# ---------------------------------------------------------------- adapters -----------------------------
+@pytest.mark.parametrize("name", list(FEWSHOT))
+def test_adapter_against_reference_fixture(ops, name):
+    from proto_clip_amd.model import Adapter, Adapter_FC
+    g = golden("fewshot_" + name)
+    split, emb_v, emb_t, cfg = fewshot_inputs(name)
+    sd = adapter_sd(g)
+    ad = Adapter_FC(split.D, dtype=torch.half) if cfg["adapter"] == "fc" else Adapter(split.D, cfg["adapter"], dtype=torch.half)
+    ad.load_state_dict(sd)
+    ad = ad.cuda()
+    assert list(ad.state_dict().keys()) == list(sd.keys())            # reference key names and order
+    with torch.no_grad():
+        val_raw = ad(dev(split.val_features[:64]))
+        test_n = ad(dev(split.test_features[:64]), l2norm_out=True)
+        test_2 = ops.l2norm_rows(ad(dev(split.test_features[:64])))
+    assert_adapter_close(val_raw, torch.from_numpy(g["adapted_val_raw"]))
+    assert_adapter_close(test_n, torch.from_numpy(g["adapted_test_norm"]))
+    assert torch.equal(test_n.cpu(), test_2.cpu())                      # fused normalise == separate kernel
+    with pytest.raises(NotImplementedError):
+        ad(dev(split.val_features[:4]))                                 # training forward is not built: loud
+
+
+@pytest.mark.parametrize("kind,D", [("conv-3x", 512), ("conv-2x", 768), ("conv-3x", 1024), ("fc", 1024), ("conv-2x", 100)])
+def test_adapter_random_weights_vs_oracle(ops, kind, D):
+    from proto_clip_amd.model import Adapter, Adapter_FC
+    if kind == "fc" and D % 256:
+        pytest.skip("fc kernel needs D/4 % 64 == 0")
+    torch.manual_seed(3)
+    ad = Adapter_FC(D, dtype=torch.half) if kind == "fc" else Adapter(D, kind, dtype=torch.half)
+    with torch.no_grad():
+        for n_, p_ in ad.named_parameters():
+            if "bn" in n_ or "fc.1" in n_ or "fc.3" in n_:
+                p_.add_((torch.randn(p_.shape) * 0.1).half())
+    x = po.l2norm_rows(torch.from_numpy(synth.normal((300, D), 13, 0)).half())
+    sd = {k: v.clone() for k, v in ad.state_dict().items()}
+    ref = po.adapter_fc(x, sd) if kind == "fc" else po.adapter_conv(x, sd, kind)
+    with torch.no_grad():
+        y = ad.cuda()(dev(x))
+    assert_adapter_close(y, ref)
+
+
+# ---------------------------------------------------------------- whole test pass ----------------------
+@pytest.mark.parametrize("name", ["C2", "C6", "C5", "C1"])
+def test_run_proto_clip_test_pass(ops, name, tmp_path, monkeypatch):
+    """reference main.py:383-455 through proto_clip_amd.main.run_proto_clip, against the reference's grids."""
+    import os
+    import types
+    from proto_clip_amd import main as pm
+    from proto_clip_amd.utils import get_model_dir_root
+    g = golden("fewshot_" + name)
+    split, emb_v, emb_t, cfg = fewshot_inputs(name)
+    cfg["cache_dir"] = str(tmp_path / "caches")
+    model_dir = f"{get_model_dir_root(cfg)}/alpha-beta/{cfg['alpha']}-{cfg['beta']}"
+    os.makedirs(model_dir, exist_ok=True)
+    prefix = f"{model_dir}/best_lr_{cfg['lr']}_aug_{cfg['augment_epoch']}_epochs_{cfg['train_epoch']}"
+    torch.save(torch.nn.Parameter(emb_v), prefix + "_v.pt")               # reference file layout (main.py:367-369)
+    torch.save(torch.nn.Parameter(emb_t), prefix + "_t.pt")
+    torch.save(adapter_sd(g), prefix + "_a.pt")
+    out = pm.run_proto_clip(cfg, dev(split.visual_memory_keys), dev(split.visual_memory_values), dev(split.val_features),
+                            dev(split.val_labels), dev(split.test_features), dev(split.test_labels),
+                            dev(split.textual_memory_bank), types.SimpleNamespace(dtype=torch.float16), None)
+    n = dict(val=len(split.val_labels), test=len(split.test_labels), train=split.N * split.K)
+    for s in ("val", "test", "train"):
+        assert_grid_close(out["zero_shot"][s][:, 2], g["zs_" + s][:, 2], n[s], exact=True)
+        assert_grid_close(out["test"][s][:, 2], g["test_" + s][:, 2], n[s])
+    assert abs(out["test"]["fixed_acc"] - float(g["fixed_acc"])) <= 1.0 / n["test"] + 1e-9
+    # the pickles the reference writes (main.py:205-207) exist with the reference's names
+    for s in ("val", "test", "train"):
+        assert os.path.exists(os.path.join(get_model_dir_root(cfg), f"zero_shot_hp_search_{s}_ViT_B_16_K_{cfg['shots']}.pkl"))
+
+
+# ---------------------------------------------------------------- error behaviour ----------------------
+def test_loud_failures(ops):
+    from proto_clip_amd import PclipError
+    with pytest.raises(PclipError):
+        ops.l2norm_rows(torch.zeros(4, 512, dtype=torch.float16))          # CPU tensor: no fallback
+    with pytest.raises(PclipError):
+        ops.l2norm_rows(torch.zeros(4, 510, dtype=torch.float16, device="cuda"))
+    with pytest.raises(PclipError):
+        ops.sqdist(torch.zeros(4, 72, dtype=torch.float16, device="cuda"), torch.zeros(3, 72, dtype=torch.float16, device="cuda"))
+    from proto_clip_amd.utils import P
+    with pytest.raises(PclipError):
+        P(torch.zeros(4, 512, device="cuda"), torch.zeros(3, 512, device="cuda"), torch.zeros(3, 512, device="cuda"), 0.5, 1.0)
+
+
+# ---------------------------------------------------------------- full-size properties -----------------
+def test_full_size_properties_C3(ops):
+    """BASELINE sizes (Q=50 000, N=1000, D=512): size-independent properties instead of an oracle run."""
+    split = synth.make_split(1000, 16, 512, 64, 50000, seed=1, sigma=4.0, sigma_text=2.4)
+    rows = dev(split.visual_memory_keys.t().contiguous())
+    zi, zi_sq = ops.proto_build(rows, 1000, 16, want_sq=True)
+    zt = ops.l2norm_rows(dev(split.textual_memory_bank.t().contiguous()))
+    assert (zi_sq - 1).abs().max().item() < 2e-3                          # unit norm in fp16
+    acc_lo, acc_hi = 0.2, 0.99
+    assert torch.equal(ops.l2norm_rows(zt), zt) or ulp_diff(ops.l2norm_rows(zt), zt) <= 1   # idempotent up to 1 ulp
+    q = dev(split.test_features)
+    d2i, d2t, ldd = ops.sqdist(q, zi, zt)
+    # distance to self: a prototype queried against its own bank sits on the diagonal at ~0 and is the row min
+    dself, _, _ = ops.sqdist(zi, zi)
+    assert dself[:, :1000].diagonal().abs().max().item() < 1e-3
+    assert torch.equal(dself[:, :1000].argmin(1).cpu(), torch.arange(1000))
+    # permutation equivariance over queries and over classes
+    perm = torch.randperm(50000, generator=torch.Generator().manual_seed(0)).cuda()
+    d2p, _, _ = ops.sqdist(q[perm], zi)
+    assert torch.equal(d2p[:, :1000], d2i[perm][:, :1000])
+    p, am, _, _ = ops.fuse_probs(d2i, d2t, 1000, 0.5, 12.0, want_p=True, want_argmax=True)
+    assert (p.sum(1) - 1).abs().max().item() < 1e-5 and p.min().item() >= 0
+    assert torch.equal(am.long(), p.max(1)[1])
+    # the sweep's count at (alpha, beta) equals the argmax path's count; alpha=1 ignores the text bank
+    al, bl = np.array([0.0, 0.5, 1.0]), np.array([0.7, 12.0])
+    cnt = ops.hp_sweep(d2i, d2t, 1000, dev(split.test_labels), al, bl).cpu()
+    assert cnt[1, 1].item() == (am.long().cpu() == split.test_labels).sum().item()
+    _, am1, _, _ = ops.fuse_probs(d2i, None, 1000, 1.0, 12.0, want_p=False, want_argmax=True)
+    assert cnt[2, 1].item() == (am1.long().cpu() == split.test_labels).sum().item()
+    assert acc_lo < cnt[1, 1].item() / 50000 < acc_hi, cnt
