@@ -12,6 +12,7 @@ LayerNorm and embedding parameters fp32, activations fp16 with fp32 accumulation
 Only the transformer towers (ViT-B/32, ViT-B/16, ViT-L/14 and every text tower) are built; the
 ModifiedResNet tower (RN50/RN101, clip/model.py:95-152) is not — BASELINE pins its only config (C1) to
 the CPU path."""
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -107,7 +108,9 @@ class VisionTransformer(nn.Module):
         self.ln_post = _ln(width)
         self.proj = nn.Parameter(torch.empty(width, output_dim), requires_grad=False)
         self._cache = _Cached()
-        self.chunk = 128     # images per pass: keeps one layer's activations inside the 256 MiB Infinity Cache
+        # images per pass: bounds activation memory (c_fc output = chunk*L*4W*2 B) and keeps tile counts
+        # a large multiple of the 512 resident GEMM workgroups (tail quantisation); tuned on MI355X
+        self.chunk = int(os.environ.get("PCLIP_VIT_CHUNK", "256"))
 
     def forward(self, x: torch.Tensor):
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != self.input_resolution or x.shape[3] != self.input_resolution:

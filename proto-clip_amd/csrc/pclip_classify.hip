@@ -10,18 +10,7 @@ namespace {
 // torch.cdist (mm path) evaluates ||q||^2 + ||z||^2 - 2 q.z in fp32, clamps at 0, takes sqrt; the
 // reference then squares it again (utils.py:230-233).  fp16 operands make every product exact in the
 // fp32 accumulator, so only summation order differs from the reference's fp32 GEMM.
-struct SqdistEpi {
-    const float* __restrict__ q_sq;
-    const float* __restrict__ z_sq;
-    float* __restrict__ out;
-    int ldd;
-    __device__ __forceinline__ void operator()(int row, int col, float dot) const {
-        float v = __fadd_rn(__fadd_rn(-2.f * dot, q_sq[row]), z_sq[col]);
-        float d = sqrtf(fmaxf(v, 0.f));
-        out[(size_t)row * ldd + col] = __fmul_rn(d, d);
-    }
-};
-
+// Each lane finishes four consecutive classes of one query row: one 16-byte store.
 __global__ __launch_bounds__(256, 2) void sqdist_kernel(const half_t* __restrict__ q, const half_t* __restrict__ zi,
                                                         const half_t* __restrict__ zt, int Q, int N, int D,
                                                         const float* __restrict__ q_sq, const float* __restrict__ zi_sq,
@@ -31,8 +20,40 @@ __global__ __launch_bounds__(256, 2) void sqdist_kernel(const half_t* __restrict
     const int bank = blockIdx.y;
     const int swz = pgemm::xcd_remap(blockIdx.x, gridDim.x);
     const int tile_m = swz / tiles_n, tile_n = swz - tile_m * tiles_n;
-    SqdistEpi epi{q_sq, bank ? zt_sq : zi_sq, bank ? d2t : d2i, ldd};
-    pgemm::gemm_tile(q, D, bank ? zt : zi, D, Q, N, D, tile_m, tile_n, smem, epi);
+    const int m0 = tile_m * pgemm::BM, n0 = tile_n * pgemm::BN;
+    pgemm::Acc acc;
+    int pbuf = 0;
+    pgemm::stage_first(q, D, bank ? zt : zi, D, Q, N, m0, n0, smem, 0);
+    pgemm::mainloop(q, D, bank ? zt : zi, D, Q, N, D, m0, n0, smem, acc, pbuf);
+    const float* __restrict__ z_sq = bank ? zt_sq : zi_sq;
+    float* __restrict__ out = bank ? d2t : d2i;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1, hi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wr * 64 + i * 32 + (lane & 31);
+        if (m >= Q) continue;
+        const float qs = q_sq[m];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wc * 64 + j * 32 + 8 * g + 4 * hi;
+                float4_t o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float zs = n + e < N ? z_sq[n + e] : 0.f;
+                    const float v = __fadd_rn(__fadd_rn(-2.f * acc.v[i][j][4 * g + e], qs), zs);
+                    const float d = sqrtf(fmaxf(v, 0.f));
+                    o[e] = __fmul_rn(d, d);
+                }
+                float* dst = out + (size_t)m * ldd + n;
+                if (n + 3 < ldd) *reinterpret_cast<float4_t*>(dst) = o;      // columns in [N, ldd) are padding
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (n + e < ldd) dst[e] = o[e];
+                }
+            }
+    }
 }
 
 // ---- stage 2: softmax fusion, one wave per query row ----------------------------------------------
@@ -223,7 +244,7 @@ extern "C" int pclip_sqdist_f16(const void* q, const void* zi, const void* zt, i
                                 int ldd, void* ws, size_t ws_bytes, pclip_stream_t stream) {
     PCLIP_REQUIRE(q && zi && d2i, "pclip_sqdist_f16: null pointer");
     PCLIP_REQUIRE(!zt || d2t, "pclip_sqdist_f16: zt given without d2t");
-    PCLIP_REQUIRE(Q >= 0 && N > 0 && ldd >= N, "pclip_sqdist_f16: bad Q=%d N=%d ldd=%d", Q, N, ldd);
+    PCLIP_REQUIRE(Q >= 0 && N > 0 && ldd >= N && ldd % 4 == 0, "pclip_sqdist_f16: bad Q=%d N=%d ldd=%d (ldd %% 4 == 0)", Q, N, ldd);
     PCLIP_REQUIRE(D > 0 && D % 64 == 0 && D <= 4096, "pclip_sqdist_f16: D=%d must be a multiple of 64, <= 4096", D);
     if (Q == 0) return PCLIP_OK;
     hipStream_t s = (hipStream_t)stream;

@@ -15,28 +15,112 @@ struct LinearEpi {
     half_t* __restrict__ C;
     int ldc;
     int act;
-    __device__ __forceinline__ void operator()(int row, int col, float acc) const {
-        float v = acc;
-        if (bias) v += (float)bias[col];
-        v = r16(v);
-        if (act == 1) {
-            const float t = r16(1.702f * v);
-            const float s = r16(1.f / (1.f + expf(-t)));
-            v = r16(v * s);
-        }
-        const size_t o = (size_t)row * ldc + col;
-        if (residual) v = (float)residual[o] + v;
-        C[o] = (half_t)v;
-    }
 };
 
+// QuickGELU with the reference's three fp16 roundings.  exp / reciprocal use the hardware approximations
+// (v_exp_f32, v_rcp_f32: ~1-2 ulp in fp32), far inside the fp16 rounding that follows each step.
+__device__ __forceinline__ float quick_gelu16(float v) {
+    const float t = r16(1.702f * v);
+    const float s = r16(__builtin_amdgcn_rcpf(1.f + __expf(-t)));
+    return r16(v * s);
+}
+
+// Persistent: gridDim.x <= 2 workgroups per CU; each walks output tiles round by round (round r covers tiles
+// [r*G, (r+1)*G), XCD-remapped inside the round so that one XCD's L2 sees neighbouring tiles).  The next
+// tile's first K-tile is already in flight while the epilogue of the current tile stages through LDS, and the
+// current tile's global stores drain under the next tile's K-loop instead of delaying workgroup exit.
+// Everything the epilogue needs from global memory (bias, residual) is loaded BEFORE the K-loop, so that it
+// lands behind the K-loop's first barrier and the epilogue itself never waits on the vector-memory counter
+// (which would also wait for the next tile's prefetch).
 __global__ __launch_bounds__(256, 2) void linear_kernel(const half_t* __restrict__ A, int lda,
                                                         const half_t* __restrict__ B, int ldb, int M, int N, int K,
-                                                        LinearEpi epi, int tiles_n) {
+                                                        LinearEpi epi, int tiles_n, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int swz = pgemm::xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_m = swz / tiles_n, tile_n = swz - tile_m * tiles_n;
-    pgemm::gemm_tile(A, lda, B, ldb, M, N, K, tile_m, tile_n, smem, epi);
+    const int G = gridDim.x;
+    int tile = pgemm::xcd_remap(blockIdx.x, G);
+    if (tile >= ntiles) return;
+    int p = 0;
+    {
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        pgemm::stage_first(A, lda, B, ldb, M, N, tm * pgemm::BM, tn * pgemm::BN, smem, p);
+    }
+    const half_t* __restrict__ bias = epi.bias;
+    const half_t* __restrict__ residual = epi.residual;
+    const int act = epi.act;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wc = wave & 1, hi = lane >> 5;
+    const int c = threadIdx.x & 15;                       // row-major pass: 16-byte column chunk of this thread
+    const bool ldc_vec = (epi.ldc & 7) == 0;
+    for (; tile < ntiles; tile += G) {
+        const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+        const int m0 = tile_m * pgemm::BM, n0 = tile_n * pgemm::BN;
+        const int col = n0 + 8 * c;
+        const bool vec = (col + 7 < N) && ldc_vec;
+        // ---- epilogue operands, fetched up front ----
+        half4_t bv[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wc * 64 + j * 32 + 8 * g + 4 * hi;
+                half4_t b = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+                if (bias) {
+                    if (n + 3 < N) b = *reinterpret_cast<const half4_t*>(bias + n);     // n % 4 == 0: 8-byte aligned
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) b[e] = n + e < N ? bias[n + e] : (half_t)0.f;
+                    }
+                }
+                bv[j][g] = b;
+            }
+        half8_t rs[8];
+        if (residual && vec) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = m0 + (threadIdx.x >> 4) + 16 * i;
+                rs[i] = ld_half8(residual + (size_t)(row < M ? row : M - 1) * epi.ldc + col);
+            }
+        }
+        pgemm::Acc acc;
+        pgemm::mainloop(A, lda, B, ldb, M, N, K, m0, n0, smem, acc, p);
+        const int next = tile + G;
+        if (next < ntiles) {                                  // buffer p is free: prefetch the next tile's K-tile 0
+            const int tm = next / tiles_n, tn = next - tm * tiles_n;
+            pgemm::stage_first(A, lda, B, ldb, M, N, tm * pgemm::BM, tn * pgemm::BN, smem, p);
+        }
+        char* stg = smem + (p ^ 1) * 2 * pgemm::TILE_BYTES;   // buffer of the last K-tile, reused after a barrier
+        pgemm::stage_out_f16(acc, stg, [&](int j, int g, float4_t v) {
+            half4_t h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = r16(v[e] + (float)bv[j][g][e]);
+                if (act == 1) x = quick_gelu16(x);
+                h[e] = (half_t)x;
+            }
+            return h;
+        });
+        // ---- row-major pass: thread -> (row r, 8 columns 8c .. 8c+7) ----
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = (threadIdx.x >> 4) + 16 * i;
+            const int row = m0 + r;
+            if (row >= M || col >= N) continue;
+            half8_t h = pgemm::staged_row_chunk(stg, r, c);
+            const size_t o = (size_t)row * epi.ldc + col;
+            if (vec) {
+                if (residual) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h[e] = (half_t)((float)rs[i][e] + (float)h[e]);
+                }
+                st_half8(epi.C + o, h);
+            } else {
+                for (int e = 0; e < 8 && col + e < N; ++e) {
+                    float x = (float)h[e];
+                    if (residual) x = (float)residual[o + e] + x;
+                    epi.C[o + e] = (half_t)x;
+                }
+            }
+        }
+    }
 }
 
 // ---- LayerNorm, one wave per row ----------------------------------------------------------------
@@ -120,41 +204,55 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
     }
 }
 
-// ---- attention: one workgroup per (image, head), whole sequence resident in LDS -------------------
-// S^T = K Q^T is computed (operands swapped) so that a lane owns ONE query row: its 16 accumulator
-// registers per 32-key tile are 16 different keys, the softmax max/sum are in-lane reductions plus one
-// cross-half shuffle, and the fp16 probabilities are already laid out as the A operand of the P.V MFMA
-// (k-order permuted identically for P and V, which a contraction does not care about).
+// ---- attention: one workgroup per (image, head), whole K/V of the head resident in LDS ----------------
+// The CLIP sequences (50 .. 257 tokens) fit one workgroup.  Both contractions are computed TRANSPOSED so
+// that a lane owns ONE query row throughout:
+//   S^T = K Q^T      (A = K rows from LDS, B = Q rows in registers)  -> lane (q = lane&31) holds 16 keys
+//   O^T = V^T P^T    (A = V^T rows from LDS, B = P^T = the S^T registers, already in B-operand order)
+// so the softmax max / sum / rescale are in-lane scalars (one cross-half shuffle), no LDS round trip for P,
+// and the k-order of the second contraction is whatever the first one produced (a contraction does not
+// care, as long as A and B agree).  Keys are walked in 32-wide tiles with an online softmax, which keeps
+// the register footprint at ~100 VGPRs (2 workgroups per CU) for any L <= 288.
 constexpr int ATT_DH = 64;
-constexpr int ATT_MAX_TILES = 9;   // L <= 288
+constexpr int ATT_MAX_L = 288;
 
-template <int NT>   // NT = ceil(L / 32) key tiles
-__global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
-                                                        int L, int H, int causal) {
+__global__ __launch_bounds__(256, 2) void attention_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
+                                                           int L, int H, int causal, int NT, int LV) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int LP = NT * 32;
-    constexpr int LV = (LP / 4) % 2 ? LP : LP + 4;            // Vt row stride (halves): (LV/4) odd -> no ds_read_b64 conflicts
-    half_t* Ks = reinterpret_cast<half_t*>(smem);             // [LP][64], 16-byte chunks XOR-swizzled by (row & 7)
-    half_t* Vt = Ks + LP * ATT_DH;                            // [64][LV]
+    const int LP = NT * 32;
+    half_t* Ks = reinterpret_cast<half_t*>(smem);             // [LP][64], 16-byte chunks XOR-swizzled by swz_key(row)
+    half_t* Vt = Ks + LP * ATT_DH;                            // [64][LV]: V transposed, (LV/4) odd -> conflict-free b64 reads
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int W = H * ATT_DH;
     const half_t* base = qkv + (size_t)b * L * 3 * W + h * ATT_DH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // stage K (swizzled rows) and V (transposed); rows >= L are zero so padded keys contribute nothing
-    for (int i = tid; i < LP * 8; i += 256) {
-        const int r = i >> 3, c = i & 7;
-        half8_t kv, vv;
-        if (r < L) {
-            kv = ld_half8(base + (size_t)r * 3 * W + W + c * 8);
-            vv = ld_half8(base + (size_t)r * 3 * W + 2 * W + c * 8);
-        } else {
+    // K: global_load_lds, 8 rows x 128 B per wave instruction, swizzle on the source chunk (as the GEMM tiles)
+    for (int r0 = wave * 8; r0 < LP; r0 += 32) {
+        const int r = r0 + (lane >> 3);
+        const int c = (lane & 7) ^ pgemm::swz_key(r);
+        const int rc = r < L ? r : L - 1;                     // rows >= L are masked in the scores
+        __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(base + (size_t)rc * 3 * W + W + c * 8),
+                                         (pgemm::lds_ptr_t)(Ks + r0 * ATT_DH), 16, 0, 0);
+    }
+    // V^T: each thread transposes a 4-key x 8-dim block: 4 x 16-byte loads -> 8 x ds_write_b64
+    for (int i = tid; i < (LP / 4) * 8; i += 256) {
+        const int kg = i >> 3, c = i & 7;
+        half8_t v[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { kv[j] = (half_t)0.f; vv[j] = (half_t)0.f; }
+        for (int u = 0; u < 4; ++u) {
+            const int r = kg * 4 + u;
+            if (r < L) v[u] = ld_half8(base + (size_t)r * 3 * W + 2 * W + c * 8);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[u][j] = (half_t)0.f;     // padded keys must contribute exact zeros
+            }
         }
-        *reinterpret_cast<half8_t*>(Ks + r * ATT_DH + ((c ^ (r & 7)) << 3)) = kv;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * LV + r] = vv[j];
+        for (int j = 0; j < 8; ++j) {
+            half4_t t = {v[0][j], v[1][j], v[2][j], v[3][j]};
+            *reinterpret_cast<half4_t*>(Vt + (c * 8 + j) * LV + kg * 4) = t;
+        }
     }
     __syncthreads();
 
@@ -165,66 +263,74 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* __restrict
         half8_t qf[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[s] = ld_half8(base + (size_t)qc * 3 * W + s * 16 + hi * 8);
-
-        float16_t st[NT];
-        float mx = -__builtin_inff();
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) st[t][e] = 0.f;
-            const int kr = t * 32 + ql;                 // key row this lane feeds as A operand
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                half8_t kf = *reinterpret_cast<const half8_t*>(Ks + kr * ATT_DH + (((s * 2 + hi) ^ (kr & 7)) << 3));
-                st[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[t], 0, 0, 0);
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int k = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                const bool ok = k < L && (!causal || k <= q);
-                st[t][e] = ok ? st[t][e] * 0.125f : -__builtin_inff();   // 1/sqrt(64), exact
-                mx = fmaxf(mx, st[t][e]);
-            }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
-        float sum = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { st[t][e] = expf(st[t][e] - mx); sum += st[t][e]; }
-        sum += __shfl_xor(sum, 32, WAVE);
-        const float inv = 1.f / sum;
-
         float16_t o[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[j][e] = 0.f;
+        float mrun = -__builtin_inff(), lrun = 0.f;
+        const int tend = causal ? (qb + 1 < NT ? qb + 1 : NT) : NT;      // causal: keys beyond the block's last query are all masked
+        for (int t = 0; t < tend; ++t) {
+            float16_t st;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+            for (int e = 0; e < 16; ++e) st[e] = 0.f;
+            const int kr = t * 32 + ql;                 // key row this lane feeds as the A operand
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + kr * ATT_DH + (((s * 2 + hi) ^ pgemm::swz_key(kr)) << 3));
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st, 0, 0, 0);
+            }
+            float tmax = -__builtin_inff();
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                const bool ok = k < L && (!causal || k <= q);
+                st[e] = ok ? st[e] * 0.125f : -__builtin_inff();     // 1/sqrt(64), exact
+                tmax = fmaxf(tmax, st[e]);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, WAVE));
+            const float mnew = fmaxf(mrun, tmax);       // finite from the first tile on: key 0 is never masked
+            const float alpha = expf(mrun - mnew);
+            float psum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { st[e] = expf(st[e] - mnew); psum += st[e]; }
+            psum += __shfl_xor(psum, 32, WAVE);
+            lrun = lrun * alpha + psum;
+            mrun = mnew;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[j][e] *= alpha;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 half8_t pf;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pf[e] = (half_t)(st[t][s * 8 + e] * inv);
+                for (int e = 0; e < 8; ++e) pf[e] = (half_t)st[s * 8 + e];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    // V^T fragment: column d = j*32 + ql, keys t*32 + 16s + 4hi + {0..3} and +8
+                    // V^T fragment: row d = j*32 + ql, keys t*32 + 16s + 4hi + {0..3} and the same + 8
                     const half_t* vp = Vt + (j * 32 + ql) * LV + t * 32 + s * 16 + hi * 4;
-                    half4_t v0 = *reinterpret_cast<const half4_t*>(vp);
-                    half4_t v1 = *reinterpret_cast<const half4_t*>(vp + 8);
-                    half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf, vf, o[j], 0, 0, 0);
+                    const half4_t v0 = *reinterpret_cast<const half4_t*>(vp);
+                    const half4_t v1 = *reinterpret_cast<const half4_t*>(vp + 8);
+                    const half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[j], 0, 0, 0);
                 }
             }
-        // O tile: col d = j*32 + (lane & 31), row q = qb*32 + (e&3) + 8*(e>>2) + 4*hi
+        }
+        // O^T tile: column q = lane & 31 (this lane's query), rows d = j*32 + 8*(e>>2) + 4*hi + (e&3)
+        if (q < L) {
+            const float inv = 1.f / lrun;
+            half_t* orow = out + ((size_t)b * L + q) * W + h * ATT_DH;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int qr = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                if (qr < L) out[((size_t)b * L + qr) * W + h * ATT_DH + j * 32 + ql] = (half_t)o[j][e];
-            }
+                for (int g = 0; g < 4; ++g) {
+                    half4_t hv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hv[e] = (half_t)(o[j][4 * g + e] * inv);
+                    *reinterpret_cast<half4_t*>(orow + j * 32 + 8 * g + 4 * hi) = hv;
+                }
+        }
     }
 }
 
@@ -320,10 +426,13 @@ extern "C" int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, vo
     PCLIP_REQUIRE(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0, "pclip_gemm_f16: bad leading dims");
     PCLIP_REQUIRE(act == 0 || act == 1, "pclip_gemm_f16: unknown activation %d", act);
     if (M == 0) return PCLIP_OK;
-    const int tiles_m = ceil_div(M, pgemm::BM), tiles_n = ceil_div(N, pgemm::BN);
+    const int tiles_m = ceil_div(M, pgemm::BM), tiles_n = ceil_div(N, pgemm::BN), ntiles = tiles_m * tiles_n;
     LinearEpi epi{(const half_t*)bias, (const half_t*)residual, (half_t*)C, ldc, act};
-    linear_kernel<<<tiles_m * tiles_n, 256, pgemm::LDS_BYTES, (hipStream_t)stream>>>(
-        (const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, tiles_n);
+    static int slots = 0;                        // 2 resident workgroups per CU (64 KiB LDS, <= 128 VGPRs each)
+    if (!slots) { slots = 2 * pclip_device_cus(); if (slots <= 0) slots = 512; }
+    const int grid = ntiles < slots ? ntiles : slots;
+    linear_kernel<<<grid, 256, pgemm::LDS_BYTES, (hipStream_t)stream>>>(
+        (const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, tiles_n, ntiles);
     return pclip_check_launch("gemm_f16");
 }
 
@@ -362,43 +471,26 @@ int pclip_layernorm_f16p(const void* x, const void* gamma, const void* beta, flo
     return pclip_check_launch("layernorm_f16p");
 }
 
-template <int NT>
-static int launch_attention(const void* qkv, void* out, int B, int L, int H, int causal, hipStream_t s) {
-    constexpr int LP = NT * 32;
-    constexpr int LV = (LP / 4) % 2 ? LP : LP + 4;
-    const size_t lds = (size_t)LP * ATT_DH * 2 + (size_t)ATT_DH * LV * 2;
-    auto kern = attention_kernel<NT>;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            pclip_set_error("pclip_attention_f16: cannot raise dynamic LDS to %zu", lds);
-            return PCLIP_E_LAUNCH;
-        }
-        attr_set = true;
-    }
-    kern<<<B * H, 256, lds, s>>>((const half_t*)qkv, (half_t*)out, L, H, causal);
-    return pclip_check_launch("attention");
-}
-
 extern "C" int pclip_attention_f16(const void* qkv, void* out, int B, int L, int H, int dh, int causal,
                                    pclip_stream_t stream) {
     PCLIP_REQUIRE(qkv && out, "pclip_attention_f16: null pointer");
     PCLIP_REQUIRE(dh == ATT_DH, "pclip_attention_f16: head dim %d unsupported (must be 64)", dh);
-    PCLIP_REQUIRE(B >= 0 && H > 0 && L > 0 && L <= ATT_MAX_TILES * 32, "pclip_attention_f16: bad B=%d H=%d L=%d (L <= %d)",
-                  B, H, L, ATT_MAX_TILES * 32);
+    PCLIP_REQUIRE(B >= 0 && H > 0 && L > 0 && L <= ATT_MAX_L, "pclip_attention_f16: bad B=%d H=%d L=%d (L <= %d)",
+                  B, H, L, ATT_MAX_L);
     if (B == 0) return PCLIP_OK;
-    hipStream_t s = (hipStream_t)stream;
-    switch (ceil_div(L, 32)) {
-        case 1: return launch_attention<1>(qkv, out, B, L, H, causal, s);
-        case 2: return launch_attention<2>(qkv, out, B, L, H, causal, s);
-        case 3: return launch_attention<3>(qkv, out, B, L, H, causal, s);
-        case 4: return launch_attention<4>(qkv, out, B, L, H, causal, s);
-        case 5: return launch_attention<5>(qkv, out, B, L, H, causal, s);
-        case 6: return launch_attention<6>(qkv, out, B, L, H, causal, s);
-        case 7: return launch_attention<7>(qkv, out, B, L, H, causal, s);
-        case 8: return launch_attention<8>(qkv, out, B, L, H, causal, s);
-        default: return launch_attention<9>(qkv, out, B, L, H, causal, s);
+    const int NT = ceil_div(L, 32), LP = NT * 32;
+    const int LV = (LP / 4) % 2 ? LP : LP + 4;
+    const size_t lds = (size_t)LP * ATT_DH * 2 + (size_t)ATT_DH * LV * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) {
+            pclip_set_error("pclip_attention_f16: cannot raise the dynamic LDS limit");
+            return PCLIP_E_LAUNCH;
+        }
+        attr_set = true;
     }
+    attention_kernel<<<B * H, 256, lds, (hipStream_t)stream>>>((const half_t*)qkv, (half_t*)out, L, H, causal, NT, LV);
+    return pclip_check_launch("attention");
 }
 
 extern "C" int pclip_im2col_patches_f16(const void* img, int B, int R, int P, void* cols, int ld,

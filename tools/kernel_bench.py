@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmarks on the shapes of the ImageNet ViT-B/16 configuration (used while tuning;
+bench.py is the judged benchmark).  Prints one line per case: time, TFLOP/s or GB/s."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from proto_clip_amd import ops  # noqa: E402
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--what", default="gemm,attn,ln,classify,adapter")
+    ap.add_argument("--imgs", type=int, default=128)
+    args = ap.parse_args()
+    what = args.what.split(",")
+    dev = "cuda"
+    B, L, W = args.imgs, 197, 768
+    M = B * L
+    if "gemm" in what:
+        for name, (m, n, k, act, res) in {"qkv": (M, 3 * W, W, 0, False), "out_proj": (M, W, W, 0, True),
+                                          "c_fc": (M, 4 * W, W, 1, False), "c_proj": (M, W, 4 * W, 0, True),
+                                          "patch": (B * 196, W, 768, 0, False), "sq4096": (4096, 4096, 4096, 0, False),
+                                          "sq8192": (8192, 8192, 8192, 0, False)}.items():
+            a = torch.randn(m, k, device=dev).half()
+            w = (torch.randn(n, k, device=dev) * k ** -0.5).half()
+            bias = torch.randn(n, device=dev).half()
+            r = torch.randn(m, n, device=dev).half() if res else None
+            out = torch.empty(m, n, device=dev, dtype=torch.float16)
+            t = timeit(lambda: ops.gemm(a, w, bias, act, r, out))
+            print(f"gemm {name:9s} M={m} N={n} K={k}: {t * 1e6:8.1f} us  {2.0 * m * n * k / t / 1e12:7.1f} TFLOP/s", flush=True)
+            t4 = timeit(lambda: ops.gemm(a, w, None, 0, None, out))
+            print(f"     plain (no bias/act/residual) {t4 * 1e6:8.1f} us  {2.0 * m * n * k / t4 / 1e12:7.1f} TFLOP/s", flush=True)
+    if "attn" in what:
+        for name, (b, l, h, causal) in {"vitb16": (B, 197, 12, False), "vitb32": (B, 50, 12, False), "vitl14": (B // 2, 257, 16, False),
+                                        "text": (1024, 77, 8, True)}.items():
+            qkv = torch.randn(b * l, 3 * h * 64, device=dev).half()
+            out = torch.empty(b * l, h * 64, device=dev, dtype=torch.float16)
+            t = timeit(lambda: ops.attention(qkv, b, l, h, causal, out))
+            fl = 4.0 * b * h * l * l * 64
+            print(f"attn {name:7s} B={b} L={l} H={h}: {t * 1e6:8.1f} us  {fl / t / 1e12:7.1f} TFLOP/s", flush=True)
+    if "ln" in what:
+        x = torch.randn(M, W, device=dev).half()
+        g, b_ = torch.ones(W, device=dev), torch.zeros(W, device=dev)
+        out = torch.empty_like(x)
+        t = timeit(lambda: ops.layernorm(x, g, b_, out=out))
+        print(f"layernorm [{M},{W}]: {t * 1e6:8.1f} us  {2.0 * M * W * 2 / t / 1e9:7.1f} GB/s", flush=True)
+    if "classify" in what:
+        Q, N, D = 50000, 1000, 512
+        q = torch.nn.functional.normalize(torch.randn(Q, D, device=dev), dim=-1).half()
+        zi = torch.nn.functional.normalize(torch.randn(N, D, device=dev), dim=-1).half()
+        zt = torch.nn.functional.normalize(torch.randn(N, D, device=dev), dim=-1).half()
+        t = timeit(lambda: ops.sqdist(q, zi, zt), iters=10)
+        print(f"sqdist Q={Q} N={N} D={D} (both banks): {t * 1e6:8.1f} us  {4.0 * Q * N * D / t / 1e12:7.1f} TFLOP/s", flush=True)
+        d2i, d2t, ldd = ops.sqdist(q, zi, zt)
+        t = timeit(lambda: ops.fuse_probs(d2i, d2t, N, 0.5, 12.0, want_p=False, want_argmax=True), iters=10)
+        print(f"fuse_probs argmax-only: {t * 1e6:8.1f} us  {2.0 * Q * ldd * 4 / t / 1e9:7.1f} GB/s", flush=True)
+        t = timeit(lambda: ops.fuse_probs(d2i, d2t, N, 0.5, 12.0, want_p=True), iters=10)
+        print(f"fuse_probs full p     : {t * 1e6:8.1f} us  {(2.0 * Q * ldd * 4 + Q * N * 4) / t / 1e9:7.1f} GB/s", flush=True)
+        t = timeit(lambda: ops.classify(q, zi, zt, 0.5, 12.0), iters=10)
+        print(f"classify (argmax) end to end: {t * 1e6:8.1f} us  {Q / t / 1e6:7.2f} M queries/s", flush=True)
+        import numpy as np
+        al, bl = np.arange(0, 1.1, 0.1).round(1), np.concatenate((np.arange(0.1, 1, 0.1), np.arange(1, 21, 1.0)))
+        lab = torch.randint(0, N, (Q,), device=dev)
+        t = timeit(lambda: ops.hp_sweep(d2i, d2t, N, lab, al, bl), iters=3, warm=1)
+        print(f"hp_sweep 319 pairs x {Q} queries: {t * 1e3:8.2f} ms", flush=True)
+        mem = torch.randn(16000, D, device=dev).half()
+        t = timeit(lambda: ops.proto_build(mem, 1000, 16))
+        print(f"proto_build N=1000 K=16 D=512: {t * 1e6:8.1f} us  {(16000 * D * 2 + 1000 * D * 2) / t / 1e9:7.1f} GB/s", flush=True)
+        t = timeit(lambda: ops.l2norm_rows(q))
+        print(f"l2norm_rows [{Q},{D}]: {t * 1e6:8.1f} us  {2.0 * Q * D * 2 / t / 1e9:7.1f} GB/s", flush=True)
+    if "adapter" in what:
+        from proto_clip_amd.model import Adapter, Adapter_FC
+        Q, D = 50000, 512
+        x = torch.nn.functional.normalize(torch.randn(Q, D, device=dev), dim=-1).half()
+        for kind in ("conv-3x", "conv-2x", "fc"):
+            ad = (Adapter_FC(D, dtype=torch.half) if kind == "fc" else Adapter(D, kind, dtype=torch.half)).cuda()
+            with torch.no_grad():
+                t = timeit(lambda: ad(x, l2norm_out=True), iters=5, warm=1)
+            print(f"adapter {kind:8s} Q={Q} D={D}: {t * 1e3:8.3f} ms  {Q / t / 1e6:7.2f} M rows/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
