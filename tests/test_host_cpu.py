@@ -35,7 +35,7 @@ def test_argument_validation_is_loud_and_precedes_any_launch():
     buf = ctypes.c_void_p(0x1000)      # never dereferenced: validation rejects first
     assert lib.pclip_l2norm_rows_f16(buf, buf, 4, 510, None, None) == -1
     assert b"multiple of 8" in lib.pclip_last_error()
-    assert lib.pclip_sqdist_f16(buf, buf, None, 4, 3, 72, None, None, None, buf, None, 3, None, 0, None) == -1
+    assert lib.pclip_sqdist_f16(buf, buf, None, 4, 3, 72, None, None, None, buf, None, 64, None, 0, None) == -1
     assert b"multiple of 64" in lib.pclip_last_error()
     assert lib.pclip_proto_build_f16(buf, 3, 0, 512, 1, buf, None, None, None) == -1
     assert lib.pclip_fuse_probs(buf, buf, 4, 5000, 5056, 0.5, 0.5, 1.0, buf, None, None, None, 0, None) == -1
