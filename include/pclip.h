@@ -138,6 +138,12 @@ int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, void* C, int 
 int pclip_layernorm_f16(const void* x, int ld_x, const float* gamma, const float* beta, float eps, void* y,
                         int R, int D, pclip_stream_t stream);
 
+/* Residual add fused into the following LayerNorm (clip/model.py:188-189 then ln_2 / next ln_1 / ln_post /
+ * ln_final): xs = r16(x + delta); x_out (nullable, may alias x; row stride ld) receives xs;
+ * y [R, D] = r16(LayerNorm(xs)).  x and delta rows are ld elements apart. */
+int pclip_add_layernorm_f16(const void* x, const void* delta, int ld, void* x_out, const float* gamma,
+                            const float* beta, float eps, void* y, int R, int D, pclip_stream_t stream);
+
 /* Multi-head self-attention core on a fused QKV buffer (nn.MultiheadAttention inside
  * ResidualAttentionBlock.attention, clip/model.py:183-185): qkv [B, L, 3*H*dh] fp16 (q|k|v blocks,
  * heads contiguous inside each) -> out [B, L, H*dh] fp16 = softmax(q k^T / sqrt(dh) [+causal]) v.

@@ -64,16 +64,24 @@ def _transformer(width, layers):
 
 
 def _run_blocks(x, blocks, B, L, heads, causal):
-    """x [B*L, W] fp16 -> same; ResidualAttentionBlock.forward (clip/model.py:187-190) per layer."""
+    """ResidualAttentionBlock.forward (clip/model.py:187-190) per layer on x [B*L, W] fp16.
+    Each residual add is fused into the LayerNorm that reads its result, so the stream of a block is
+        h = LN1(x [+ d])   qkv = in_proj(h)   a = attention(qkv)   d = out_proj(a)
+        h = LN2(x += d)    f = QuickGELU(c_fc(h))                  d = c_proj(f)
+    Returns (x, d): the block stack's output is x + d, left for the caller's final LayerNorm to fuse."""
+    d = None
     for blk in blocks:
-        h = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias)
+        if d is None:
+            h = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias)
+        else:
+            h = ops.add_layernorm(x, d, blk.ln_1.weight, blk.ln_1.bias)
         qkv = ops.gemm(h, blk.attn.in_proj_weight, blk.attn.in_proj_bias)
         a = ops.attention(qkv, B, L, heads, causal=causal)
-        x = ops.gemm(a, blk.attn.out_proj.weight, blk.attn.out_proj.bias, residual=x)
-        h = ops.layernorm(x, blk.ln_2.weight, blk.ln_2.bias)
+        d = ops.gemm(a, blk.attn.out_proj.weight, blk.attn.out_proj.bias)
+        h = ops.add_layernorm(x, d, blk.ln_2.weight, blk.ln_2.bias)
         f = ops.gemm(h, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, act=1)
-        x = ops.gemm(f, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, residual=x)
-    return x
+        d = ops.gemm(f, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)
+    return x, d
 
 
 class _Cached:
@@ -144,8 +152,11 @@ class VisionTransformer(nn.Module):
         patch = ops.gemm(cols, wconv)
         x = ops.vit_assemble_tokens(patch, cls16, pos16, B, G * G, W)       # clip/model.py:225-226
         x = ops.layernorm(x, self.ln_pre.weight, self.ln_pre.bias)          # 227
-        x = _run_blocks(x, self.transformer.resblocks, B, L, self.heads, causal=False)   # 229-231
-        cls = ops.layernorm(x, self.ln_post.weight, self.ln_post.bias, rows=B, ld=L * W)  # ln_post(x[:,0,:]) 233
+        x, d = _run_blocks(x, self.transformer.resblocks, B, L, self.heads, causal=False)   # 229-231
+        if d is None:
+            cls = ops.layernorm(x, self.ln_post.weight, self.ln_post.bias, rows=B, ld=L * W)
+        else:                                                               # ln_post((x + d)[:, 0, :]), 233
+            cls = ops.add_layernorm(x, d, self.ln_post.weight, self.ln_post.bias, update_x=False, rows=B, ld=L * W)
         return ops.gemm(cls, projT)                                         # x @ proj, 235-236
 
 
@@ -194,8 +205,11 @@ class CLIP(nn.Module):
         pos16 = self._cache.get("pos", self.positional_embedding, lambda t: t.half().contiguous())
         projT = self._cache.get("tprojT", self.text_projection, lambda t: t.t().contiguous())
         x = ops.text_embed(text, emb16, pos16)                                   # 342-344
-        x = _run_blocks(x, self.transformer.resblocks, B, L, self.transformer_heads, causal=True)   # 345-347
-        x = ops.layernorm(x, self.ln_final.weight, self.ln_final.bias)           # 348
+        x, d = _run_blocks(x, self.transformer.resblocks, B, L, self.transformer_heads, causal=True)   # 345-347
+        if d is None:
+            x = ops.layernorm(x, self.ln_final.weight, self.ln_final.bias)       # 348
+        else:
+            x = ops.add_layernorm(x, d, self.ln_final.weight, self.ln_final.bias, update_x=False)
         eot = ops.gather_eot(x, text, B, L, W)                                   # x[arange, text.argmax(-1)]
         return ops.gemm(eot, projT)                                              # @ text_projection, 352
 

@@ -20,11 +20,12 @@ __global__ __launch_bounds__(256, 2) void sqdist_kernel(const half_t* __restrict
     const int bank = blockIdx.y;
     const int swz = pgemm::xcd_remap(blockIdx.x, gridDim.x);
     const int tile_m = swz / tiles_n, tile_n = swz - tile_m * tiles_n;
-    const int m0 = tile_m * pgemm::BM, n0 = tile_n * pgemm::BN;
-    pgemm::Acc acc;
+    using C = pgemm::CfgSmall;
+    const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
+    pgemm::Acc<C> acc;
     int pbuf = 0;
-    pgemm::stage_first(q, D, bank ? zt : zi, D, Q, N, m0, n0, smem, 0);
-    pgemm::mainloop(q, D, bank ? zt : zi, D, Q, N, D, m0, n0, smem, acc, pbuf);
+    pgemm::stage_first<C>(q, D, bank ? zt : zi, D, Q, N, m0, n0, smem, 0);
+    pgemm::mainloop<C>(q, D, bank ? zt : zi, D, Q, N, D, m0, n0, smem, acc, pbuf);
     const float* __restrict__ z_sq = bank ? zt_sq : zi_sq;
     float* __restrict__ out = bank ? d2t : d2i;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1, hi = lane >> 5;
@@ -257,9 +258,9 @@ extern "C" int pclip_sqdist_f16(const void* q, const void* zi, const void* zt, i
         if (!zi_sq) { if ((e = pclip_row_sqnorm_f16(zi, N, D, w.zi_sq, stream))) return e; zi_sq = w.zi_sq; }
         if (zt && !zt_sq) { if ((e = pclip_row_sqnorm_f16(zt, N, D, w.zt_sq, stream))) return e; zt_sq = w.zt_sq; }
     }
-    const int tiles_m = ceil_div(Q, pgemm::BM), tiles_n = ceil_div(N, pgemm::BN);
+    const int tiles_m = ceil_div(Q, pgemm::CfgSmall::BM), tiles_n = ceil_div(N, pgemm::CfgSmall::BN);
     dim3 grid(tiles_m * tiles_n, zt ? 2 : 1);
-    sqdist_kernel<<<grid, 256, pgemm::LDS_BYTES, s>>>((const half_t*)q, (const half_t*)zi, (const half_t*)zt, Q, N, D,
+    sqdist_kernel<<<grid, 256, pgemm::CfgSmall::LDS_BYTES, s>>>((const half_t*)q, (const half_t*)zi, (const half_t*)zt, Q, N, D,
                                                       q_sq, zi_sq, zt_sq, d2i, d2t, ldd, tiles_n);
     return pclip_check_launch("sqdist");
 }

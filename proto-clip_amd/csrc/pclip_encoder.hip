@@ -3,6 +3,7 @@
 // bias / QuickGELU / residual epilogues, fp32-statistics LayerNorm, and a whole-sequence attention
 // kernel (the CLIP sequences, 50..257 tokens, fit one workgroup, so no online softmax is needed).
 #include "pclip_gemm.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -25,102 +26,152 @@ __device__ __forceinline__ float quick_gelu16(float v) {
     return r16(v * s);
 }
 
-// Persistent: gridDim.x <= 2 workgroups per CU; each walks output tiles round by round (round r covers tiles
-// [r*G, (r+1)*G), XCD-remapped inside the round so that one XCD's L2 sees neighbouring tiles).  The next
-// tile's first K-tile is already in flight while the epilogue of the current tile stages through LDS, and the
-// current tile's global stores drain under the next tile's K-loop instead of delaying workgroup exit.
-// Everything the epilogue needs from global memory (bias, residual) is loaded BEFORE the K-loop, so that it
-// lands behind the K-loop's first barrier and the epilogue itself never waits on the vector-memory counter
-// (which would also wait for the next tile's prefetch).
-__global__ __launch_bounds__(256, 2) void linear_kernel(const half_t* __restrict__ A, int lda,
-                                                        const half_t* __restrict__ B, int ldb, int M, int N, int K,
-                                                        LinearEpi epi, int tiles_n, int ntiles) {
+// ---- fast kernel: N % BN == 0, 16-byte aligned C rows, no residual -----------------------------------------
+// Persistent: one launch = at most `slots` resident workgroups; each walks output tiles round by round
+// (round r covers tiles [r*G, (r+1)*G), XCD-remapped inside the round so that one XCD's L2 sees
+// neighbouring tiles).  Around a tile boundary nothing drains the vector-memory counter:
+//   K-loop(i) -> glds of K-tile 0 of tile i+1 -> epilogue(i) on LDS-only barriers (stores stay in flight)
+//   -> bias glds(i+1) -> first barrier of K-loop(i+1) waits with vmcnt(#stores + 1): only the K-tile glds.
+// Every vector-memory operation of this kernel is an LDS-DMA or a store (the bias row of the tile also
+// travels by global_load_lds into a small double-buffered LDS strip), because hipcc answers any ordinary
+// VGPR load issued beside an LDS-DMA with a full vmcnt(0) drain at its use (guide §5, trap (b)).
+template <class C, bool HAS_BIAS, int ACT>
+__global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_t* __restrict__ A, int lda,
+                                                                     const half_t* __restrict__ B, int ldb, int M, int N,
+                                                                     int K, const half_t* __restrict__ bias,
+                                                                     half_t* __restrict__ Cout, int ldc, int tiles_n,
+                                                                     int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* bias_lds = reinterpret_cast<half_t*>(smem + C::LDS_BYTES);       // [2][BN] fp16
     const int G = gridDim.x;
     int tile = pgemm::xcd_remap(blockIdx.x, G);
     if (tile >= ntiles) return;
     int p = 0;
     {
         const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-        pgemm::stage_first(A, lda, B, ldb, M, N, tm * pgemm::BM, tn * pgemm::BN, smem, p);
+        pgemm::stage_first<C>(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, smem, p);
     }
-    const half_t* __restrict__ bias = epi.bias;
-    const half_t* __restrict__ residual = epi.residual;
-    const int act = epi.act;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wc = wave & 1, hi = lane >> 5;
-    const int c = threadIdx.x & 15;                       // row-major pass: 16-byte column chunk of this thread
-    const bool ldc_vec = (epi.ldc & 7) == 0;
-    for (; tile < ntiles; tile += G) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave % C::WN, hi = lane >> 5;
+    constexpr int YOUNGER = C::NH * C::NPASS + (HAS_BIAS ? 1 : 0);
+    bool prev_full = false;
+    int parity = 0;
+    for (; tile < ntiles; tile += G, parity ^= 1) {
         const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
-        const int m0 = tile_m * pgemm::BM, n0 = tile_n * pgemm::BN;
-        const int col = n0 + 8 * c;
-        const bool vec = (col + 7 < N) && ldc_vec;
-        // ---- epilogue operands, fetched up front ----
-        half4_t bv[2][4];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wc * 64 + j * 32 + 8 * g + 4 * hi;
-                half4_t b = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-                if (bias) {
-                    if (n + 3 < N) b = *reinterpret_cast<const half4_t*>(bias + n);     // n % 4 == 0: 8-byte aligned
-                    else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) b[e] = n + e < N ? bias[n + e] : (half_t)0.f;
-                    }
-                }
-                bv[j][g] = b;
-            }
-        half8_t rs[8];
-        if (residual && vec) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = m0 + (threadIdx.x >> 4) + 16 * i;
-                rs[i] = ld_half8(residual + (size_t)(row < M ? row : M - 1) * epi.ldc + col);
-            }
-        }
-        pgemm::Acc acc;
-        pgemm::mainloop(A, lda, B, ldb, M, N, K, m0, n0, smem, acc, p);
+        const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
+        const bool full = m0 + C::BM <= M;                    // workgroup-uniform: every row of the tile exists
+        half_t* bl = bias_lds + parity * C::BN;
+        if (HAS_BIAS && lane < C::BN / 8)                     // every wave copies the same BN biases: uniform vmcnt bookkeeping
+            __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(bias + n0 + lane * 8), (pgemm::lds_ptr_t)bl, 16, 0, 0);
+        pgemm::Acc<C> acc;
+        pgemm::mainloop<C, YOUNGER>(A, lda, B, ldb, M, N, K, m0, n0, smem, acc, p, prev_full);
+        pgemm::wait_vm<0>();                                  // free unless K == 64: the bias strip has landed
         const int next = tile + G;
         if (next < ntiles) {                                  // buffer p is free: prefetch the next tile's K-tile 0
             const int tm = next / tiles_n, tn = next - tm * tiles_n;
-            pgemm::stage_first(A, lda, B, ldb, M, N, tm * pgemm::BM, tn * pgemm::BN, smem, p);
+            pgemm::stage_first<C>(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, smem, p);
         }
-        char* stg = smem + (p ^ 1) * 2 * pgemm::TILE_BYTES;   // buffer of the last K-tile, reused after a barrier
-        pgemm::stage_out_f16(acc, stg, [&](int j, int g, float4_t v) {
+        char* stg = smem + (p ^ 1) * C::STAGE_BYTES;          // buffer of the last K-tile, reused after a barrier
+        const int col = n0 + 8 * (tid % C::CPR);
+        auto pre = [&](int, int j, int g, float4_t v) {
+            half4_t h, b = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+            if (HAS_BIAS) b = *reinterpret_cast<const half4_t*>(bl + wn * (C::BN / C::WN) + j * 32 + 8 * g + 4 * hi);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = r16(v[e] + (float)b[e]);
+                if (ACT == 1) x = quick_gelu16(x);
+                h[e] = (half_t)x;
+            }
+            return h;
+        };
+        if (full)
+            pgemm::epilogue_f16<C>(acc, stg, [](int) {}, pre,
+                                   [&](int r, int, int, half8_t h) { st_half8(Cout + (size_t)(m0 + r) * ldc + col, h); });
+        else
+            pgemm::epilogue_f16<C>(acc, stg, [](int) {}, pre, [&](int r, int, int, half8_t h) {
+                if (m0 + r < M) st_half8(Cout + (size_t)(m0 + r) * ldc + col, h);
+            });
+        prev_full = full;
+    }
+}
+
+// ---- generic kernel: any M, N, leading dimensions; optional residual; one 128x128 tile per workgroup ------
+__global__ __launch_bounds__(256, 2) void linear_generic_kernel(const half_t* __restrict__ A, int lda,
+                                                                const half_t* __restrict__ B, int ldb, int M, int N,
+                                                                int K, LinearEpi epi, int tiles_n) {
+    using C = pgemm::CfgSmall;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int swz = pgemm::xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = swz / tiles_n, tile_n = swz - tile_m * tiles_n;
+    const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave % C::WN, hi = lane >> 5;
+    int p = 0;
+    pgemm::stage_first<C>(A, lda, B, ldb, M, N, m0, n0, smem, p);
+    pgemm::Acc<C> acc;
+    pgemm::mainloop<C, 0>(A, lda, B, ldb, M, N, K, m0, n0, smem, acc, p, false);
+    const half_t* __restrict__ bias = epi.bias;
+    const half_t* __restrict__ residual = epi.residual;
+    const int act = epi.act, ldc = epi.ldc;
+    const int col = n0 + 8 * (tid % C::CPR);
+    pgemm::epilogue_f16<C>(
+        acc, smem + (p ^ 1) * C::STAGE_BYTES, [](int) {},
+        [&](int, int j, int g, float4_t v) {
+            const int n = n0 + wn * (C::BN / C::WN) + j * 32 + 8 * g + 4 * hi;
             half4_t h;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float x = r16(v[e] + (float)bv[j][g][e]);
+                float x = v[e];
+                if (bias) x += (float)bias[n + e < N ? n + e : N - 1];
+                x = r16(x);
                 if (act == 1) x = quick_gelu16(x);
                 h[e] = (half_t)x;
             }
             return h;
-        });
-        // ---- row-major pass: thread -> (row r, 8 columns 8c .. 8c+7) ----
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = (threadIdx.x >> 4) + 16 * i;
+        },
+        [&](int r, int, int, half8_t h) {
             const int row = m0 + r;
-            if (row >= M || col >= N) continue;
-            half8_t h = pgemm::staged_row_chunk(stg, r, c);
-            const size_t o = (size_t)row * epi.ldc + col;
-            if (vec) {
-                if (residual) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) h[e] = (half_t)((float)rs[i][e] + (float)h[e]);
-                }
-                st_half8(epi.C + o, h);
-            } else {
-                for (int e = 0; e < 8 && col + e < N; ++e) {
-                    float x = (float)h[e];
-                    if (residual) x = (float)residual[o + e] + x;
-                    epi.C[o + e] = (half_t)x;
-                }
+            if (row >= M || col >= N) return;
+            const size_t o = (size_t)row * ldc + col;
+            for (int e = 0; e < 8 && col + e < N; ++e) {
+                float x = (float)h[e];
+                if (residual) x = (float)residual[o + e] + x;
+                epi.C[o + e] = (half_t)x;
             }
+        });
+}
+
+using CfgBig = pgemm::Cfg<256, 256, 2, 4>;
+using CfgWide = pgemm::Cfg<256, 128, 4, 2>;
+using CfgSmall = pgemm::CfgSmall;
+
+template <class C, bool HAS_BIAS, int ACT>
+static int launch_fast2(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const LinearEpi& epi,
+                        int slots, hipStream_t s) {
+    static bool attr = false;
+    constexpr int LDS = C::LDS_BYTES + 2 * C::BN * 2;          // K-tile ring + double-buffered bias strip
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)linear_fast_kernel<C, HAS_BIAS, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                LDS) != hipSuccess) {
+            pclip_set_error("pclip_gemm_f16: cannot raise the dynamic LDS limit to %d", LDS);
+            return PCLIP_E_LAUNCH;
         }
+        attr = true;
     }
+    const int tiles_m = ceil_div(M, C::BM), tiles_n = N / C::BN, ntiles = tiles_m * tiles_n;
+    const int grid = ntiles < slots ? ntiles : slots;
+    linear_fast_kernel<C, HAS_BIAS, ACT><<<grid, C::NTHREADS, LDS, s>>>(
+        (const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi.bias, epi.C, epi.ldc, tiles_n, ntiles);
+    return pclip_check_launch("gemm_f16");
+}
+
+template <class C>
+static int launch_fast(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const LinearEpi& epi,
+                       int slots, hipStream_t s) {
+    if (epi.bias) {
+        if (epi.act == 1) return launch_fast2<C, true, 1>(A, lda, B, ldb, M, N, K, epi, slots, s);
+        return launch_fast2<C, true, 0>(A, lda, B, ldb, M, N, K, epi, slots, s);
+    }
+    if (epi.act == 1) return launch_fast2<C, false, 1>(A, lda, B, ldb, M, N, K, epi, slots, s);
+    return launch_fast2<C, false, 0>(A, lda, B, ldb, M, N, K, epi, slots, s);
 }
 
 // ---- LayerNorm, one wave per row ----------------------------------------------------------------
@@ -200,6 +251,67 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
         if (MODE == 1 && sq_out) {
             ss = wave_sum(ss);
             if (lane == 0) sq_out[row] = ss;
+        }
+    }
+}
+
+// Residual add fused into the next LayerNorm (clip/model.py:188-189 followed by ln_2 / the next block's ln_1 /
+// ln_post / ln_final): xs = r16(x + delta) is (optionally) stored back and y = r16(LN(xs)).  Keeping the
+// residual out of the GEMM epilogues lets those run without a single ordinary vector load.
+template <int NCH>
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const half_t* __restrict__ x, const half_t* __restrict__ delta,
+                                                            int ld, half_t* x_out, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps,
+                                                            half_t* __restrict__ y, int R, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
+        const half_t* xr = x + (size_t)row * ld;
+        const half_t* dr = delta + (size_t)row * ld;
+        float v[NCH][8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int d = c * 512 + lane * 8;
+            if (d < D) {
+                const half8_t a = ld_half8(xr + d), b = ld_half8(dr + d);
+                half8_t o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    o[j] = (half_t)((float)a[j] + (float)b[j]);
+                    v[c][j] = (float)o[j];
+                    s += v[c][j];
+                }
+                if (x_out) st_half8(x_out + (size_t)row * ld + d, o);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+            }
+        }
+        const float mean = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int d = c * 512 + lane * 8;
+            if (d < D) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float t = v[c][j] - mean; q += t * t; }
+            }
+        }
+        const float rstd = 1.f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int d = c * 512 + lane * 8;
+            if (d < D) {
+                const float4_t g0 = *reinterpret_cast<const float4_t*>(gamma + d), g1 = *reinterpret_cast<const float4_t*>(gamma + d + 4);
+                const float4_t b0 = *reinterpret_cast<const float4_t*>(beta + d), b1 = *reinterpret_cast<const float4_t*>(beta + d + 4);
+                half8_t o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = (half_t)((v[c][j] - mean) * rstd * g0[j] + b0[j]);
+                    o[j + 4] = (half_t)((v[c][j + 4] - mean) * rstd * g1[j] + b1[j]);
+                }
+                st_half8(y + (size_t)row * D + d, o);
+            }
         }
     }
 }
@@ -426,14 +538,38 @@ extern "C" int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, vo
     PCLIP_REQUIRE(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0, "pclip_gemm_f16: bad leading dims");
     PCLIP_REQUIRE(act == 0 || act == 1, "pclip_gemm_f16: unknown activation %d", act);
     if (M == 0) return PCLIP_OK;
-    const int tiles_m = ceil_div(M, pgemm::BM), tiles_n = ceil_div(N, pgemm::BN), ntiles = tiles_m * tiles_n;
     LinearEpi epi{(const half_t*)bias, (const half_t*)residual, (half_t*)C, ldc, act};
-    static int slots = 0;                        // 2 resident workgroups per CU (64 KiB LDS, <= 128 VGPRs each)
-    if (!slots) { slots = 2 * pclip_device_cus(); if (slots <= 0) slots = 512; }
-    const int grid = ntiles < slots ? ntiles : slots;
-    linear_kernel<<<grid, 256, pgemm::LDS_BYTES, (hipStream_t)stream>>>(
-        (const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, tiles_n, ntiles);
-    return pclip_check_launch("gemm_f16");
+    static int cus = 0;
+    static int forced = -1;
+    if (!cus) {
+        cus = pclip_device_cus();
+        if (cus <= 0) cus = 256;
+        const char* f = getenv("PCLIP_GEMM_CFG");          // tuning override: 0 small, 1 wide, 2 big, 3 generic
+        forced = f ? atoi(f) : -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const bool aligned = !residual && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0);
+    // Tile choice among the configurations whose BN divides N: estimated time = rounds of resident workgroups
+    // x tile area / relative K-loop rate of the configuration (measured on MI355X, tools/kernel_bench.py).
+    auto cost = [&](int bm, int bn, int slots, double eff) {
+        if (!aligned || N % bn) return 1e30;
+        const long nt = (long)ceil_div(M, bm) * (N / bn);
+        return (double)((nt + slots - 1) / slots) * bm * bn * (slots / (double)cus) / eff;
+    };
+    const double c_small = cost(128, 128, 2 * cus, 0.85), c_wide = cost(256, 128, cus, 0.85), c_big = cost(256, 256, cus, 1.0);
+    int pick = 3;
+    double best = 1e29;
+    if (c_small < best) { best = c_small; pick = 0; }
+    if (c_wide < best) { best = c_wide; pick = 1; }
+    if (c_big < best) { best = c_big; pick = 2; }
+    if (forced >= 0 && (forced == 3 || cost(forced == 2 ? 256 : (forced == 1 ? 256 : 128), forced == 2 ? 256 : 128, cus, 1.0) < 1e29)) pick = forced;
+    if (pick == 2) return launch_fast<CfgBig>(A, lda, B, ldb, M, N, K, epi, cus, s);
+    if (pick == 1) return launch_fast<CfgWide>(A, lda, B, ldb, M, N, K, epi, cus, s);
+    if (pick == 0) return launch_fast<CfgSmall>(A, lda, B, ldb, M, N, K, epi, 2 * cus, s);
+    const int tiles_m = ceil_div(M, 128), tiles_n = ceil_div(N, 128);
+    linear_generic_kernel<<<tiles_m * tiles_n, 256, CfgSmall::LDS_BYTES, s>>>((const half_t*)A, lda, (const half_t*)B, ldb,
+                                                                             M, N, K, epi, tiles_n);
+    return pclip_check_launch("gemm_f16 (generic)");
 }
 
 #define DISPATCH_NCH(D, CALL)                                  \
@@ -453,6 +589,17 @@ extern "C" int pclip_layernorm_f16(const void* x, int ld_x, const float* gamma, 
     DISPATCH_NCH(D, (layernorm_kernel<NCH, float, 0><<<row_grid(R), 256, 0, (hipStream_t)stream>>>(
                         (const half_t*)x, ld_x, gamma, beta, eps, (half_t*)y, R, D, nullptr, 0.f, 0.f, 0, nullptr)));
     return pclip_check_launch("layernorm");
+}
+
+extern "C" int pclip_add_layernorm_f16(const void* x, const void* delta, int ld, void* x_out, const float* gamma,
+                                       const float* beta, float eps, void* y, int R, int D, pclip_stream_t stream) {
+    PCLIP_REQUIRE(x && delta && gamma && beta && y, "pclip_add_layernorm_f16: null pointer");
+    PCLIP_REQUIRE(D > 0 && D % 8 == 0 && D <= 4096 && ld >= D && ld % 8 == 0 && R >= 0,
+                  "pclip_add_layernorm_f16: bad shape R=%d D=%d ld=%d", R, D, ld);
+    if (R == 0) return PCLIP_OK;
+    DISPATCH_NCH(D, (add_layernorm_kernel<NCH><<<row_grid(R), 256, 0, (hipStream_t)stream>>>(
+                        (const half_t*)x, (const half_t*)delta, ld, (half_t*)x_out, gamma, beta, eps, (half_t*)y, R, D)));
+    return pclip_check_launch("add_layernorm");
 }
 
 // internal (used by pclip_adapter.hip): LayerNorm with fp16 affine parameters, optional Adapter_FC blend

@@ -2,16 +2,17 @@
 // K-contiguous — the layout of every contraction on the Proto-CLIP path: queries x prototypes
 // (utils.py:230-233) and activations x nn.Linear weights (clip/model.py:176-178)).
 //
-// Tile: 128 x 128 x 64 per 256-thread workgroup (4 waves in a 2x2 grid, 64x64 per wave as 2x2
-// v_mfma_f32_32x32x16_f16 accumulators = 64 accumulator registers).  Staging: global_load_lds_dwordx4
-// straight into a double-buffered 64 KiB LDS image (no VGPR round trip); because the LDS destination of
-// that instruction is lane-linear, the bank-conflict swizzle is applied to the per-lane SOURCE address
-// and undone on the ds_read_b128 side (guide §5.4 rule 21): LDS slot (row, s) holds global 16-byte chunk
-// s ^ ((row >> 1) & 7) of that row, which makes every 16-lane group of a ds_read_b128 fragment read hit
-// 16 distinct 16-byte slots of the 256-byte bank row (conflict-free).  One barrier per K-tile; the next
-// tile's loads are in flight while the current one feeds the matrix cores; two workgroups per CU overlap
-// each other's barrier stalls.  Workgroup ids are remapped so each XCD (private L2) walks a contiguous run
-// of tiles.
+// Tile configurations (template Cfg): BM x BN x 64 per workgroup of WM x WN waves, each wave owning a
+// (BM/WM) x (BN/WN) block as TM x TN accumulators of v_mfma_f32_32x32x16_f16.
+//   Cfg<256,256,2,4>  512 threads, 128 acc VGPRs/lane, 128 KiB LDS, 1 workgroup/CU — large GEMMs
+//   Cfg<256,128,4,2>  512 threads,  64 acc VGPRs/lane,  96 KiB LDS, 1 workgroup/CU — N = 768-wide layers
+//   Cfg<128,128,2,2>  256 threads,  64 acc VGPRs/lane,  64 KiB LDS, 2 workgroups/CU — small problems
+// Staging: global_load_lds_dwordx4 straight into a double-buffered LDS image (no VGPR round trip); because
+// the LDS destination of that instruction is lane-linear, the bank-conflict swizzle is applied to the
+// per-lane SOURCE address and undone on the ds_read_b128 side (guide §5.4 rule 21): LDS slot (row, s) holds
+// global 16-byte chunk s ^ ((row >> 1) & 7) of that row, which makes every 16-lane group of a ds_read_b128
+// fragment read hit 16 distinct 16-byte slots of the 256-byte bank row (conflict-free).  One barrier per
+// K-tile; the next tile's loads are in flight while the current one feeds the matrix cores.
 //
 // The MFMA operands are SWAPPED (D = Btile . Atile^T), so a lane owns ONE output row m and, per
 // accumulator register quad, FOUR CONSECUTIVE output columns: epilogues get float4 / half4 vectors.
@@ -20,32 +21,66 @@
 
 namespace pgemm {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;            // 16 KiB per operand tile
-constexpr int LDS_BYTES = 4 * TILE_BYTES;          // A0 B0 A1 B1
+constexpr int BK = 64;
+constexpr int ROW_BYTES = BK * 2;                  // 128 B of K per tile row
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
+template <int BM_, int BN_, int WM_, int WN_>
+struct Cfg {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+    static constexpr int NWAVES = WM * WN, NTHREADS = NWAVES * 64;
+    static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;      // 32x32 accumulators per wave
+    static constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
+    static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    // epilogue: the output tile passes through LDS in NH row-slabs of HR rows (HR * BN * 2 <= STAGE_BYTES)
+    static constexpr int HR = 128, NH = BM / HR;
+    static constexpr int CPR = BN / 8;                               // 16-byte chunks per output row
+    static constexpr int ROWS_PER_PASS = NTHREADS / CPR, NPASS = HR / ROWS_PER_PASS;
+    static_assert(HR * BN * 2 <= STAGE_BYTES, "epilogue slab must fit one stage buffer");
+    static_assert(BM % (8 * NWAVES) == 0 && BN % (8 * NWAVES) == 0, "tile rows must split over the waves");
+};
+using CfgSmall = Cfg<128, 128, 2, 2>;
+
 __device__ __forceinline__ int swz_key(int row) { return (row >> 1) & 7; }
 
-// One wave stages rows [wave*32, wave*32+32) of a 128-row tile: 4 x (8 rows x 128 B) glds pieces.
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the vector-memory
+// counter, so global stores and LDS-DMA prefetches stay in flight across it (guide §5 "Pipelining across
+// barriers").  Every LDS read/write issued before it has completed (lgkmcnt(0)) when the wave arrives.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// Wait until at most N of this wave's vector-memory operations (in issue order) are outstanding.
+// Uses the builtin (not inline asm) so that the compiler's own wait-count bookkeeping sees it.
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    // gfx9 s_waitcnt immediate: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]; exp/lgkm left at max
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+
+// All waves of the workgroup stage a ROWS x 64 tile: each glds piece is 8 rows x 128 B (64 lanes x 16 B).
+template <int ROWS, int NWAVES>
 __device__ __forceinline__ void stage_tile(const half_t* __restrict__ g, int ld, int row0, int nrows, int k0,
                                            char* lds_tile, int wave, int lane) {
+    constexpr int RPW = ROWS / NWAVES;                               // rows per wave
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = wave * 32 + i * 8 + (lane >> 3);           // tile row this lane fills
-        const int c = (lane & 7) ^ swz_key(r);                   // source chunk for LDS slot (lane&7)
+    for (int i = 0; i < RPW / 8; ++i) {
+        const int r = wave * RPW + i * 8 + (lane >> 3);              // tile row this lane fills
+        const int c = (lane & 7) ^ swz_key(r);                       // source chunk for LDS slot (lane&7)
         int gr = row0 + r;
-        gr = gr < nrows ? gr : nrows - 1;                        // clamp: out-of-range rows are never stored
+        gr = gr < nrows ? gr : nrows - 1;                            // clamp: out-of-range rows are never stored
         const half_t* src = g + (size_t)gr * ld + k0 + c * 8;
-        char* dst = lds_tile + (wave * 32 + i * 8) * (BK * 2);   // wave-uniform base; HW adds lane*16
+        char* dst = lds_tile + (wave * RPW + i * 8) * ROW_BYTES;     // wave-uniform base; HW adds lane*16
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
     }
 }
 
 __device__ __forceinline__ half8_t lds_frag(const char* lds_tile, int row, int kc) {
-    return *reinterpret_cast<const half8_t*>(lds_tile + row * (BK * 2) + ((kc ^ swz_key(row)) << 4));
+    return *reinterpret_cast<const half8_t*>(lds_tile + row * ROW_BYTES + ((kc ^ swz_key(row)) << 4));
 }
 
 // XCD-aware, bijective remap of a linear workgroup id (guide §5.5 T1).
@@ -55,57 +90,75 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
-// Accumulator layout after mainloop(): acc[i][j][e] is C[m][n] with
-//   m = m0 + wr*64 + i*32 + (lane & 31)
-//   n = n0 + wc*64 + j*32 + 8*(e >> 2) + 4*(lane >> 5) + (e & 3)
+// Accumulator layout after mainloop(): acc.v[i][j][e] is C[m][n] with (wm, wn = wave / WN, wave % WN)
+//   m = m0 + wm*(BM/WM) + i*32 + (lane & 31)
+//   n = n0 + wn*(BN/WN) + j*32 + 8*(e >> 2) + 4*(lane >> 5) + (e & 3)
+template <class C>
 struct Acc {
-    float16_t v[2][2];
+    float16_t v[C::TM][C::TN];
 };
+
+// Stage K-tile 0 of output tile (m0, n0) into buffer p.
+template <class C>
+__device__ __forceinline__ void stage_first(const half_t* __restrict__ A, int lda, const half_t* __restrict__ B, int ldb,
+                                            int M, int N, int m0, int n0, char* smem, int p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* a = smem + p * C::STAGE_BYTES;
+    stage_tile<C::BM, C::NWAVES>(A, lda, m0, M, 0, a, wave, lane);
+    stage_tile<C::BN, C::NWAVES>(B, ldb, n0, N, 0, a + C::A_BYTES, wave, lane);
+}
 
 // K-loop over a tile whose K-tile 0 has ALREADY been staged into buffer `p` (0/1) by stage_first().
 // On return `p` names the FREE buffer (the one that held K-tile nt-2): a persistent caller stages the next
 // output tile's K-tile 0 there before running its epilogue out of the other buffer.
-__device__ __forceinline__ void stage_first(const half_t* __restrict__ A, int lda, const half_t* __restrict__ B, int ldb,
-                                            int M, int N, int m0, int n0, char* smem, int p) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    char* a = smem + p * 2 * TILE_BYTES;
-    stage_tile(A, lda, m0, M, 0, a, wave, lane);
-    stage_tile(B, ldb, n0, N, 0, a + TILE_BYTES, wave, lane);
-}
-
+// YOUNGER = number of vector-memory operations this wave issued AFTER the K-tile-0 staging and that may stay
+// in flight across the first barrier (epilogue stores of the previous tile, bias loads): the first wait is
+// vmcnt(YOUNGER) instead of a full drain.
+template <class C, int YOUNGER = 0>
 __device__ __forceinline__ void mainloop(const half_t* __restrict__ A, int lda, const half_t* __restrict__ B, int ldb,
-                                         int M, int N, int K, int m0, int n0, char* smem, Acc& acc, int& p) {
+                                         int M, int N, int K, int m0, int n0, char* smem, Acc<C>& acc, int& p,
+                                         bool counted_first = false) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wm = wave / C::WN, wn = wave % C::WN;
     const int nt = K / BK;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < C::TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < C::TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc.v[i][j][e] = 0.f;
 
     for (int t = 0; t < nt; ++t) {
-        __syncthreads();   // drains this wave's glds (vmcnt(0)) and orders all waves: tile t is in LDS
-        const char* la = smem + p * 2 * TILE_BYTES;
-        const char* lb = la + TILE_BYTES;
-        if (t + 1 < nt) {
-            char* na = smem + (p ^ 1) * 2 * TILE_BYTES;
-            stage_tile(A, lda, m0, M, (t + 1) * BK, na, wave, lane);
-            stage_tile(B, ldb, n0, N, (t + 1) * BK, na + TILE_BYTES, wave, lane);
-        }
+        // this wave's share of K-tile t has landed; the barrier then publishes every wave's share
+        if (t == 0 && counted_first) wait_vm<YOUNGER>(); else wait_vm<0>();
+        lds_barrier();
+        const char* la = smem + p * C::STAGE_BYTES;
+        const char* lb = la + C::A_BYTES;
+        // The two waves that share a SIMD (wave w and w + NWAVES/2) issue the next tile's LDS-DMA at different
+        // points of the iteration, so that one of them feeds the matrix pipe while the other spends its ~400
+        // cycles of address arithmetic / M0 set-up.
+        const bool late = C::NWAVES == 8 && __builtin_amdgcn_readfirstlane(wave) >= 4;
+        auto stage_next = [&]() {
+            if (t + 1 < nt) {
+                char* na = smem + (p ^ 1) * C::STAGE_BYTES;
+                stage_tile<C::BM, C::NWAVES>(A, lda, m0, M, (t + 1) * BK, na, wave, lane);
+                stage_tile<C::BN, C::NWAVES>(B, ldb, n0, N, (t + 1) * BK, na + C::A_BYTES, wave, lane);
+            }
+        };
+        if (!late) stage_next();
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
+            if (ks == BK / 32 && late) stage_next();
             const int kc = ks * 2 + (lane >> 5);
-            half8_t af[2], bf[2];
+            half8_t af[C::TM], bf[C::TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = lds_frag(la, wr * 64 + i * 32 + (lane & 31), kc);
+            for (int i = 0; i < C::TM; ++i) af[i] = lds_frag(la, wm * (C::BM / C::WM) + i * 32 + (lane & 31), kc);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = lds_frag(lb, wc * 64 + j * 32 + (lane & 31), kc);
+            for (int j = 0; j < C::TN; ++j) bf[j] = lds_frag(lb, wn * (C::BN / C::WN) + j * 32 + (lane & 31), kc);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < C::TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < C::TN; ++j)
                     acc.v[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc.v[i][j], 0, 0, 0);
         }
         p ^= 1;
@@ -113,37 +166,51 @@ __device__ __forceinline__ void mainloop(const half_t* __restrict__ A, int lda, 
 }
 
 // ---- fp16 output through an LDS-staged, fully coalesced epilogue -----------------------------------------
-// Step 1 (MFMA layout): `pre(j, g, v4)` turns four consecutive-column accumulators (columns
-// n0 + wc*64 + j*32 + 8g + 4*(lane>>5) + 0..3) into the fp16-rounded
-// values (bias / activation), written as 8-byte units into a [128][128] fp16 LDS image whose units are
-// XOR-swizzled by 2*(row & 15) (conflict-free ds_write_b64, pairs of units stay adjacent).
-// Step 2 (row-major): each thread owns 8 consecutive columns of a row: one ds_read_b128, optional 16-byte
-// residual load, one 16-byte global store — a wave instruction covers 4 rows x 256 contiguous bytes.
-template <class Pre>
-__device__ __forceinline__ void stage_out_f16(const Acc& acc, char* smem /* 32 KiB region */, const Pre& pre) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1, hi = lane >> 5;
-    __syncthreads();   // every wave is done reading the last K-tile
+// The BM x BN tile leaves in NH slabs of HR = 128 rows.  For slab h:
+//  step 0 `slab(h)`: caller hook before the slab is staged;
+//  step 1 (MFMA layout, waves owning rows of the slab): `pre(i, j, g, v4)` turns four consecutive-column
+//          accumulators into fp16 values (bias / activation); they are written as 8-byte units into a
+//          [HR][BN] fp16 LDS image with unit' = unit ^ (row & 15)  (conflict-free ds_write_b64);
+//  step 2 (row-major, all waves): `post(row_in_tile, chunk, pass, half8)` receives 8 consecutive columns of a
+//          row (one ds_read_b128; the XOR may swap the two 8-byte halves) — a wave instruction covers whole
+//          512-byte / 256-byte row segments: 16-byte fully coalesced global stores.
+template <class C, class Slab, class Pre, class Post>
+__device__ __forceinline__ void epilogue_f16(const Acc<C>& acc, char* stg, const Slab& slab, const Pre& pre, const Post& post) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / C::WN, wn = wave % C::WN, hi = lane >> 5;
+    constexpr int RB = C::BN * 2;                                    // bytes per staged row
+    constexpr int WROWS = C::BM / C::WM;                             // rows per wave
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int ml = wr * 64 + i * 32 + (lane & 31);
+    for (int h = 0; h < C::NH; ++h) {
+        slab(h);           // caller hook: e.g. issue this slab's residual loads so they fly during the staging
+        lds_barrier();     // slab buffer free: K-loop reads (h = 0) / previous slab's row-major reads are done
+        if ((wm * WROWS) / C::HR == h) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < C::TM; ++i) {
+                const int ml = (wm * WROWS) % C::HR + i * 32 + (lane & 31);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nl = wc * 64 + j * 32 + 8 * g + 4 * hi;
-                float4_t v = {acc.v[i][j][4 * g], acc.v[i][j][4 * g + 1], acc.v[i][j][4 * g + 2], acc.v[i][j][4 * g + 3]};
-                const half4_t h = pre(j, g, v);
-                const int unit = (nl >> 2) ^ ((ml & 15) << 1);
-                *reinterpret_cast<half4_t*>(smem + ml * 256 + unit * 8) = h;
+                for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nl = wn * (C::BN / C::WN) + j * 32 + 8 * g + 4 * hi;
+                        float4_t v = {acc.v[i][j][4 * g], acc.v[i][j][4 * g + 1], acc.v[i][j][4 * g + 2], acc.v[i][j][4 * g + 3]};
+                        const half4_t hv = pre(i, j, g, v);
+                        const int unit = (nl >> 2) ^ (ml & 15);
+                        *reinterpret_cast<half4_t*>(stg + ml * RB + unit * 8) = hv;
+                    }
             }
+        }
+        lds_barrier();
+        const int c = tid % C::CPR;
+#pragma unroll
+        for (int ps = 0; ps < C::NPASS; ++ps) {
+            const int r = tid / C::CPR + ps * C::ROWS_PER_PASS;       // row inside the slab
+            const int pair = c ^ ((r & 15) >> 1);
+            half8_t hv = *reinterpret_cast<const half8_t*>(stg + r * RB + pair * 16);
+            if (r & 1) hv = half8_t{hv[4], hv[5], hv[6], hv[7], hv[0], hv[1], hv[2], hv[3]};
+            post(h * C::HR + r, c, h * C::NPASS + ps, hv);
+        }
     }
-    __syncthreads();
-}
-
-__device__ __forceinline__ half8_t staged_row_chunk(const char* smem, int r, int c) {
-    const int unit = (2 * c) ^ ((r & 15) << 1);
-    return *reinterpret_cast<const half8_t*>(smem + r * 256 + unit * 8);
 }
 
 }  // namespace pgemm

@@ -250,6 +250,21 @@ def layernorm(x, gamma, beta, eps: float = 1e-5, out=None, rows: int = None, ld:
     return out
 
 
+def add_layernorm(x, delta, gamma, beta, eps: float = 1e-5, out=None, update_x: bool = True, rows: int = None,
+                  ld: int = None):
+    """xs = r16(x + delta) (written back into x when update_x) and returns r16(LayerNorm(xs)): the residual add of
+    clip/model.py:188-189 fused into the LayerNorm that consumes it."""
+    require_cuda(x, delta, gamma, beta)
+    D = x.shape[-1]
+    R = x.numel() // D if rows is None else rows
+    ld = D if ld is None else ld
+    if out is None:
+        out = torch.empty(R, D, dtype=torch.float16, device=x.device)
+    check(_lib.load().pclip_add_layernorm_f16(ptr(x), ptr(delta), ld, ptr(x) if update_x else None, ptr(gamma), ptr(beta),
+                                              eps, ptr(out), R, D, stream()), "pclip_add_layernorm_f16")
+    return out
+
+
 def attention(qkv, B: int, L: int, H: int, causal: bool = False, out=None):
     require_cuda(qkv)
     W = H * 64

@@ -26,7 +26,8 @@ def ops():
 
 
 # ---------------------------------------------------------------- building blocks --------------------
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1, 64, 64), (197, 2304, 768), (1000, 512, 3072), (257, 100, 128), (4096, 768, 768)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1, 64, 64), (197, 2304, 768), (1000, 512, 3072), (257, 100, 128), (4096, 768, 768),
+                                   (3000, 2304, 128), (2560, 1024, 64), (5000, 768, 192)])
 def test_gemm_epilogues(ops, M, N, K):
     a = (torch.from_numpy(synth.normal((M, K), 21, 0)).float() * 0.5).half()
     w = (torch.from_numpy(synth.normal((N, K), 21, 1)).float() * K ** -0.5).half()
@@ -63,6 +64,25 @@ def test_layernorm(ops, R, D):
     xs = x[: (R // 3) * 3].reshape(-1, 3 * D).contiguous()
     y2 = ops.layernorm(xs.cuda().view(-1, D), g.cuda(), b.cuda(), rows=xs.shape[0], ld=3 * D).cpu()
     assert ulp_diff(y2, torch.nn.functional.layer_norm(xs[:, :D].float(), [D], g, b).half()) <= 1
+
+
+@pytest.mark.parametrize("R,D,L", [(12, 64, 3), (394, 768, 197), (77, 512, 7)])
+def test_add_layernorm(ops, R, D, L):
+    """Residual add fused into the LayerNorm: x += delta (fp16 rounding), y = LN(x); also the strided CLS-row form."""
+    x = (torch.from_numpy(synth.normal((R, D), 25, 0)).float() * 2).half()
+    dl = torch.from_numpy(synth.normal((R, D), 25, 1)).half()
+    g = 1 + 0.1 * torch.from_numpy(synth.normal((D,), 25, 2)).float()
+    b = 0.1 * torch.from_numpy(synth.normal((D,), 25, 3)).float()
+    xs = (x.float() + dl.float()).half()
+    ref = torch.nn.functional.layer_norm(xs.float(), [D], g, b).half()
+    xd = x.cuda()
+    y = ops.add_layernorm(xd, dl.cuda(), g.cuda(), b.cuda())
+    assert torch.equal(xd.cpu(), xs)                       # x updated in place, bit exact
+    assert ulp_diff(y, ref) <= 1
+    xd = x.cuda()
+    y2 = ops.add_layernorm(xd, dl.cuda(), g.cuda(), b.cuda(), update_x=False, rows=R // L, ld=L * D)
+    assert torch.equal(xd.cpu(), x)                        # untouched
+    assert ulp_diff(y2, ref[::L][: R // L]) <= 1
 
 
 @pytest.mark.parametrize("B,L,H,causal", [(2, 50, 2, False), (3, 197, 12, False), (2, 77, 8, True), (1, 257, 16, False),

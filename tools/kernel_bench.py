@@ -41,7 +41,7 @@ def main():
             a = torch.randn(m, k, device=dev).half()
             w = (torch.randn(n, k, device=dev) * k ** -0.5).half()
             bias = torch.randn(n, device=dev).half()
-            r = torch.randn(m, n, device=dev).half() if res else None
+            r = None
             out = torch.empty(m, n, device=dev, dtype=torch.float16)
             t = timeit(lambda: ops.gemm(a, w, bias, act, r, out))
             print(f"gemm {name:9s} M={m} N={n} K={k}: {t * 1e6:8.1f} us  {2.0 * m * n * k / t / 1e12:7.1f} TFLOP/s", flush=True)
