@@ -99,6 +99,18 @@ def measure_gemm(st):
     return dict(launches=len(rec), total_ms=ms, avg_us=1e3 * ms / max(len(rec), 1), tflops=fl / (ms * 1e-3) / 1e12, flops=fl)
 
 
+def pmc_traffic():
+    """HBM bytes per GEMM launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE x2 + WRITE_SIZE,
+    separate passes, gfx950 correction) — counters cannot be read from inside the process, so the committed summary
+    profiles/r01_pmc_traffic.json (tools/gpu_round.sh) is reported; null when it is absent."""
+    path = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["linear_kernel_hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(n_img=32):
     """The ORACLE (CPU restatement of the reference path, fp32 model as clip.load(device='cpu') yields)
     timed on the host cores on a bounded sample of the same workload."""
@@ -187,9 +199,10 @@ def main():
             "config": {"workload": "C3 ImageNet 16-shot ViT-B/16 conv-3x: prototype reduce + encode_image + adapter + dual-bank classify",
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "classes": N_CLASS, "shots": SHOTS, "embed_dim": DIM,
                        "alpha": ALPHA, "beta": BETA, "parallelism": f"dp{world} (support rows and queries sharded; all-gather of class sums)"},
-            "roofline": {"bound": "mfma", "kernel": "linear_kernel (fp16 MFMA GEMM, all encoder + adapter linears)",
+            "roofline": {"bound": "mfma", "kernel": "linear_fast_kernel (fp16 MFMA GEMM: every encoder linear incl. patch embedding and projection)",
                          "achieved": gm["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gm["tflops"] / MFMA_PEAK_TFLOPS,
-                         "traffic": None, "launches_per_step": gm["launches"], "avg_launch_us": gm["avg_us"],
+                         "traffic": pmc_traffic(), "traffic_unit": "HBM bytes per launch (profiles/r01_pmc_traffic.json)",
+                         "launches_per_step": gm["launches"], "avg_launch_us": gm["avg_us"],
                          "gemm_ms_per_step": gm["total_ms"], "algorithmic_gflop_per_step": gm["flops"] / 1e9},
             "whole_path": {"gflop_per_image": GFLOP_PER_IMG_ENCODER + 0.00452, "achieved_tflops": imgs_per_s / world * (GFLOP_PER_IMG_ENCODER + 0.00452) / 1e3,
                            "frac_of_mfma_peak": imgs_per_s / world * (GFLOP_PER_IMG_ENCODER + 0.00452) / 1e3 / MFMA_PEAK_TFLOPS},

@@ -380,6 +380,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const half_t* __restr
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[j][e] = 0.f;
+        // scores are kept in the log2 domain: s2 = (q.k) * (1/sqrt(64)) * log2(e), p = exp2(s2 - max2) — one
+        // v_exp_f32 per probability; masks are applied only on the tiles that need them (last key tile, causal
+        // diagonal); the running output is rescaled only when some row's maximum actually moved.
+        constexpr float kScale = 0.125f * 1.4426950408889634f;
         float mrun = -__builtin_inff(), lrun = 0.f;
         const int tend = causal ? (qb + 1 < NT ? qb + 1 : NT) : NT;      // causal: keys beyond the block's last query are all masked
         for (int t = 0; t < tend; ++t) {
@@ -392,27 +396,39 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const half_t* __restr
                 const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + kr * ATT_DH + (((s * 2 + hi) ^ pgemm::swz_key(kr)) << 3));
                 st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st, 0, 0, 0);
             }
+            const bool need_mask = (t * 32 + 32 > L) || (causal && t == qb);     // wave-uniform
             float tmax = -__builtin_inff();
+            if (need_mask) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int k = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                const bool ok = k < L && (!causal || k <= q);
-                st[e] = ok ? st[e] * 0.125f : -__builtin_inff();     // 1/sqrt(64), exact
-                tmax = fmaxf(tmax, st[e]);
+                for (int e = 0; e < 16; ++e) {
+                    const int k = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                    const bool ok = k < L && (!causal || k <= q);
+                    st[e] = ok ? st[e] * kScale : -__builtin_inff();
+                    tmax = fmaxf(tmax, st[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    st[e] *= kScale;
+                    tmax = fmaxf(tmax, st[e]);
+                }
             }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, WAVE));
             const float mnew = fmaxf(mrun, tmax);       // finite from the first tile on: key 0 is never masked
-            const float alpha = expf(mrun - mnew);
             float psum = 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { st[e] = expf(st[e] - mnew); psum += st[e]; }
+            for (int e = 0; e < 16; ++e) { st[e] = __builtin_amdgcn_exp2f(st[e] - mnew); psum += st[e]; }
             psum += __shfl_xor(psum, 32, WAVE);
-            lrun = lrun * alpha + psum;
+            if (__any(mnew != mrun)) {
+                const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+                lrun *= alpha;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[j][e] *= alpha;
+            }
+            lrun += psum;
             mrun = mnew;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o[j][e] *= alpha;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 half8_t pf;
