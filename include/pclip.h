@@ -84,6 +84,11 @@ int pclip_sqdist_f16(const void* q, const void* zi, const void* zt, int Q, int N
                      const float* q_sq, const float* zi_sq, const float* zt_sq,
                      float* d2i, float* d2t, int ldd, void* ws, size_t ws_bytes, pclip_stream_t stream);
 
+/* fp32-operand variant for the training path (main.py:262-281: fp32 prototypes and adapted queries): exact
+ * fp32 arithmetic on v_mfma_f32_32x32x2_f32; any D; norms computed in the kernel. */
+int pclip_sqdist_f32(const float* q, const float* zi, const float* zt, int Q, int N, int D, float* d2i,
+                     float* d2t, int ldd, pclip_stream_t stream);
+
 /* p = alpha*softmax(-beta*d2i) + one_minus_alpha*softmax(-beta*d2t) over classes (max-subtracted,
  * fp32).  Outputs (each nullable): p [Q, N] dense; argmax [Q] (lowest index among ties,
  * main.py:190); top-k probabilities/indices [Q, k] sorted descending (toolkit

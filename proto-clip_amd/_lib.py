@@ -33,6 +33,7 @@ _SIGS = {
     "pclip_partial_sums_f16": [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P],
     "pclip_proto_finalize": [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P],
     "pclip_sqdist_f16": [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P],
+    "pclip_sqdist_f32": [_P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, _P],
     "pclip_fuse_probs": [_P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P, c_int, _P],
     "pclip_classify_f16": [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P,
                            _P, c_int, _P, c_size_t, _P],

@@ -57,6 +57,58 @@ __global__ __launch_bounds__(256, 2) void sqdist_kernel(const half_t* __restrict
     }
 }
 
+// fp32-operand variant (training path, main.py:262-281: fp32 prototypes / adapted queries).  Exact fp32
+// products and accumulation on v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain, guide §3); 64x64 output tile per
+// workgroup, one 32x32 accumulator per wave, K staged 32 columns at a time through LDS (padded rows: no
+// conflicts on the per-lane column reads).  The problem sizes of that path are small (<= a few thousand rows).
+__global__ __launch_bounds__(256) void sqdist_f32_kernel(const float* __restrict__ q, const float* __restrict__ z, int Q, int N,
+                                                         int D, float* __restrict__ out, int ldd) {
+    __shared__ float As[64][33], Bs[64][33];
+    __shared__ float qn[64], zn[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int wr = wave >> 1, wc = wave & 1, hi = lane >> 5, l31 = lane & 31;
+    float16_t acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    float nrm = 0.f;                                   // threads 0..63: ||q_row||^2, 64..127: ||z_row||^2
+    for (int k0 = 0; k0 < D; k0 += 32) {
+        __syncthreads();
+        for (int i = tid; i < 64 * 32; i += 256) {
+            const int r = i >> 5, c = i & 31;
+            As[r][c] = (m0 + r < Q && k0 + c < D) ? q[(size_t)(m0 + r) * D + k0 + c] : 0.f;
+            Bs[r][c] = (n0 + r < N && k0 + c < D) ? z[(size_t)(n0 + r) * D + k0 + c] : 0.f;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const float* row = tid < 64 ? As[tid] : Bs[tid - 64];
+#pragma unroll 8
+            for (int c = 0; c < 32; ++c) nrm = fmaf(row[c], row[c], nrm);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 2) {
+            // swapped operands as in the fp16 kernel: D[n][m] so that a lane owns row m = lane & 31
+            const float b = Bs[wc * 32 + l31][kk + hi], a = As[wr * 32 + l31][kk + hi];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc, 0, 0, 0);
+        }
+    }
+    if (tid < 64) qn[tid] = nrm; else if (tid < 128) zn[tid - 64] = nrm;
+    __syncthreads();
+    const int m = m0 + wr * 32 + l31;
+    if (m >= Q) return;
+    const float qs = qn[wr * 32 + l31];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int nl = wc * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
+        const int n = n0 + nl;
+        if (n < N) {
+            const float v = __fadd_rn(__fadd_rn(-2.f * acc[e], qs), zn[nl]);
+            const float d = sqrtf(fmaxf(v, 0.f));
+            out[(size_t)m * ldd + n] = __fmul_rn(d, d);
+        }
+    }
+}
+
 // ---- stage 2: softmax fusion, one wave per query row ----------------------------------------------
 // Lane l owns classes n = i*64 + l (scalar mapping) — coalesced 256-byte row segments.
 template <int NV>
@@ -263,6 +315,18 @@ extern "C" int pclip_sqdist_f16(const void* q, const void* zi, const void* zt, i
     sqdist_kernel<<<grid, 256, pgemm::CfgSmall::LDS_BYTES, s>>>((const half_t*)q, (const half_t*)zi, (const half_t*)zt, Q, N, D,
                                                       q_sq, zi_sq, zt_sq, d2i, d2t, ldd, tiles_n);
     return pclip_check_launch("sqdist");
+}
+
+extern "C" int pclip_sqdist_f32(const float* q, const float* zi, const float* zt, int Q, int N, int D, float* d2i,
+                                float* d2t, int ldd, pclip_stream_t stream) {
+    PCLIP_REQUIRE(q && zi && d2i, "pclip_sqdist_f32: null pointer");
+    PCLIP_REQUIRE(!zt || d2t, "pclip_sqdist_f32: zt given without d2t");
+    PCLIP_REQUIRE(Q >= 0 && N > 0 && D > 0 && ldd >= N, "pclip_sqdist_f32: bad Q=%d N=%d D=%d ldd=%d", Q, N, D, ldd);
+    if (Q == 0) return PCLIP_OK;
+    dim3 grid(ceil_div(N, 64), ceil_div(Q, 64));
+    sqdist_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(q, zi, Q, N, D, d2i, ldd);
+    if (zt) sqdist_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(q, zt, Q, N, D, d2t, ldd);
+    return pclip_check_launch("sqdist_f32");
 }
 
 extern "C" int pclip_fuse_probs(const float* d2i, const float* d2t, int Q, int N, int ldd, float alpha,

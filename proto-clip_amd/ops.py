@@ -139,6 +139,21 @@ def sqdist(q: torch.Tensor, zi: torch.Tensor, zt: torch.Tensor = None, q_sq=None
     return d2i, d2t, ldd
 
 
+def sqdist_f32(q: torch.Tensor, zi: torch.Tensor, zt: torch.Tensor = None):
+    """fp32-operand squared distances (training path: fp32 prototypes / adapted queries, main.py:262-281)."""
+    require_cuda(q, zi, zt)
+    q, zi = q.float().contiguous(), zi.float().contiguous()
+    zt = None if zt is None else zt.float().contiguous()
+    Q, D = q.shape
+    N = zi.shape[0]
+    ldd = padded_ld(N)
+    d2i = torch.empty(Q, ldd, dtype=torch.float32, device=q.device)
+    d2t = torch.empty(Q, ldd, dtype=torch.float32, device=q.device) if zt is not None else None
+    check(_lib.load().pclip_sqdist_f32(ptr(q), ptr(zi), ptr(zt), Q, N, D, ptr(d2i), ptr(d2t), ldd, stream()),
+          "pclip_sqdist_f32")
+    return d2i, d2t, ldd
+
+
 def fuse_probs(d2i, d2t, N: int, alpha: float, beta: float, want_p=True, want_argmax=False, topk: int = 0):
     """alpha*softmax(-beta*d2i) + (1-alpha)*softmax(-beta*d2t) (utils.py:236-242) + argmax / top-k."""
     require_cuda(d2i, d2t)

@@ -40,24 +40,30 @@ def get_model_dir_root(cfg):
     return f"{cfg['cache_dir']}/models/{beautify(cfg['backbone'])}/K-{cfg['shots']}"
 
 
-def _as_f16_rows(t: torch.Tensor, what: str) -> torch.Tensor:
-    """The reference casts every operand of P with .float() (utils.py:230-233); the MFMA path consumes
-    the fp16 values directly, which is lossless exactly when the operand is fp16 already."""
-    if t.dtype == torch.float16:
-        return t
-    raise PclipError(
-        f"P(): {what} is {t.dtype}; the gfx950 path takes the fp16 feature/prototype tensors of the eval path "
-        "(main.py:399-409). fp32 operands only occur in the training step, which is not built yet (SURVEY §8f #3).")
+def _all_f16(*ts):
+    for t in ts:
+        if t.dtype not in (torch.float16, torch.float32):
+            raise PclipError(f"P(): unsupported operand dtype {t.dtype} (fp16 or fp32 expected)")
+    return all(t.dtype == torch.float16 for t in ts)
 
 
 def P(zq_imgs_flat, z_img_proto, z_text_proto, alpha, beta):
     """p = alpha * softmax(-beta * d2(q, z_img)) + (1 - alpha) * softmax(-beta * d2(q, z_txt)), fp32 [Q, N]
-    (reference utils.py:225-244)."""
-    q = _as_f16_rows(zq_imgs_flat, "zq_imgs_flat")
-    zi = _as_f16_rows(z_img_proto, "z_img_proto")
-    zt = _as_f16_rows(z_text_proto, "z_text_proto")
-    p, _, _, _ = ops.classify(q, zi, zt, alpha, beta, want_p=True, want_argmax=False)
+    (reference utils.py:225-244).  The reference casts every operand with .float(): fp16 operands (the eval path,
+    main.py:399-409) go to the fp16-input MFMA kernel, which is lossless for them; if any operand is fp32 (the
+    training path, main.py:262-281) everything is promoted and the exact-fp32 MFMA kernel is used."""
+    if _all_f16(zq_imgs_flat, z_img_proto, z_text_proto):
+        p, _, _, _ = ops.classify(zq_imgs_flat, z_img_proto, z_text_proto, alpha, beta, want_p=True, want_argmax=False)
+        return p
+    d2i, d2t, _ = ops.sqdist_f32(zq_imgs_flat, z_img_proto, z_text_proto)
+    p, _, _, _ = ops.fuse_probs(d2i, d2t, z_img_proto.shape[0], alpha, beta, want_p=True)
     return p
+
+
+def _as_f16_rows(t: torch.Tensor, what: str) -> torch.Tensor:
+    if t.dtype == torch.float16:
+        return t
+    raise PclipError(f"{what} is {t.dtype}: the fused argmax / top-k entry points take the fp16 tensors of the eval path")
 
 
 def P_argmax(zq_imgs_flat, z_img_proto, z_text_proto, alpha, beta):

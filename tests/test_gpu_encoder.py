@@ -199,3 +199,47 @@ def test_clip_classifier_batched(ops):
     emb = clip_oracle.encode_text(sd, toks, half=True)
     ref = po.proto_build(emb, 5, 3, per_shot_norm=True)               # normalise rows, mean over templates, normalise
     assert rel_err(w.t(), ref) <= 5e-3
+
+
+def test_serving_entry_eager_and_graph(ops, tmp_path):
+    """toolkit-style consumer (proto_clip_classifier.py:48-71, 132-147): banks + adapter from disk, top-k per
+    request; hipGraph replay must reproduce the eager launch sequence bit for bit."""
+    from proto_clip_amd.model import Adapter
+    from proto_clip_amd.serving import ProtoClipClassifier, load_pretrained_mb_and_adapters
+    from conftest import randomize_adapter_
+    kw = ENCODERS["tiny"]
+    sd = random_state_dict(seed=11, **kw)
+    model = build_model({k: v.clone() for k, v in sd.items()}).cuda()
+    N, K, D = 9, 4, 64
+    split = synth.make_split(N, K, D, 8, 8, seed=6, sigma=2.0)
+    emb_v = (split.visual_memory_keys.t().float() * 1.3).half().contiguous()
+    emb_t = (split.textual_memory_bank.t().float() * 1.4).half().contiguous()
+    torch.manual_seed(5)
+    ad = randomize_adapter_(Adapter(D, "conv-3x", dtype=torch.half), 5)
+    torch.save(torch.nn.Parameter(emb_v), tmp_path / "v.pt")
+    torch.save(torch.nn.Parameter(emb_t), tmp_path / "t.pt")
+    torch.save(ad.state_dict(), tmp_path / "a.pt")
+    ev, et, adapter = load_pretrained_mb_and_adapters(memory_bank_v_path=str(tmp_path / "v.pt"), memory_bank_t_path=str(tmp_path / "t.pt"),
+                                                      adapter_type="conv-3x", adapter_weights_path=str(tmp_path / "a.pt"))
+    clf = ProtoClipClassifier(model, ev, et, adapter, shots=K, alpha=0.3, beta=7.0, top_k=3, class_names=[f"c_{i}" for i in range(N)])
+    imgs = synth.make_images(4, 32, seed=9, n_class=N).cuda()
+    tp, ti = clf.classify(imgs)
+    assert tp.shape == (4, 3) and ti.shape == (4, 3) and ti.dtype == torch.int64
+    # oracle on the GPU's own adapted features isolates the classification arithmetic
+    with torch.no_grad():
+        f = ops.l2norm_rows(model.encode_image(imgs))
+        a = adapter(f, l2norm_out=True)
+    p = po.P(a.cpu(), po.proto_build(emb_v, N, K), po.l2norm_rows(emb_t), 0.3, 7.0)
+    rv, ri = p.topk(3, dim=1)
+    torch.testing.assert_close(tp.cpu(), rv, rtol=0, atol=1e-4)
+    assert torch.equal(ti.cpu(), ri)
+    clf.capture(4)
+    for _ in range(3):
+        tg, ig = clf.classify(imgs)
+        assert torch.equal(tg, tp) and torch.equal(ig, ti)
+    imgs2 = synth.make_images(4, 32, seed=10, n_class=N).cuda()
+    t2, i2 = clf.classify(imgs2)                     # replay on new inputs == eager on new inputs
+    e2, j2 = clf._forward(imgs2)
+    assert torch.equal(t2, e2) and torch.equal(i2, j2.long())
+    names, probs = clf.classify_objects(imgs)
+    assert names[0][0] == f"c {int(ti[0, 0])}" and torch.equal(probs, tp)

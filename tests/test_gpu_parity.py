@@ -276,7 +276,25 @@ def test_loud_failures(ops):
         ops.sqdist(torch.zeros(4, 72, dtype=torch.float16, device="cuda"), torch.zeros(3, 72, dtype=torch.float16, device="cuda"))
     from proto_clip_amd.utils import P
     with pytest.raises(PclipError):
-        P(torch.zeros(4, 512, device="cuda"), torch.zeros(3, 512, device="cuda"), torch.zeros(3, 512, device="cuda"), 0.5, 1.0)
+        P(torch.zeros(4, 512, device="cuda").double(), torch.zeros(3, 512, device="cuda"), torch.zeros(3, 512, device="cuda"), 0.5, 1.0)
+
+
+@pytest.mark.parametrize("Q,N,D", [(70, 10, 512), (257, 198, 768), (33, 1000, 100), (1, 1, 8)])
+def test_P_fp32_operands_training_path(ops, Q, N, D):
+    """main.py:262-281: fp32 prototypes (train variant of the prototype kernel) and fp32 queries through P."""
+    from proto_clip_amd.utils import P
+    q = torch.nn.functional.normalize(torch.from_numpy(synth.normal((Q, D), 31, 0)).float(), dim=-1)
+    zi = torch.nn.functional.normalize(torch.from_numpy(synth.normal((N, D), 31, 1)).float(), dim=-1)
+    zt = torch.nn.functional.normalize(torch.from_numpy(synth.normal((N, D), 31, 2)).float(), dim=-1) * 1.3
+    d2i, d2t, _ = ops.sqdist_f32(dev(q), dev(zi), dev(zt))
+    assert (d2i.cpu()[:, :N] - po.sqdist(q, zi)).abs().max().item() <= 5e-6
+    assert (d2t.cpu()[:, :N] - po.sqdist(q, zt)).abs().max().item() <= 1e-5
+    p = P(dev(q), dev(zi), dev(zt), 0.4, 9.0).cpu()
+    ref = po.P(q, zi, zt, 0.4, 9.0)
+    assert (p - ref).abs().max().item() <= 1e-5
+    assert torch.equal(p.max(1)[1], ref.max(1)[1]) or N == 1
+    pm = P(dev(q), dev(zi.half()), dev(zt), 0.4, 9.0).cpu()             # mixed dtypes promote like .float()
+    assert (pm - po.P(q, zi.half(), zt, 0.4, 9.0)).abs().max().item() <= 1e-5
 
 
 # ---------------------------------------------------------------- full-size properties -----------------
