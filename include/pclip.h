@@ -170,6 +170,25 @@ int pclip_text_embed_f16(const int64_t* tokens, const void* tok_emb, const void*
 int pclip_gather_eot_f16(const void* x, const int64_t* tokens, int B, int L, int W, void* out,
                          pclip_stream_t stream);
 
+/* ---- ModifiedResNet tower pieces: clip/model.py:10-152 (activations NHWC fp16) ------------------------ */
+
+/* im2col for a 3x3 / padding 1 / stride 1|2 convolution (clip/model.py:20, 109-113): element (b,y,x,c) of the
+ * input sits at x[b*sb + y*sh + x*sw + c*sc] (NHWC activations or the NCHW image);
+ * cols[((b*Ho+oy)*Wo+ox)*ld + (ky*3+kx)*C + c], zero outside the image and for columns >= 9*C. */
+int pclip_im2col3x3_f16(const void* x, long sb, long sh, long sw, long sc, int B, int H, int W, int C, int stride,
+                        void* cols, int ld, pclip_stream_t stream);
+
+/* Eval-mode BatchNorm2d (scale/shift folded from the fp32 statistics) + optional residual add + optional ReLU on
+ * [rows, C] fp16: y = relu(r16(r16(x*scale + shift) + residual))  (clip/model.py:43-52). */
+int pclip_bn_act_f16(const void* x, const float* scale, const float* shift, const void* residual, int relu, void* y,
+                     size_t rows, int C, pclip_stream_t stream);
+
+/* nn.AvgPool2d(k) on NHWC fp16 (clip/model.py:23, 35, 115). */
+int pclip_avgpool_nhwc_f16(const void* x, int B, int H, int W, int C, int k, void* y, pclip_stream_t stream);
+
+/* AttentionPool2d token assembly (clip/model.py:68-70): [mean token ; tokens] + positional embedding. */
+int pclip_attnpool_tokens_f16(const void* x, const void* pos, int B, int HW, int C, void* tokens, pclip_stream_t stream);
+
 /* fp32 -> fp16 cast (image.type(self.dtype), clip/model.py:339). */
 int pclip_cast_f32_f16(const float* x, void* y, size_t n, pclip_stream_t stream);
 

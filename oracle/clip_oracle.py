@@ -93,3 +93,60 @@ def encode_text(sd, text, half=True):
     eot = x[torch.arange(x.shape[0]), text.argmax(dim=-1)]
     out = _r(eot @ _w(sd, "text_projection", half, True), half)
     return out.half() if half else out
+
+
+# ---- ModifiedResNet tower (clip/model.py:10-152) ----------------------------------------------------------
+
+def _bn_eval(x, sd, p, half):
+    """nn.BatchNorm2d in eval mode with fp32 statistics on a (possibly fp16-rounded) activation."""
+    w, b = sd[p + ".weight"].float(), sd[p + ".bias"].float()
+    m, v = sd[p + ".running_mean"].float(), sd[p + ".running_var"].float()
+    y = (x - m[None, :, None, None]) / torch.sqrt(v[None, :, None, None] + 1e-5) * w[None, :, None, None] + b[None, :, None, None]
+    return _r(y, half)
+
+
+def _conv(x, sd, key, half, stride=1, padding=0):
+    return _r(F.conv2d(x, _w(sd, key + ".weight", half, True), stride=stride, padding=padding), half)
+
+
+def _avgpool(x, k, half):
+    return _r(F.avg_pool2d(x, k), half) if k > 1 else x
+
+
+def _bottleneck(x, sd, p, stride, half):
+    """Bottleneck.forward (clip/model.py:40-53)."""
+    out = torch.relu(_bn_eval(_conv(x, sd, p + "conv1", half), sd, p + "bn1", half))
+    out = torch.relu(_bn_eval(_conv(out, sd, p + "conv2", half, padding=1), sd, p + "bn2", half))
+    out = _avgpool(out, stride, half)
+    out = _bn_eval(_conv(out, sd, p + "conv3", half), sd, p + "bn3", half)
+    identity = x
+    if p + "downsample.0.weight" in sd:
+        identity = _bn_eval(_conv(_avgpool(x, stride, half), sd, p + "downsample.0", half), sd, p + "downsample.1", half)
+    return torch.relu(_r(out + identity, half))
+
+
+def encode_image_resnet(sd, images, half=True):
+    """ModifiedResNet.forward + AttentionPool2d.forward (clip/model.py:137-152, 67-92)."""
+    x = _r(images.float(), half)
+    x = torch.relu(_bn_eval(_conv(x, sd, "visual.conv1", half, stride=2, padding=1), sd, "visual.bn1", half))
+    x = torch.relu(_bn_eval(_conv(x, sd, "visual.conv2", half, padding=1), sd, "visual.bn2", half))
+    x = torch.relu(_bn_eval(_conv(x, sd, "visual.conv3", half, padding=1), sd, "visual.bn3", half))
+    x = _avgpool(x, 2, half)
+    for li, stride in ((1, 1), (2, 2), (3, 2), (4, 2)):
+        nblk = len(set(k.split(".")[2] for k in sd if k.startswith(f"visual.layer{li}.")))
+        for bi in range(nblk):
+            x = _bottleneck(x, sd, f"visual.layer{li}.{bi}.", stride if bi == 0 else 1, half)
+    B, C, H, W = x.shape
+    t = x.reshape(B, C, H * W).permute(0, 2, 1)                                    # [B, HW, C]
+    t = torch.cat([_r(t.mean(dim=1, keepdim=True), half), t], dim=1)
+    t = _r(t + _r(sd["visual.attnpool.positional_embedding"].float(), half), half)
+    heads = C // 64
+    q = _linear(t, sd, "visual.attnpool.q_proj.weight", "visual.attnpool.q_proj.bias", half)
+    k = _linear(t, sd, "visual.attnpool.k_proj.weight", "visual.attnpool.k_proj.bias", half)
+    v = _linear(t, sd, "visual.attnpool.v_proj.weight", "visual.attnpool.v_proj.bias", half)
+    L = t.shape[1]
+    q, k, v = (z.view(B, L, heads, 64).transpose(1, 2) for z in (q, k, v))
+    a = _r(_r(torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1), half) @ v, half)
+    a = a.transpose(1, 2).reshape(B, L, C)[:, 0, :]
+    out = _linear(a, sd, "visual.attnpool.c_proj.weight", "visual.attnpool.c_proj.bias", half)
+    return out.half() if half else out

@@ -3,7 +3,7 @@ or a call fails, a loud exception is raised — the product path never routes th
 PyTorch-eager substitute."""
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p, POINTER
+from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
 
 import torch
 
@@ -49,6 +49,10 @@ _SIGS = {
     "pclip_vit_assemble_tokens_f16": [_P, _P, _P, c_int, c_int, c_int, _P, _P],
     "pclip_text_embed_f16": [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P],
     "pclip_gather_eot_f16": [_P, _P, c_int, c_int, c_int, _P, _P],
+    "pclip_im2col3x3_f16": [_P, c_long, c_long, c_long, c_long, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P],
+    "pclip_bn_act_f16": [_P, _P, _P, _P, c_int, _P, c_size_t, c_int, _P],
+    "pclip_avgpool_nhwc_f16": [_P, c_int, c_int, c_int, c_int, c_int, _P, _P],
+    "pclip_attnpool_tokens_f16": [_P, _P, c_int, c_int, c_int, _P, _P],
     "pclip_cast_f32_f16": [_P, _P, c_size_t, _P],
     "pclip_workspace_bytes": [c_int, c_int, c_int, c_int],
 }

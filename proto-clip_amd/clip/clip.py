@@ -12,7 +12,7 @@ import torch
 from .._lib import PclipError
 from .model import BACKBONES, build_model, random_state_dict
 
-_FILES = {"ViT-B/32": "ViT-B-32.pt", "ViT-B/16": "ViT-B-16.pt", "ViT-L/14": "ViT-L-14.pt"}
+_FILES = {"RN50": "RN50.pt", "RN101": "RN101.pt", "ViT-B/32": "ViT-B-32.pt", "ViT-B/16": "ViT-B-16.pt", "ViT-L/14": "ViT-L-14.pt"}
 
 
 def available_models() -> List[str]:

@@ -9,9 +9,9 @@ fused bias/QuickGELU/residual epilogues, fp32-statistics LayerNorm, whole-sequen
 
 Precision follows `convert_weights` (clip/model.py:373-394): Linear/conv/projection weights fp16,
 LayerNorm and embedding parameters fp32, activations fp16 with fp32 accumulation.
-Only the transformer towers (ViT-B/32, ViT-B/16, ViT-L/14 and every text tower) are built; the
-ModifiedResNet tower (RN50/RN101, clip/model.py:95-152) is not — BASELINE pins its only config (C1) to
-the CPU path."""
+Both vision towers are built: VisionTransformer (ViT-B/32, ViT-B/16, ViT-L/14) and ModifiedResNet (RN50 /
+RN101: NHWC activations, 1x1 convs as GEMMs, 3x3 convs as im2col + GEMM, eval BatchNorm folded to a streaming
+scale/shift pass)."""
 import os
 from collections import OrderedDict
 
@@ -160,17 +160,165 @@ class VisionTransformer(nn.Module):
         return ops.gemm(cls, projT)                                         # x @ proj, 235-236
 
 
+def _bn(ch):
+    b = _Box()
+    b.weight = nn.Parameter(torch.ones(ch), requires_grad=False)
+    b.bias = nn.Parameter(torch.zeros(ch), requires_grad=False)
+    b.register_buffer("running_mean", torch.zeros(ch))
+    b.register_buffer("running_var", torch.ones(ch))
+    b.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+    b.eps = 1e-5
+    return b
+
+
+def _conv(cout, cin, k):
+    b = _Box()
+    b.weight = nn.Parameter(torch.empty(cout, cin, k, k), requires_grad=False)
+    return b
+
+
+class _Bottleneck(_Box):
+    """Parameter tree of clip/model.py:10-38 (conv1 1x1, conv2 3x3, avgpool(stride), conv3 1x1, optional
+    downsample = avgpool(stride) -> 1x1 conv -> bn, whose Sequential keys are '0' and '1')."""
+
+    def __init__(self, inplanes, planes, stride):
+        super().__init__()
+        self.conv1, self.bn1 = _conv(planes, inplanes, 1), _bn(planes)
+        self.conv2, self.bn2 = _conv(planes, planes, 3), _bn(planes)
+        self.conv3, self.bn3 = _conv(planes * 4, planes, 1), _bn(planes * 4)
+        self.stride = stride
+        self.downsample = None
+        if stride > 1 or inplanes != planes * 4:
+            self.downsample = nn.ModuleDict({"0": _conv(planes * 4, inplanes, 1), "1": _bn(planes * 4)})
+
+
+class ModifiedResNet(nn.Module):
+    """clip/model.py:95-152 on the gfx950 kernels.  Activations are NHWC fp16 rows [B*H*W, C]: 1x1 convolutions are
+    plain MFMA GEMMs, 3x3 convolutions are an im2col gather + the same GEMM, BatchNorm(eval)+ReLU(+residual) is one
+    streaming pass, the attention pool reuses the transformer attention kernel (head dim 64)."""
+
+    def __init__(self, layers, output_dim, heads, input_resolution=224, width=64):
+        super().__init__()
+        self.output_dim, self.input_resolution, self.heads = output_dim, input_resolution, heads
+        self.conv1, self.bn1 = _conv(width // 2, 3, 3), _bn(width // 2)
+        self.conv2, self.bn2 = _conv(width // 2, width // 2, 3), _bn(width // 2)
+        self.conv3, self.bn3 = _conv(width, width // 2, 3), _bn(width)
+        inpl = width
+        for li, (planes, nblk, stride) in enumerate(zip((width, width * 2, width * 4, width * 8), layers, (1, 2, 2, 2)), 1):
+            blocks = [_Bottleneck(inpl, planes, stride)]
+            inpl = planes * 4
+            blocks += [_Bottleneck(inpl, planes, 1) for _ in range(1, nblk)]
+            setattr(self, f"layer{li}", nn.Sequential(*blocks))
+        embed = width * 32
+        if embed // heads != 64:
+            raise PclipError(f"attention pool head dim {embed // heads} unsupported (the attention kernel needs 64)")
+        self.attnpool = _Box()
+        self.attnpool.positional_embedding = nn.Parameter(torch.empty((input_resolution // 32) ** 2 + 1, embed), requires_grad=False)
+        for nm in ("k_proj", "q_proj", "v_proj"):
+            setattr(self.attnpool, nm, _linear(embed, embed))
+        self.attnpool.c_proj = _linear(output_dim, embed)
+        self._cache = _Cached()
+        self.chunk = int(os.environ.get("PCLIP_RN_CHUNK", "32"))
+
+    # -- helpers ---------------------------------------------------------------------------------------------------
+    def _bn_affine(self, key, bn):
+        def fold(_):
+            inv = torch.rsqrt(bn.running_var.float() + bn.eps)
+            scale = bn.weight.float() * inv
+            return torch.stack([scale, bn.bias.float() - bn.running_mean.float() * scale]).contiguous()
+        tag_src = bn.weight            # refreshed when the affine weight tensor is replaced; running stats are frozen in eval
+        ss = self._cache.get(("bn", key), tag_src, fold)
+        return ss[0], ss[1]
+
+    def _w1x1(self, key, conv):
+        return self._cache.get(("w1", key), conv.weight, lambda w: w.reshape(w.shape[0], w.shape[1]).contiguous())
+
+    def _w3x3(self, key, conv):
+        def prep(w):                   # [Cout, Cin, 3, 3] -> [Cout, (ky, kx, Cin)] padded to the GEMM's K-tile
+            co, ci = w.shape[0], w.shape[1]
+            w2 = w.permute(0, 2, 3, 1).reshape(co, 9 * ci)
+            kpad = (9 * ci + 63) // 64 * 64
+            if kpad != 9 * ci:
+                w2 = torch.cat([w2, w2.new_zeros(co, kpad - 9 * ci)], dim=1)
+            return w2.contiguous()
+        return self._cache.get(("w3", key), conv.weight, prep)
+
+    def _conv3_bn_relu(self, key, x, strides, B, H, W, C, conv, bn, stride=1):
+        cols = ops.im2col3x3(x, strides, B, H, W, C, stride)
+        y = ops.gemm(cols, self._w3x3(key, conv))
+        sc, sh = self._bn_affine(key, bn)
+        return ops.bn_act(y, sc, sh, relu=True, out=y)
+
+    def _bottleneck(self, key, blk, x, B, H, W, Cin):
+        planes = blk.conv1.weight.shape[0]
+        sc, sh = self._bn_affine(key + ".1", blk.bn1)
+        out = ops.gemm(x, self._w1x1(key + ".1", blk.conv1))
+        out = ops.bn_act(out, sc, sh, relu=True, out=out)                                    # relu(bn1(conv1(x)))
+        out = self._conv3_bn_relu(key + ".2", out, (H * W * planes, W * planes, planes, 1), B, H, W, planes, blk.conv2, blk.bn2)
+        Ho, Wo = H, W
+        if blk.stride > 1:
+            out = ops.avgpool_nhwc(out, B, H, W, planes, blk.stride)                         # anti-aliased stride
+            Ho, Wo = H // blk.stride, W // blk.stride
+        out = ops.gemm(out, self._w1x1(key + ".3", blk.conv3))
+        identity = x
+        if blk.downsample is not None:
+            idn = ops.avgpool_nhwc(x, B, H, W, Cin, blk.stride) if blk.stride > 1 else x
+            idn = ops.gemm(idn, self._w1x1(key + ".d", blk.downsample["0"]))
+            dsc, dsh = self._bn_affine(key + ".d", blk.downsample["1"])
+            identity = ops.bn_act(idn, dsc, dsh, relu=False, out=idn)
+        sc, sh = self._bn_affine(key + ".3", blk.bn3)
+        out = ops.bn_act(out, sc, sh, residual=identity, relu=True, out=out)                  # relu(bn3(conv3) + identity)
+        return out, Ho, Wo, planes * 4
+
+    def forward(self, x):
+        R = self.input_resolution
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != R or x.shape[3] != R:
+            raise PclipError(f"expected images [B,3,{R},{R}], got {tuple(x.shape)}")
+        outs = [self._forward_chunk(x[i:i + self.chunk]) for i in range(0, x.shape[0], self.chunk)]
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+
+    def _forward_chunk(self, img):
+        B, R = img.shape[0], self.input_resolution
+        if img.dtype == torch.float32:
+            img = ops.cast_f16(img)
+        img = img.contiguous()
+        w2 = self.conv1.weight.shape[0]
+        # stem (clip/model.py:138-142): the NCHW image is read through its strides by the first im2col
+        x = self._conv3_bn_relu("s1", img, (3 * R * R, R, 1, R * R), B, R, R, 3, self.conv1, self.bn1, stride=2)
+        H = W = (R - 1) // 2 + 1
+        x = self._conv3_bn_relu("s2", x, (H * W * w2, W * w2, w2, 1), B, H, W, w2, self.conv2, self.bn2)
+        x = self._conv3_bn_relu("s3", x, (H * W * w2, W * w2, w2, 1), B, H, W, w2, self.conv3, self.bn3)
+        C = self.conv3.weight.shape[0]
+        x = ops.avgpool_nhwc(x, B, H, W, C, 2)
+        H, W = H // 2, W // 2
+        for li in (1, 2, 3, 4):
+            for bi, blk in enumerate(getattr(self, f"layer{li}")):
+                x, H, W, C = self._bottleneck(f"l{li}.{bi}", blk, x, B, H, W, C)
+        # attention pool (clip/model.py:67-92): q = k = v = tokens, separate projections, output of token 0
+        ap = self.attnpool
+        pos16 = self._cache.get("appos", ap.positional_embedding, lambda t: t.half().contiguous())
+        wqkv = self._cache.get("apw", ap.q_proj.weight, lambda _: torch.cat([ap.q_proj.weight, ap.k_proj.weight, ap.v_proj.weight]).detach().contiguous())
+        bqkv = self._cache.get("apb", ap.q_proj.bias, lambda _: torch.cat([ap.q_proj.bias, ap.k_proj.bias, ap.v_proj.bias]).detach().contiguous())
+        L = H * W + 1
+        tok = ops.attnpool_tokens(x, pos16, B, H * W, C)
+        qkv = ops.gemm(tok, wqkv, bqkv)
+        a = ops.attention(qkv, B, L, self.heads, causal=False)
+        a0 = a.view(B, L * C)[:, :C]                                   # token 0 of every image (row stride L*C)
+        return ops.gemm(a0, ap.c_proj.weight, ap.c_proj.bias)
+
+
 class CLIP(nn.Module):
     """clip/model.py:241-370 (transformer towers only)."""
 
     def __init__(self, embed_dim, image_resolution, vision_layers, vision_width, vision_patch_size, context_length,
                  vocab_size, transformer_width, transformer_heads, transformer_layers):
         super().__init__()
-        if isinstance(vision_layers, (tuple, list)):
-            raise PclipError("ModifiedResNet towers (RN50/RN101) are not built in this round; use a ViT backbone")
         self.context_length = context_length
-        self.visual = VisionTransformer(image_resolution, vision_patch_size, vision_width, vision_layers,
-                                        vision_width // 64, embed_dim)
+        if isinstance(vision_layers, (tuple, list)):
+            self.visual = ModifiedResNet(vision_layers, embed_dim, vision_width * 32 // 64, image_resolution, vision_width)
+        else:
+            self.visual = VisionTransformer(image_resolution, vision_patch_size, vision_width, vision_layers,
+                                            vision_width // 64, embed_dim)
         self.transformer = _transformer(transformer_width, transformer_layers)
         self.transformer_heads = transformer_heads
         self.vocab_size = vocab_size
@@ -220,20 +368,28 @@ class CLIP(nn.Module):
 def convert_weights(model: nn.Module):
     """fp16 for Linear/conv/attention/projection parameters, fp32 elsewhere (clip/model.py:373-394)."""
     half_suffixes = ("in_proj_weight", "in_proj_bias", "out_proj.weight", "out_proj.bias", "c_fc.weight", "c_fc.bias",
-                     "c_proj.weight", "c_proj.bias", "conv1.weight", "visual.proj", "text_projection")
+                     "c_proj.weight", "c_proj.bias", "visual.proj", "text_projection", "q_proj.weight", "q_proj.bias",
+                     "k_proj.weight", "k_proj.bias", "v_proj.weight", "v_proj.bias")
     for name, p in model.named_parameters():
-        p.data = p.data.half() if name.endswith(half_suffixes) else p.data.float()
+        is_conv = p.dim() == 4                               # every nn.Conv2d weight (ViT patch conv, all ResNet convs)
+        p.data = p.data.half() if (is_conv or name.endswith(half_suffixes)) else p.data.float()
 
 
 def build_model(state_dict: dict):
     """Same shape inference as the reference's build_model (clip/model.py:397-434)."""
-    if "visual.proj" not in state_dict:
-        raise PclipError("ModifiedResNet checkpoints (RN50/RN101) are not supported by this build")
-    vision_width = state_dict["visual.conv1.weight"].shape[0]
-    vision_layers = len([k for k in state_dict if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
-    vision_patch_size = state_dict["visual.conv1.weight"].shape[-1]
-    grid_size = round((state_dict["visual.positional_embedding"].shape[0] - 1) ** 0.5)
-    image_resolution = vision_patch_size * grid_size
+    if "visual.proj" in state_dict:
+        vision_width = state_dict["visual.conv1.weight"].shape[0]
+        vision_layers = len([k for k in state_dict if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+        vision_patch_size = state_dict["visual.conv1.weight"].shape[-1]
+        grid_size = round((state_dict["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+        image_resolution = vision_patch_size * grid_size
+    else:
+        vision_layers = tuple(len(set(k.split(".")[2] for k in state_dict if k.startswith(f"visual.layer{b}"))) for b in (1, 2, 3, 4))
+        vision_width = state_dict["visual.layer1.0.conv1.weight"].shape[0]
+        output_width = round((state_dict["visual.attnpool.positional_embedding"].shape[0] - 1) ** 0.5)
+        vision_patch_size = None
+        assert output_width ** 2 + 1 == state_dict["visual.attnpool.positional_embedding"].shape[0]
+        image_resolution = output_width * 32
     embed_dim = state_dict["text_projection"].shape[1]
     context_length = state_dict["positional_embedding"].shape[0]
     vocab_size = state_dict["token_embedding.weight"].shape[0]
@@ -255,6 +411,10 @@ BACKBONES = {
                      context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8, transformer_layers=12),
     "ViT-B/16": dict(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768, vision_patch_size=16,
                      context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8, transformer_layers=12),
+    "RN50": dict(embed_dim=1024, image_resolution=224, vision_layers=(3, 4, 6, 3), vision_width=64, vision_patch_size=None,
+                 context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8, transformer_layers=12),
+    "RN101": dict(embed_dim=512, image_resolution=224, vision_layers=(3, 4, 23, 3), vision_width=64, vision_patch_size=None,
+                  context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8, transformer_layers=12),
     "ViT-L/14": dict(embed_dim=768, image_resolution=224, vision_layers=24, vision_width=1024, vision_patch_size=14,
                      context_length=77, vocab_size=49408, transformer_width=768, transformer_heads=12, transformer_layers=12),
 }
@@ -264,18 +424,53 @@ def random_state_dict(seed: int = 1, **kw) -> "OrderedDict[str, torch.Tensor]":
     """Seeded random-init weights with the statistics of CLIP.initialize_parameters
     (clip/model.py:297-324) — there are no pretrained checkpoints in the build environment."""
     g = torch.Generator().manual_seed(seed)
-    W, Lv, P = kw["vision_width"], kw["vision_layers"], kw["vision_patch_size"]
     Wt, Lt, E = kw["transformer_width"], kw["transformer_layers"], kw["embed_dim"]
-    G = kw["image_resolution"] // P
     rn = lambda *shape, std=1.0: torch.randn(*shape, generator=g) * std
     sd = OrderedDict()
-    sd["visual.class_embedding"] = rn(W, std=W ** -0.5)
-    sd["visual.positional_embedding"] = rn(G * G + 1, W, std=W ** -0.5)
-    sd["visual.proj"] = rn(W, E, std=W ** -0.5)
-    sd["visual.conv1.weight"] = rn(W, 3, P, P, std=(3 * P * P) ** -0.5)
-    for nm in ("ln_pre", "ln_post"):
-        sd[f"visual.{nm}.weight"] = 1 + rn(W, std=0.02)
-        sd[f"visual.{nm}.bias"] = rn(W, std=0.02)
+    if isinstance(kw["vision_layers"], (tuple, list)):
+        w = kw["vision_width"]
+
+        def conv(name, co, ci, k):
+            sd[name + ".weight"] = rn(co, ci, k, k, std=(ci * k * k) ** -0.5)
+
+        def bn(name, ch, gamma=1.0):
+            sd[name + ".weight"] = gamma * (1 + rn(ch, std=0.05))
+            sd[name + ".bias"] = rn(ch, std=0.05)
+            sd[name + ".running_mean"] = rn(ch, std=0.1)
+            sd[name + ".running_var"] = 1 + 0.2 * torch.rand(ch, generator=g)
+            sd[name + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+
+        conv("visual.conv1", w // 2, 3, 3); bn("visual.bn1", w // 2)
+        conv("visual.conv2", w // 2, w // 2, 3); bn("visual.bn2", w // 2)
+        conv("visual.conv3", w, w // 2, 3); bn("visual.bn3", w)
+        inpl = w
+        for li, (planes, nblk, stride) in enumerate(zip((w, 2 * w, 4 * w, 8 * w), kw["vision_layers"], (1, 2, 2, 2)), 1):
+            for bi in range(nblk):
+                p = f"visual.layer{li}.{bi}."
+                st = stride if bi == 0 else 1
+                conv(p + "conv1", planes, inpl, 1); bn(p + "bn1", planes)
+                conv(p + "conv2", planes, planes, 3); bn(p + "bn2", planes)
+                conv(p + "conv3", planes * 4, planes, 1); bn(p + "bn3", planes * 4, gamma=0.5)
+                if st > 1 or inpl != planes * 4:
+                    conv(p + "downsample.0", planes * 4, inpl, 1); bn(p + "downsample.1", planes * 4)
+                inpl = planes * 4
+        emb = w * 32
+        sd["visual.attnpool.positional_embedding"] = rn((kw["image_resolution"] // 32) ** 2 + 1, emb, std=emb ** -0.5)
+        for nm in ("k_proj", "q_proj", "v_proj"):
+            sd[f"visual.attnpool.{nm}.weight"] = rn(emb, emb, std=emb ** -0.5)
+            sd[f"visual.attnpool.{nm}.bias"] = rn(emb, std=0.02)
+        sd["visual.attnpool.c_proj.weight"] = rn(E, emb, std=emb ** -0.5)
+        sd["visual.attnpool.c_proj.bias"] = rn(E, std=0.02)
+    else:
+        W, Lv, P = kw["vision_width"], kw["vision_layers"], kw["vision_patch_size"]
+        G = kw["image_resolution"] // P
+        sd["visual.class_embedding"] = rn(W, std=W ** -0.5)
+        sd["visual.positional_embedding"] = rn(G * G + 1, W, std=W ** -0.5)
+        sd["visual.proj"] = rn(W, E, std=W ** -0.5)
+        sd["visual.conv1.weight"] = rn(W, 3, P, P, std=(3 * P * P) ** -0.5)
+        for nm in ("ln_pre", "ln_post"):
+            sd[f"visual.{nm}.weight"] = 1 + rn(W, std=0.02)
+            sd[f"visual.{nm}.bias"] = rn(W, std=0.02)
 
     def blocks(prefix, width, layers):
         proj_std, attn_std, fc_std = (width ** -0.5) * ((2 * layers) ** -0.5), width ** -0.5, (2 * width) ** -0.5
@@ -294,7 +489,8 @@ def random_state_dict(seed: int = 1, **kw) -> "OrderedDict[str, torch.Tensor]":
             sd[p + "ln_2.weight"] = 1 + rn(width, std=0.02)
             sd[p + "ln_2.bias"] = rn(width, std=0.02)
 
-    blocks("visual.transformer.", W, Lv)
+    if not isinstance(kw["vision_layers"], (tuple, list)):
+        blocks("visual.transformer.", kw["vision_width"], kw["vision_layers"])
     blocks("transformer.", Wt, Lt)
     sd["token_embedding.weight"] = rn(kw["vocab_size"], Wt, std=0.02)
     sd["positional_embedding"] = rn(kw["context_length"], Wt, std=0.01)

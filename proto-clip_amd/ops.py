@@ -332,3 +332,42 @@ def gather_eot(x, tokens, B: int, L: int, W: int) -> torch.Tensor:
     out = torch.empty(B, W, dtype=torch.float16, device=x.device)
     check(_lib.load().pclip_gather_eot_f16(ptr(x), ptr(tokens), B, L, W, ptr(out), stream()), "pclip_gather_eot_f16")
     return out
+
+
+# ---- ModifiedResNet building blocks (activations NHWC fp16) ---------------------------------------------
+
+def im2col3x3(x, strides, B: int, H: int, W: int, C: int, stride: int = 1) -> torch.Tensor:
+    """[B*Ho*Wo, round_up(9*C, 64)] fp16 rows for a 3x3 / pad 1 convolution; `strides` = element strides
+    (batch, y, x, channel) of the input buffer."""
+    require_cuda(x)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    ld = (9 * C + 63) // 64 * 64
+    cols = torch.empty(B * Ho * Wo, ld, dtype=torch.float16, device=x.device)
+    sb, sh, sw, sc = strides
+    check(_lib.load().pclip_im2col3x3_f16(ptr(x), sb, sh, sw, sc, B, H, W, C, stride, ptr(cols), ld, stream()),
+          "pclip_im2col3x3_f16")
+    return cols
+
+
+def bn_act(x, scale, shift, residual=None, relu: bool = True, out=None) -> torch.Tensor:
+    require_cuda(x, scale, shift, residual)
+    rows, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().pclip_bn_act_f16(ptr(x), ptr(scale), ptr(shift), ptr(residual), int(relu), ptr(out), rows, C, stream()),
+          "pclip_bn_act_f16")
+    return out
+
+
+def avgpool_nhwc(x, B: int, H: int, W: int, C: int, k: int) -> torch.Tensor:
+    require_cuda(x)
+    y = torch.empty(B * (H // k) * (W // k), C, dtype=torch.float16, device=x.device)
+    check(_lib.load().pclip_avgpool_nhwc_f16(ptr(x), B, H, W, C, k, ptr(y), stream()), "pclip_avgpool_nhwc_f16")
+    return y
+
+
+def attnpool_tokens(x, pos16, B: int, HW: int, C: int) -> torch.Tensor:
+    require_cuda(x, pos16)
+    t = torch.empty(B * (HW + 1), C, dtype=torch.float16, device=x.device)
+    check(_lib.load().pclip_attnpool_tokens_f16(ptr(x), ptr(pos16), B, HW, C, ptr(t), stream()), "pclip_attnpool_tokens_f16")
+    return t

@@ -32,7 +32,7 @@ def golden(name):
 
 
 sys.path.insert(0, GOLDEN)
-from spec import ENCODERS, FEWSHOT, ODD, SMALL, TINY, fewshot_inputs, randomize_adapter_   # noqa: E402,F401
+from spec import ENCODERS, FEWSHOT, ODD, RESNETS, SMALL, TINY, fewshot_inputs, randomize_adapter_   # noqa: E402,F401
 
 
 def adapter_sd(g):

@@ -28,7 +28,7 @@ sys.path.insert(0, REPO)
 from proto_clip_amd import synth                                   # noqa: E402
 from proto_clip_amd.clip.model import random_state_dict            # noqa: E402
 sys.path.insert(0, HERE)
-from spec import ENCODERS, FEWSHOT, fewshot_inputs, randomize_adapter_   # noqa: E402
+from spec import ENCODERS, FEWSHOT, RESNETS, fewshot_inputs, randomize_adapter_   # noqa: E402
 
 
 # ---------------------------------------------------------------- Appendix-B shim -----------------
@@ -218,6 +218,18 @@ def make_encoder(tag, kw, ref_clip_model, ref_utils):
           cache_values=values.to(torch.int16), cache_labels=labels, pre_features=feats, pre_labels=flabels)
 
 
+def make_resnet(tag, kw, ref_clip_model):
+    """ModifiedResNet tower of the reference (fp16-weight and fp32 variants) on seeded weights / images."""
+    sd = random_state_dict(seed=13, **kw)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m16 = ref_clip_model.build_model({k: v.clone() for k, v in sd.items()})
+        m32 = ref_clip_model.build_model({k: v.clone() for k, v in sd.items()}).float()
+    imgs = synth.make_images(6, kw["image_resolution"], seed=5, n_class=6)
+    with torch.no_grad():
+        f16, f32 = m16.encode_image(imgs), m32.encode_image(imgs)
+    savez("encoder_" + tag, img_f16=f16, img_f32=f32)
+
+
 def make_tokenizer(ref_clip):
     prompts = ["a photo of a dog.", "a centered satellite photo of annual crop land.", "itap of a forest.",
                "a bad photo of the tench, tinca tinca.", "A Photo Of The Large golden_retriever!!", "art of the 3-d   printer's nozzle"]
@@ -237,6 +249,9 @@ def main():
     for tag, kw in ENCODERS.items():
         if todo(tag):
             make_encoder(tag, kw, ref_clip_model, ref_utils)
+    for tag, kw in RESNETS.items():
+        if todo(tag):
+            make_resnet(tag, kw, ref_clip_model)
     if todo("tokenizer"):
         make_tokenizer(ref_clip)
 

@@ -19,6 +19,12 @@ SMALL = dict(embed_dim=128, image_resolution=64, vision_layers=3, vision_width=2
 ODD = dict(embed_dim=64, image_resolution=70, vision_layers=2, vision_width=192, vision_patch_size=14, context_length=77,
            vocab_size=300, transformer_width=64, transformer_heads=1, transformer_layers=1)   # L=26, K=588 (ViT-L/14-like pad)
 ENCODERS = {"tiny": TINY, "small": SMALL, "odd": ODD}
+# ModifiedResNet: RN50's real channel widths (64 -> 2048, 32 attention-pool heads) with one bottleneck per stage
+RESNET = dict(embed_dim=128, image_resolution=64, vision_layers=(1, 1, 1, 1), vision_width=64, vision_patch_size=None,
+              context_length=77, vocab_size=300, transformer_width=64, transformer_heads=1, transformer_layers=1)
+RESNET2 = dict(embed_dim=256, image_resolution=96, vision_layers=(2, 1, 2, 1), vision_width=64, vision_patch_size=None,
+               context_length=77, vocab_size=300, transformer_width=64, transformer_heads=1, transformer_layers=1)
+RESNETS = {"rn_a": RESNET, "rn_b": RESNET2}
 
 
 def fewshot_inputs(name):

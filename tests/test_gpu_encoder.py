@@ -243,3 +243,60 @@ def test_serving_entry_eager_and_graph(ops, tmp_path):
     assert torch.equal(t2, e2) and torch.equal(i2, j2.long())
     names, probs = clf.classify_objects(imgs)
     assert names[0][0] == f"c {int(ti[0, 0])}" and torch.equal(probs, tp)
+
+
+def test_resnet_building_blocks(ops):
+    """im2col 3x3 (NHWC and NCHW-strided, stride 1 and 2), eval BatchNorm + residual + ReLU, average pool,
+    attention-pool token assembly — each against a torch restatement, byte-exact where it is data movement."""
+    B, H, W, C = 2, 9, 7, 16
+    x = torch.from_numpy(synth.normal((B, C, H, W), 41, 0)).half()
+    nhwc = x.permute(0, 2, 3, 1).contiguous()
+    for stride in (1, 2):
+        cols = ops.im2col3x3(nhwc.cuda(), (H * W * C, W * C, C, 1), B, H, W, C, stride).cpu()
+        ref = torch.nn.functional.unfold(x.float(), 3, padding=1, stride=stride)              # [B, C*9, L] (c, ky, kx)
+        Lo = ref.shape[-1]
+        ref = ref.view(B, C, 9, Lo).permute(0, 3, 2, 1).reshape(B * Lo, 9 * C).half()        # -> (ky,kx,c)
+        assert cols.shape[1] == 192 and torch.equal(cols[:, :144], ref) and cols[:, 144:].abs().max().item() == 0
+    img = torch.from_numpy(synth.normal((B, 3, 8, 8), 41, 1)).half()                             # NCHW image, C=3 (scalar path)
+    cols = ops.im2col3x3(img.cuda(), (3 * 64, 8, 1, 64), B, 8, 8, 3, 2).cpu()
+    ref = torch.nn.functional.unfold(img.float(), 3, padding=1, stride=2)
+    ref = ref.view(B, 3, 9, -1).permute(0, 3, 2, 1).reshape(-1, 27).half()
+    assert cols.shape[1] == 64 and torch.equal(cols[:, :27], ref) and cols[:, 27:].abs().max().item() == 0
+    rows = nhwc.reshape(-1, C)
+    sc = 1 + 0.2 * torch.from_numpy(synth.normal((C,), 41, 2)).float()
+    sh = 0.3 * torch.from_numpy(synth.normal((C,), 41, 3)).float()
+    res = torch.from_numpy(synth.normal(tuple(rows.shape), 41, 4)).half()
+    y = ops.bn_act(rows.cuda(), sc.cuda(), sh.cuda(), residual=res.cuda(), relu=True).cpu()
+    ref = torch.relu(po.r16(po.r16(rows.float() * sc + sh) + res.float())).half()
+    assert ulp_diff(y, ref) <= 1
+    y = ops.bn_act(rows.cuda(), sc.cuda(), sh.cuda(), relu=False).cpu()
+    assert ulp_diff(y, po.r16(rows.float() * sc + sh).half()) <= 1
+    x8 = torch.from_numpy(synth.normal((B, C, 8, 6), 41, 5)).half()
+    p = ops.avgpool_nhwc(x8.permute(0, 2, 3, 1).contiguous().cuda(), B, 8, 6, C, 2).cpu().view(B, 4, 3, C).permute(0, 3, 1, 2)
+    assert ulp_diff(p.reshape(B * C, -1), torch.nn.functional.avg_pool2d(x8.float(), 2).half().reshape(B * C, -1)) <= 1
+    pos = torch.from_numpy(synth.normal((H * W + 1, C), 41, 6)).half()
+    t = ops.attnpool_tokens(rows.cuda(), pos.cuda(), B, H * W, C).cpu().view(B, H * W + 1, C)
+    tok = nhwc.view(B, H * W, C).float()
+    ref = torch.cat([po.r16(tok.mean(1, keepdim=True)), tok], 1)
+    assert ulp_diff(t.reshape(-1, C), po.r16(ref + pos.float()).half().reshape(-1, C)) <= 1
+
+
+@pytest.mark.parametrize("tag", ["rn_a", "rn_b"])
+def test_resnet_tower_against_reference(ops, tag):
+    """ModifiedResNet (clip/model.py:95-152) end to end against the reference's fp32 and fp16-weight towers."""
+    from conftest import RESNETS
+    g = golden("encoder_" + tag)
+    kw = RESNETS[tag]
+    sd = random_state_dict(seed=13, **kw)
+    model = build_model({k: v.clone() for k, v in sd.items()}).cuda()
+    assert set(model.state_dict()) == set(sd)
+    imgs = synth.make_images(6, kw["image_resolution"], seed=5, n_class=6)
+    f = model.encode_image(imgs.cuda())
+    assert f.dtype == torch.float16 and f.shape == (6, kw["embed_dim"])
+    r16_, r32_ = torch.from_numpy(g["img_f16"]), torch.from_numpy(g["img_f32"])
+    gap = rel_err(r16_, r32_)
+    assert rel_err(f, r32_) <= max(2.0 * gap, 5e-3), (rel_err(f, r32_), gap)
+    assert rel_err(f, r16_) <= max(2.0 * gap, 5e-3), (rel_err(f, r16_), gap)
+    assert rel_err(f, clip_oracle.encode_image_resnet(sd, imgs, half=True)) <= 5e-3
+    model.visual.chunk = 4                                 # chunked path == single pass
+    assert torch.equal(model.encode_image(imgs.cuda()).cpu(), f.cpu())
