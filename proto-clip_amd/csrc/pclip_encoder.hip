@@ -4,6 +4,7 @@
 // kernel (the CLIP sequences, 50..257 tokens, fit one workgroup, so no online softmax is needed).
 #include "pclip_gemm.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -386,38 +387,44 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const half_t* __restr
         constexpr float kScale = 0.125f * 1.4426950408889634f;
         float mrun = -__builtin_inff(), lrun = 0.f;
         const int tend = causal ? (qb + 1 < NT ? qb + 1 : NT) : NT;      // causal: keys beyond the block's last query are all masked
-        for (int t = 0; t < tend; ++t) {
-            float16_t st;
+        // Key tiles are taken two at a time: the two score accumulators are independent MFMA chains (a single
+        // 32x32x16 chain is issue-limited by its own accumulator dependency), and one max / rescale serves 64 keys.
+        auto tiles = [&](auto NTILE_C, int t0) {
+            constexpr int NTILE = decltype(NTILE_C)::value;
+            float16_t st[NTILE];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) st[e] = 0.f;
-            const int kr = t * 32 + ql;                 // key row this lane feeds as the A operand
+            for (int u = 0; u < NTILE; ++u)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + kr * ATT_DH + (((s * 2 + hi) ^ pgemm::swz_key(kr)) << 3));
-                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st, 0, 0, 0);
-            }
-            const bool need_mask = (t * 32 + 32 > L) || (causal && t == qb);     // wave-uniform
+                for (int e = 0; e < 16; ++e) st[u][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int u = 0; u < NTILE; ++u) {
+                    const int kr = (t0 + u) * 32 + ql;                 // key row this lane feeds as the A operand
+                    const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + kr * ATT_DH + (((s * 2 + hi) ^ pgemm::swz_key(kr)) << 3));
+                    st[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[u], 0, 0, 0);
+                }
             float tmax = -__builtin_inff();
-            if (need_mask) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int k = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                    const bool ok = k < L && (!causal || k <= q);
-                    st[e] = ok ? st[e] * kScale : -__builtin_inff();
-                    tmax = fmaxf(tmax, st[e]);
-                }
-            } else {
+            for (int u = 0; u < NTILE; ++u) {
+                const int t = t0 + u;
+                if ((t * 32 + 32 > L) || (causal && t == qb)) {        // wave-uniform: only edge tiles pay for the mask
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    st[e] *= kScale;
-                    tmax = fmaxf(tmax, st[e]);
+                    for (int e = 0; e < 16; ++e) {
+                        const int k = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                        if (!(k < L && (!causal || k <= q))) st[u][e] = -__builtin_inff();
+                    }
                 }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, st[u][e]);
             }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, WAVE));
-            const float mnew = fmaxf(mrun, tmax);       // finite from the first tile on: key 0 is never masked
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, WAVE)) * kScale;   // kScale > 0: max commutes with the scaling
+            const float mnew = fmaxf(mrun, tmax);                      // finite from the first tile on: key 0 is never masked
             float psum = 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { st[e] = __builtin_amdgcn_exp2f(st[e] - mnew); psum += st[e]; }
+            for (int u = 0; u < NTILE; ++u)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { st[u][e] = __builtin_amdgcn_exp2f(fmaf(st[u][e], kScale, -mnew)); psum += st[u][e]; }
             psum += __shfl_xor(psum, 32, WAVE);
             if (__any(mnew != mrun)) {
                 const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
@@ -430,21 +437,26 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const half_t* __restr
             lrun += psum;
             mrun = mnew;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                half8_t pf;
+            for (int u = 0; u < NTILE; ++u)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pf[e] = (half_t)st[s * 8 + e];
+                for (int s = 0; s < 2; ++s) {
+                    half8_t pf;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    // V^T fragment: row d = j*32 + ql, keys t*32 + 16s + 4hi + {0..3} and the same + 8
-                    const half_t* vp = Vt + (j * 32 + ql) * LV + t * 32 + s * 16 + hi * 4;
-                    const half4_t v0 = *reinterpret_cast<const half4_t*>(vp);
-                    const half4_t v1 = *reinterpret_cast<const half4_t*>(vp + 8);
-                    const half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[j], 0, 0, 0);
+                    for (int e = 0; e < 8; ++e) pf[e] = (half_t)st[u][s * 8 + e];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        // V^T fragment: row d = j*32 + ql, keys t*32 + 16s + 4hi + {0..3} and the same + 8
+                        const half_t* vp = Vt + (j * 32 + ql) * LV + (t0 + u) * 32 + s * 16 + hi * 4;
+                        const half4_t v0 = *reinterpret_cast<const half4_t*>(vp);
+                        const half4_t v1 = *reinterpret_cast<const half4_t*>(vp + 8);
+                        const half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                        o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[j], 0, 0, 0);
+                    }
                 }
-            }
-        }
+        };
+        int t = 0;
+        for (; t + 1 < tend; t += 2) tiles(std::integral_constant<int, 2>{}, t);
+        if (t < tend) tiles(std::integral_constant<int, 1>{}, t);
         // O^T tile: column q = lane & 31 (this lane's query), rows d = j*32 + 8*(e>>2) + 4*hi + (e&3)
         if (q < L) {
             const float inv = 1.f / lrun;

@@ -32,9 +32,9 @@ def sharded_prototypes(mem_shard, labels_shard, N: int, per_shot_norm: bool = Tr
         partial_fn = partial_fn or ops.partial_sums
         finalize_fn = finalize_fn or ops.proto_finalize
     sums, counts = partial_fn(mem_shard, labels_shard, N, per_shot_norm)
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return finalize_fn(sums[None], counts[None], fp32_out=fp32_out)
+    world = dist.get_world_size(group)
     D = sums.shape[1]
     # one message per rank: [N*D sums | N counts (bit-cast to fp32)] so a single all-gather suffices
     payload = torch.cat([sums.reshape(-1), counts.view(torch.float32).reshape(-1)])

@@ -236,7 +236,7 @@ def test_adapter_random_weights_vs_oracle(ops, kind, D):
 
 
 # ---------------------------------------------------------------- whole test pass ----------------------
-@pytest.mark.parametrize("name", ["C2", "C6", "C5", "C1"])
+@pytest.mark.parametrize("name", ["C2", "C6", "C5", "C1", "C3"])
 def test_run_proto_clip_test_pass(ops, name, tmp_path, monkeypatch):
     """reference main.py:383-455 through proto_clip_amd.main.run_proto_clip, against the reference's grids."""
     import os
