@@ -88,15 +88,20 @@ def measure_gemm(st):
         rec.append((e0, e1, gemm_flops(a.shape[0], w.shape[0], a.shape[1])))
         return y
 
+    from proto_clip_amd import _lib
+    lib = _lib.load()
     ops.gemm = timed
+    n0 = lib.pclip_gemm_kernel_launches()
     try:
         step(st)
         torch.cuda.synchronize()
     finally:
         ops.gemm = real
+    launches = lib.pclip_gemm_kernel_launches() - n0           # a call whose last round is split = two kernel launches
     ms = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
     fl = sum(f for _, _, f in rec)
-    return dict(launches=len(rec), total_ms=ms, avg_us=1e3 * ms / max(len(rec), 1), tflops=fl / (ms * 1e-3) / 1e12, flops=fl)
+    return dict(launches=launches, calls=len(rec), total_ms=ms, avg_us=1e3 * ms / max(launches, 1),
+                tflops=fl / (ms * 1e-3) / 1e12, flops=fl)
 
 
 def pmc_traffic():

@@ -35,6 +35,9 @@ int pclip_abi_version(void);
 const char* pclip_last_error(void);
 /* number of compute units of the current device (used by host code to size batches) */
 int pclip_device_cus(void);
+/* cumulative number of GEMM KERNEL launches issued by pclip_gemm_f16 in this process (one call may be split into
+ * two launches, see the dispatch in csrc/pclip_encoder.hip); bench.py uses the delta to quote per-launch figures */
+long pclip_gemm_kernel_launches(void);
 
 /* ---- memory-bank / prototype reductions -------------------------------------------------- */
 

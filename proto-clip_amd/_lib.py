@@ -25,6 +25,7 @@ _SIGS = {
     "pclip_abi_version": [],
     "pclip_last_error": [],
     "pclip_device_cus": [],
+    "pclip_gemm_kernel_launches": [],
     "pclip_l2norm_rows_f16": [_P, _P, c_int, c_int, _P, _P],
     "pclip_row_sqnorm_f16": [_P, c_int, c_int, _P, _P],
     "pclip_proto_build_f16": [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P],
@@ -56,7 +57,7 @@ _SIGS = {
     "pclip_cast_f32_f16": [_P, _P, c_size_t, _P],
     "pclip_workspace_bytes": [c_int, c_int, c_int, c_int],
 }
-_RESTYPES = {"pclip_last_error": c_char_p, "pclip_workspace_bytes": c_size_t}
+_RESTYPES = {"pclip_last_error": c_char_p, "pclip_workspace_bytes": c_size_t, "pclip_gemm_kernel_launches": c_long}
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
 

@@ -116,9 +116,9 @@ class VisionTransformer(nn.Module):
         self.ln_post = _ln(width)
         self.proj = nn.Parameter(torch.empty(width, output_dim), requires_grad=False)
         self._cache = _Cached()
-        # images per pass: bounds activation memory (c_fc output = chunk*L*4W*2 B) and keeps tile counts
-        # a large multiple of the 512 resident GEMM workgroups (tail quantisation); tuned on MI355X
-        self.chunk = int(os.environ.get("PCLIP_VIT_CHUNK", "256"))
+        # images per pass: bounds activation memory (c_fc output = chunk*L*4W*2 B = 1.2 GB for ViT-B/16 at 1024);
+        # larger passes waste less of the GEMMs' last round of persistent tiles (measured on MI355X: 1024 > 512 > 256)
+        self.chunk = int(os.environ.get("PCLIP_VIT_CHUNK", "1024"))
 
     def forward(self, x: torch.Tensor):
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != self.input_resolution or x.shape[3] != self.input_resolution:

@@ -558,6 +558,77 @@ inline int flat_grid(size_t n) { size_t g = (n + 255) / 256; return (int)(g < 1 
 
 }  // namespace
 
+// Tile choice and row split.  The fast kernels are persistent (one workgroup per resident slot), so a launch costs
+// ceil(tiles / slots) ROUNDS of one tile each; when the last round is mostly empty (M=50432, N=768: 591 tiles of
+// 256x256 on 256 slots = 2.31 rounds, paid as 3) the rows of the partial round are split off and dispatched again,
+// where a smaller tile spreads them over every CU.  Estimated time of a configuration = rounds x tile area x
+// (slots / CUs) / relative K-loop rate (measured on MI355X, tools/ab_cfg.py), in units of 128x128 tile areas.
+static long g_gemm_launches = 0;
+extern "C" long pclip_gemm_kernel_launches(void) { return g_gemm_launches; }
+
+namespace {
+struct TileCfg { int bm, bn, wg_per_cu; double eff; };
+constexpr TileCfg kTileCfgs[3] = {{128, 128, 2, 0.85}, {256, 128, 1, 0.85}, {256, 256, 1, 1.0}};
+constexpr double kLaunchCost = 0.5;          // extra launch of a split, in the same units
+
+inline double tile_cost(const TileCfg& c, long M, int N, int cus) {
+    if (N % c.bn) return 1e30;
+    const long slots = (long)c.wg_per_cu * cus, nt = ((M + c.bm - 1) / c.bm) * (N / c.bn);
+    return (double)((nt + slots - 1) / slots) * (c.bm / 128.0) * (c.bn / 128.0) * c.wg_per_cu / c.eff;
+}
+inline int best_cfg(long M, int N, int cus, double* cost_out) {
+    int pick = -1;
+    double best = 1e29;
+    for (int i = 0; i < 3; ++i) {
+        const double c = tile_cost(kTileCfgs[i], M, N, cus);
+        if (c < best) { best = c; pick = i; }
+    }
+    if (cost_out) *cost_out = best;
+    return pick;
+}
+
+int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int N, int K, LinearEpi epi, int cus, int forced,
+                  bool may_split, hipStream_t s) {
+    const bool aligned = !epi.residual && epi.ldc % 8 == 0 && ((uintptr_t)epi.C & 15) == 0 && (!epi.bias || ((uintptr_t)epi.bias & 15) == 0);
+    double cost = 1e30;
+    int pick = aligned ? best_cfg(M, N, cus, &cost) : -1;
+    if (forced >= 0) {
+        may_split = false;
+        if (forced == 3) pick = -1;
+        else if (aligned && forced < 3 && N % kTileCfgs[forced].bn == 0) pick = forced;
+    }
+    if (pick >= 0 && may_split) {
+        long split_rows = 0;                                   // rows given to the full rounds of configuration split_cfg
+        int split_cfg = -1;
+        for (int i = 0; i < 3; ++i) {
+            const TileCfg& c = kTileCfgs[i];
+            if (N % c.bn) continue;
+            const long slots = (long)c.wg_per_cu * cus, tiles_n = N / c.bn, nt = ((M + c.bm - 1) / c.bm) * tiles_n;
+            const long full_rows = (nt / slots) * slots / tiles_n * c.bm;
+            if (nt <= slots || nt % slots == 0 || full_rows >= M) continue;
+            double rest = 1e30;
+            best_cfg(M - full_rows, N, cus, &rest);
+            const double split = tile_cost(c, full_rows, N, cus) + rest + kLaunchCost;
+            if (split < cost) { cost = split; split_cfg = i; split_rows = full_rows; }
+        }
+        if (split_cfg >= 0) {
+            int rc = gemm_dispatch(A, lda, B, ldb, (int)split_rows, N, K, epi, cus, split_cfg, false, s);
+            if (rc != PCLIP_OK) return rc;
+            LinearEpi tail = epi;
+            tail.C = epi.C + (size_t)split_rows * epi.ldc;
+            return gemm_dispatch(A + (size_t)split_rows * lda, lda, B, ldb, M - (int)split_rows, N, K, tail, cus, -1, true, s);
+        }
+    }
+    ++g_gemm_launches;
+    if (pick == 2) return launch_fast<CfgBig>(A, lda, B, ldb, M, N, K, epi, cus, s);
+    if (pick == 1) return launch_fast<CfgWide>(A, lda, B, ldb, M, N, K, epi, cus, s);
+    if (pick == 0) return launch_fast<CfgSmall>(A, lda, B, ldb, M, N, K, epi, 2 * cus, s);
+    const int tiles_m = ceil_div(M, 128), tiles_n = ceil_div(N, 128);
+    linear_generic_kernel<<<tiles_m * tiles_n, 256, CfgSmall::LDS_BYTES, s>>>(A, lda, B, ldb, M, N, K, epi, tiles_n);
+    return pclip_check_launch("gemm_f16 (generic)");
+}
+}  // namespace
+
 extern "C" int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                               const void* bias, int act, const void* residual, pclip_stream_t stream) {
     PCLIP_REQUIRE(A && B && C, "pclip_gemm_f16: null pointer");
@@ -569,35 +640,16 @@ extern "C" int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, vo
     LinearEpi epi{(const half_t*)bias, (const half_t*)residual, (half_t*)C, ldc, act};
     static int cus = 0;
     static int forced = -1;
-    if (!cus) {
+    static bool live = false, nosplit = false;
+    if (!cus || live) {
         cus = pclip_device_cus();
         if (cus <= 0) cus = 256;
         const char* f = getenv("PCLIP_GEMM_CFG");          // tuning override: 0 small, 1 wide, 2 big, 3 generic
         forced = f ? atoi(f) : -1;
+        live = getenv("PCLIP_GEMM_CFG_LIVE") != nullptr;   // tools/ab_cfg.py: re-read the overrides on every call
+        nosplit = getenv("PCLIP_GEMM_NOSPLIT") != nullptr;
     }
-    hipStream_t s = (hipStream_t)stream;
-    const bool aligned = !residual && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0);
-    // Tile choice among the configurations whose BN divides N: estimated time = rounds of resident workgroups
-    // x tile area / relative K-loop rate of the configuration (measured on MI355X, tools/kernel_bench.py).
-    auto cost = [&](int bm, int bn, int slots, double eff) {
-        if (!aligned || N % bn) return 1e30;
-        const long nt = (long)ceil_div(M, bm) * (N / bn);
-        return (double)((nt + slots - 1) / slots) * bm * bn * (slots / (double)cus) / eff;
-    };
-    const double c_small = cost(128, 128, 2 * cus, 0.85), c_wide = cost(256, 128, cus, 0.85), c_big = cost(256, 256, cus, 1.0);
-    int pick = 3;
-    double best = 1e29;
-    if (c_small < best) { best = c_small; pick = 0; }
-    if (c_wide < best) { best = c_wide; pick = 1; }
-    if (c_big < best) { best = c_big; pick = 2; }
-    if (forced >= 0 && (forced == 3 || cost(forced == 2 ? 256 : (forced == 1 ? 256 : 128), forced == 2 ? 256 : 128, cus, 1.0) < 1e29)) pick = forced;
-    if (pick == 2) return launch_fast<CfgBig>(A, lda, B, ldb, M, N, K, epi, cus, s);
-    if (pick == 1) return launch_fast<CfgWide>(A, lda, B, ldb, M, N, K, epi, cus, s);
-    if (pick == 0) return launch_fast<CfgSmall>(A, lda, B, ldb, M, N, K, epi, 2 * cus, s);
-    const int tiles_m = ceil_div(M, 128), tiles_n = ceil_div(N, 128);
-    linear_generic_kernel<<<tiles_m * tiles_n, 256, CfgSmall::LDS_BYTES, s>>>((const half_t*)A, lda, (const half_t*)B, ldb,
-                                                                             M, N, K, epi, tiles_n);
-    return pclip_check_launch("gemm_f16 (generic)");
+    return gemm_dispatch((const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, cus, forced, !nosplit, (hipStream_t)stream);
 }
 
 #define DISPATCH_NCH(D, CALL)                                  \

@@ -50,6 +50,26 @@ def test_gemm_epilogues(ops, M, N, K):
     assert torch.equal(ops.gemm(ai.cuda(), wi.cuda()).cpu().float(), (ai.float() @ wi.float().t()).half().float())
 
 
+@pytest.mark.parametrize("M,N,K", [(50432, 768, 64), (50432, 3072, 64), (70001, 512, 64), (201728, 768, 64)])
+def test_gemm_row_split(ops, M, N, K):
+    """Shapes whose last round of persistent tiles is mostly empty are dispatched as two launches (full rounds with the
+    large tile + the remaining rows with a smaller one): every output row must come out exactly as from one launch.
+    Integer-valued operands make the product exact, so any dropped / doubled / misplaced row block shows."""
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    a = torch.randint(-3, 4, (M, K), device="cuda", generator=g).half()
+    w = torch.randint(-2, 3, (N, K), device="cuda", generator=g).half()
+    bias = torch.randint(-4, 5, (N,), device="cuda", generator=g).half()
+    n0 = ops._lib.load().pclip_gemm_kernel_launches()
+    y = ops.gemm(a, w, bias)
+    launches = ops._lib.load().pclip_gemm_kernel_launches() - n0
+    ref = torch.empty_like(y)
+    for i in range(0, M, 16384):                            # fp32 reference in slabs (bounded memory)
+        ref[i:i + 16384] = (a[i:i + 16384].float() @ w.float().t() + bias.float()).half()
+    assert torch.equal(y, ref)
+    if ops._lib.load().pclip_device_cus() == 256 and (M, N) == (50432, 768):
+        assert launches == 2                                # 2 full rounds of 256x256 tiles + the last 6912 rows
+
+
 @pytest.mark.parametrize("R,D", [(7, 64), (500, 768), (197, 1024), (3, 512)])
 def test_layernorm(ops, R, D):
     x = (torch.from_numpy(synth.normal((R, D), 22, 0)).float() * 2 + 0.3).half()
