@@ -195,6 +195,70 @@ int pclip_attnpool_tokens_f16(const void* x, const void* pos, int B, int HW, int
 /* fp32 -> fp16 cast (image.type(self.dtype), clip/model.py:339). */
 int pclip_cast_f32_f16(const float* x, void* y, size_t n, pclip_stream_t stream);
 
+/* ---- episodic training step (reference main.py:216-310, utils.py:80-109; torch autograd + torch.optim.AdamW there) -------- */
+
+/* fp16 -> fp32 copy (`.float()`, main.py:263, 270, 279). */
+int pclip_cast_f16_f32(const void* x, float* y, size_t n, pclip_stream_t stream);
+
+/* C[M,N] (ldc) = alpha * op(A) op(B) + beta * C on v_mfma_f32_32x32x2_f32, element (m,k) of op(A) at A[m*rsa + k*csa], element
+ * (k,n) of op(B) at B[k*rsb + n*csb]; a_f16 / b_f16 != 0: that operand is fp16 in memory (exact in fp32).  Serves every
+ * matmul autograd issues in the training step: cdist backward (dq = -2 G Z, dz = -2 G^T q), InfoNCE logits and their
+ * gradients, Linear weight / input gradients of Adapter_FC. */
+int pclip_gemm_f32(const void* A, int a_f16, long rsa, long csa, const void* B, int b_f16, long rsb, long csb, float* C, int ldc,
+                   int M, int N, int K, float alpha, float beta, pclip_stream_t stream);
+
+/* out[c] (+)= scale * sum_r x[r, c]  (fixed summation order; accumulate != 0 adds to out). */
+int pclip_colsum_f32(const float* x, int ldx, int R, int C, float scale, float* out, int accumulate, pclip_stream_t stream);
+
+/* C[r, :] += s * rowscale[r] * X[r, :]  (the 2*rowsum(G)*q and 2*colsum(G)*z terms of the cdist backward). */
+int pclip_addscaled_rows_f32(float* C, int ldc, const float* X, int ldx, const float* rowscale, float s, int R, int D,
+                             pclip_stream_t stream);
+
+/* L = mean_q -log p[q, y_q] with p as in pclip_fuse_probs (utils.py:90-93 `NLLLoss()(torch.log(p), target)`): per-query terms
+ * nll[q] = -log p[q,y_q], pmax[q], argmax[q] (utils.py:84-85) and the gradients gi/gt [Q, ldd] of L wrt the two squared-distance
+ * rows; rowsum[q] = sum_c (gi + gt)[q, c]. */
+int pclip_nll_grad(const float* d2i, const float* d2t, const int32_t* labels, int Q, int N, int ldd, float alpha,
+                   float one_minus_alpha, float beta, float* gi, float* gt, float* rowsum, float* nll, float* pmax,
+                   int32_t* argmax, pclip_stream_t stream);
+
+/* Cross entropy of the rows of S [R, C>=R] against the diagonal (InfoNCE of utils.py:72-77 with the info-nce-pytorch
+ * defaults): loss[r] = logsumexp(S[r,:]) - S[r,r], dS[r,c] = scale * (softmax(S[r,:])[c] - [c == r]). */
+int pclip_softmax_ce_rows(const float* S, int lds, int R, int C, float scale, float* dS, int ldds, float* loss,
+                          pclip_stream_t stream);
+
+/* F.normalize(x, dim=-1, eps) on fp32 rows and its backward gx (+)= (gy - y (y.gy)) / max(|x|, eps): InfoNCE normalises
+ * both of its arguments (utils.py:72-77). */
+int pclip_l2norm_rows_f32(const float* x, float* y, int R, int D, float eps, pclip_stream_t stream);
+int pclip_l2norm_rows_backward_f32(const float* x, const float* gy, float* gx, int R, int D, float eps, int accumulate,
+                                   pclip_stream_t stream);
+
+/* Backward of the prototype chain (main.py:260-264 image bank; 276-279 text bank with K = 1, final_norm = 0; the query rows
+ * `adapter(x).float()` / norm with K = 1, per_shot_norm = 0): g [N, D] fp32 is the gradient wrt the chain's fp32 output, dmem
+ * [N*K, D] fp16 the gradient wrt the fp16 rows `mem`; fp16 stages are rounded where autograd materialises fp16 tensors. */
+int pclip_proto_backward_f16(const void* mem, const float* g, int N, int K, int D, int per_shot_norm, int final_norm, void* dmem,
+                             pclip_stream_t stream);
+
+/* nn.LayerNorm backward on fp16 tensors (model.py:86, 88): dx [R, D]; part [nblk][2][D] fp32 receives the partial
+ * (dgamma | dbeta) sums of the rows each of the nblk workgroups visits (reduce with pclip_colsum_f32).  dy_scale: factor applied
+ * to dy first, rounded to fp16 (the `ratio * x` of model.py:93-94). */
+int pclip_layernorm_backward_f16(const void* x, int ldx, const void* gamma, const void* dy, int lddy, int R, int D, float eps,
+                                 float dy_scale, void* dx, int lddx, float* part, int nblk, pclip_stream_t stream);
+
+/* Backward of pclip_adapter_conv_f16 for the training step (reference: autograd through model.py:49-78; the input rows
+ * are constants, main.py:266).  x, g [B, D] fp16 (input rows, gradient wrt the adapter output).  Outputs are PER-ROW fp32
+ * contributions to the parameter gradients, to be summed over rows with pclip_colsum_f32: pw1/pw3 [B,16] (conv1 / conv3),
+ * pw2 [B, 16*16*9] (conv2, layout [co][ci][ky][kx]), pg1/pb1, pg2/pb2 [B, 16*s*s], pg3/pb3 [B, s*s] (LayerNorm weight | bias),
+ * s = ceil(sqrt(D)).  conv-2x: conv2 / ln2* / pw2 / pg2 / pb2 are NULL (those parameters receive no gradient). */
+int pclip_adapter_conv_backward_f16(const void* x, const void* g, int B, int D, int three_x, const void* conv1, const void* ln1w,
+                                    const void* ln1b, const void* conv2, const void* ln2w, const void* ln2b, const void* conv3,
+                                    const void* ln3w, float* pw1, float* pw2, float* pw3, float* pg1, float* pb1, float* pg2,
+                                    float* pb2, float* pg3, float* pb3, pclip_stream_t stream);
+
+/* One torch.optim.AdamW step (main.py:134-135: eps 1e-4, weight_decay 0.05) on fp16 parameters with fp16 moments, every
+ * intermediate rounded to fp16 where the single-tensor implementation materialises an fp16 tensor; step counts from 1. */
+int pclip_adamw_f16(void* p, const void* g, void* m, void* v, size_t n, double lr, double beta1, double beta2, double eps,
+                    double weight_decay, int step, pclip_stream_t stream);
+
 /* ---- workspace sizing -------------------------------------------------------------------- */
 #define PCLIP_OP_SQDIST 1
 #define PCLIP_OP_CLASSIFY 2

@@ -3,7 +3,7 @@ or a call fails, a loud exception is raised — the product path never routes th
 PyTorch-eager substitute."""
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
 
 import torch
 
@@ -55,6 +55,18 @@ _SIGS = {
     "pclip_avgpool_nhwc_f16": [_P, c_int, c_int, c_int, c_int, c_int, _P, _P],
     "pclip_attnpool_tokens_f16": [_P, _P, c_int, c_int, c_int, _P, _P],
     "pclip_cast_f32_f16": [_P, _P, c_size_t, _P],
+    "pclip_cast_f16_f32": [_P, _P, c_size_t, _P],
+    "pclip_gemm_f32": [_P, c_int, c_long, c_long, _P, c_int, c_long, c_long, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P],
+    "pclip_colsum_f32": [_P, c_int, c_int, c_int, c_float, _P, c_int, _P],
+    "pclip_adapter_conv_backward_f16": [_P, _P, c_int, c_int, c_int] + [_P] * 8 + [_P] * 9 + [_P],
+    "pclip_addscaled_rows_f32": [_P, c_int, _P, c_int, _P, c_float, c_int, c_int, _P],
+    "pclip_nll_grad": [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P, _P],
+    "pclip_softmax_ce_rows": [_P, c_int, c_int, c_int, c_float, _P, c_int, _P, _P],
+    "pclip_l2norm_rows_f32": [_P, _P, c_int, c_int, c_float, _P],
+    "pclip_l2norm_rows_backward_f32": [_P, _P, _P, c_int, c_int, c_float, c_int, _P],
+    "pclip_proto_backward_f16": [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P],
+    "pclip_layernorm_backward_f16": [_P, c_int, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, c_int, _P, c_int, _P],
+    "pclip_adamw_f16": [_P, _P, _P, _P, c_size_t, c_double, c_double, c_double, c_double, c_double, c_int, _P],
     "pclip_workspace_bytes": [c_int, c_int, c_int, c_int],
 }
 _RESTYPES = {"pclip_last_error": c_char_p, "pclip_workspace_bytes": c_size_t, "pclip_gemm_kernel_launches": c_long}

@@ -178,6 +178,321 @@ __global__ __launch_bounds__(256) void adapter_conv_kernel(const half_t* __restr
     }
 }
 
+// ---- backward of the conv adapter for the training step (main.py:267 `adapter(zq_imgs)`; autograd in the reference) ----
+// One workgroup per row again: the forward is recomputed into LDS (nothing was saved), then the chain
+//   +identity <- LN3 <- conv3 <- [LN2 <- conv2 <-] LN1 <- conv1
+// is walked backwards with every gradient tensor rounded to fp16 where autograd materialises one.  The input rows are
+// constants (main.py:266), so only parameter gradients leave the kernel, as PER-ROW contributions (fp32) that the host
+// reduces over rows with pclip_colsum_f32 — deterministic, no atomics:
+//   pw1/pw3 [B,16], pw2 [B,2304], pg1/pb1/pg2/pb2 [B,16*s2], pg3/pb3 [B,s2]   (dgamma | dbeta of the three LayerNorms)
+// Extra LDS over the forward: dt2 as channel pairs with a zero halo (the transposed 3x3 convolution reads it the way the
+// forward reads a1) and conv2's weights paired over the OUTPUT channel.
+__device__ __forceinline__ void block_sum16(float (&v)[CW], float* red /* [4][16] */) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) v[c] = wave_sum(v[c]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) red[wave * CW + c] = v[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CW; ++c) v[c] = red[c] + red[CW + c] + red[2 * CW + c] + red[3 * CW + c];
+}
+
+template <bool THREE_X>
+__global__ __launch_bounds__(256) void adapter_conv_backward_kernel(
+    const half_t* __restrict__ x, const half_t* __restrict__ g, int D, int s, const half_t* __restrict__ conv1,
+    const half_t* __restrict__ ln1w, const half_t* __restrict__ ln1b, const half_t* __restrict__ conv2,
+    const half_t* __restrict__ ln2w, const half_t* __restrict__ ln2b, const half_t* __restrict__ conv3,
+    const half_t* __restrict__ ln3w, float* __restrict__ pw1, float* __restrict__ pw2, float* __restrict__ pw3,
+    float* __restrict__ pg1, float* __restrict__ pb1, float* __restrict__ pg2, float* __restrict__ pb2,
+    float* __restrict__ pg3, float* __restrict__ pb3) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int s2 = s * s, sp = s + 2, hp = sp * sp, n1 = CW * s2;
+    float* xs = reinterpret_cast<float*>(smem);
+    float* u = xs + 1024;
+    float* red = u + 1024;                                       // [4] scalar reductions, then [64] for block_sum16
+    float* red16 = red + 4;
+    half2_t* a1p = reinterpret_cast<half2_t*>(red16 + 64);
+    half_t* t2 = reinterpret_cast<half_t*>(a1p + 8 * hp);        // conv2 output, later reused for da1
+    half2_t* d2p = reinterpret_cast<half2_t*>(t2 + CW * s2);     // dt2, channel pairs over co, zero halo
+    half2_t* w2p = d2p + 8 * hp;                                 // [ci pair][tap][co]
+    half2_t* w2t = w2p + 8 * 9 * CW;                             // [co pair][tap][ci]
+    const int tid = threadIdx.x;
+    const size_t row = blockIdx.x;
+    const float eps = 1e-5f;
+
+    for (int p = tid; p < s2; p += 256) xs[p] = p < D ? (float)x[row * D + p] : 0.f;
+    float w1[CW], w3[CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) { w1[c] = (float)conv1[c]; w3[c] = (float)conv3[c]; }
+    if (THREE_X) {
+        for (int i = tid; i < 8 * hp; i += 256) { a1p[i] = half2_t{(half_t)0.f, (half_t)0.f}; d2p[i] = half2_t{(half_t)0.f, (half_t)0.f}; }
+        for (int i = tid; i < 8 * 9 * CW; i += 256) {
+            const int o = i % CW, tap = (i / CW) % 9, pr = i / (CW * 9);
+            w2p[i] = half2_t{conv2[(o * CW + 2 * pr) * 9 + tap], conv2[(o * CW + 2 * pr + 1) * 9 + tap]};          // o = co, pr = ci pair
+            w2t[i] = half2_t{conv2[((2 * pr) * CW + o) * 9 + tap], conv2[((2 * pr + 1) * CW + o) * 9 + tap]};      // o = ci, pr = co pair
+        }
+    }
+    __syncthreads();
+
+    // ---------------- forward recomputation (identical arithmetic to adapter_conv_kernel) ----------------
+    float sm = 0.f;
+    for (int p = tid; p < s2; p += 256) {
+        const float xv = xs[p];
+#pragma unroll
+        for (int c = 0; c < CW; ++c) sm += r16(w1[c] * xv);
+    }
+    const float mean1 = block_sum(sm, red) / (float)n1;
+    float sq = 0.f;
+    for (int p = tid; p < s2; p += 256) {
+        const float xv = xs[p];
+#pragma unroll
+        for (int c = 0; c < CW; ++c) { const float t = r16(w1[c] * xv) - mean1; sq += t * t; }
+    }
+    const float rstd1 = 1.f / sqrtf(block_sum(sq, red) / (float)n1 + eps);
+    float mean2 = 0.f, rstd2 = 0.f;
+    if (THREE_X) {
+        for (int p = tid; p < s2; p += 256) {
+            const float xv = xs[p];
+            const int py = p / s, px = p - py * s;
+            const int hpos = (py + 1) * sp + px + 1;
+#pragma unroll
+            for (int cp = 0; cp < 8; ++cp) {
+                const int c0 = 2 * cp, c1 = c0 + 1;
+                const float a0 = (r16(w1[c0] * xv) - mean1) * rstd1 * (float)ln1w[c0 * s2 + p] + (float)ln1b[c0 * s2 + p];
+                const float a1 = (r16(w1[c1] * xv) - mean1) * rstd1 * (float)ln1w[c1 * s2 + p] + (float)ln1b[c1 * s2 + p];
+                a1p[cp * hp + hpos] = half2_t{(half_t)a0, (half_t)a1};
+            }
+        }
+        __syncthreads();
+        float sm2 = 0.f;
+        for (int p = tid; p < s2; p += 256) {
+            const int py = p / s, px = p - py * s;
+            float acc[CW];
+#pragma unroll
+            for (int c = 0; c < CW; ++c) acc[c] = 0.f;
+#pragma unroll 1
+            for (int cp = 0; cp < 8; ++cp) {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int dy = tap / 3, dx = tap - dy * 3;
+                    const half2_t a = a1p[cp * hp + (py + dy) * sp + px + dx];
+                    const half2_t* wv = w2p + (cp * 9 + tap) * CW;
+#pragma unroll
+                    for (int co = 0; co < CW; ++co) acc[co] = __builtin_amdgcn_fdot2(a, wv[co], acc[co], false);
+                }
+            }
+#pragma unroll
+            for (int co = 0; co < CW; ++co) {
+                const half_t h = (half_t)acc[co];
+                t2[co * s2 + p] = h;
+                sm2 += (float)h;
+            }
+        }
+        mean2 = block_sum(sm2, red) / (float)n1;
+        float sq2 = 0.f;
+        for (int i = tid; i < n1; i += 256) { const float t = (float)t2[i] - mean2; sq2 += t * t; }
+        rstd2 = 1.f / sqrtf(block_sum(sq2, red) / (float)n1 + eps);
+        for (int p = tid; p < s2; p += 256) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                const float a2 = r16(((float)t2[c * s2 + p] - mean2) * rstd2 * (float)ln2w[c * s2 + p] + (float)ln2b[c * s2 + p]);
+                acc = fmaf(w3[c], a2, acc);
+            }
+            u[p] = r16(acc);
+        }
+    } else {
+        for (int p = tid; p < s2; p += 256) {
+            const float xv = xs[p];
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                const float a1 = r16((r16(w1[c] * xv) - mean1) * rstd1 * (float)ln1w[c * s2 + p] + (float)ln1b[c * s2 + p]);
+                acc = fmaf(w3[c], a1, acc);
+            }
+            u[p] = r16(acc);
+        }
+    }
+    float s3 = 0.f;
+    for (int p = tid; p < s2; p += 256) s3 += u[p];
+    const float mean3 = block_sum(s3, red) / (float)s2;
+    float q3 = 0.f;
+    for (int p = tid; p < s2; p += 256) { const float t = u[p] - mean3; q3 += t * t; }
+    const float rstd3 = 1.f / sqrtf(block_sum(q3, red) / (float)s2 + eps);
+
+    // ---------------- LN3 backward: upstream = g on the first D positions (crop + identity add pass it through) ----------
+    float sa = 0.f, sb = 0.f;
+    for (int p = tid; p < s2; p += 256) {
+        const float go = p < D ? (float)g[row * D + p] : 0.f;
+        const float xh = (u[p] - mean3) * rstd3, gy = go * (float)ln3w[p];
+        sa += gy;
+        sb += gy * xh;
+        pg3[row * s2 + p] = go * xh;
+        pb3[row * s2 + p] = go;
+    }
+    const float A3 = block_sum(sa, red) / (float)s2, B3 = block_sum(sb, red) / (float)s2;
+    for (int p = tid; p < s2; p += 256) {
+        const float go = p < D ? (float)g[row * D + p] : 0.f;
+        const float xh = (u[p] - mean3) * rstd3, gy = go * (float)ln3w[p];
+        u[p] = r16(rstd3 * (gy - A3 - xh * B3));                    // du, fp16 like autograd's grad of conv3's output
+    }
+    // ---------------- conv3 backward: dW3[c] = sum_p du[p] * a_last[c,p];  da_last = r16(w3[c] * du[p]) ----------------
+    float acc16[CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) acc16[c] = 0.f;
+    for (int p = tid; p < s2; p += 256) {
+        const float du = u[p], xv = xs[p];
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+            const float al = THREE_X ? r16(((float)t2[c * s2 + p] - mean2) * rstd2 * (float)ln2w[c * s2 + p] + (float)ln2b[c * s2 + p])
+                                     : r16((r16(w1[c] * xv) - mean1) * rstd1 * (float)ln1w[c * s2 + p] + (float)ln1b[c * s2 + p]);
+            acc16[c] = fmaf(du, al, acc16[c]);
+        }
+    }
+    block_sum16(acc16, red16);
+    if (tid < CW) pw3[row * CW + tid] = acc16[tid];
+
+    if (THREE_X) {
+        // ------------ LN2 backward: da2 = r16(w3[c] du[p]); dt2 = rstd2 (gy - mean gy - xh mean(gy xh)) ------------
+        sa = sb = 0.f;
+        for (int p = tid; p < s2; p += 256) {
+            const float du = u[p];
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                const float da = r16(w3[c] * du);
+                const float xh = ((float)t2[c * s2 + p] - mean2) * rstd2, gy = da * (float)ln2w[c * s2 + p];
+                sa += gy;
+                sb += gy * xh;
+                pg2[row * n1 + c * s2 + p] = da * xh;
+                pb2[row * n1 + c * s2 + p] = da;
+            }
+        }
+        const float A2 = block_sum(sa, red) / (float)n1, B2 = block_sum(sb, red) / (float)n1;
+        for (int p = tid; p < s2; p += 256) {
+            const float du = u[p];
+            const int py = p / s, px = p - py * s;
+            const int hpos = (py + 1) * sp + px + 1;
+#pragma unroll
+            for (int cp = 0; cp < 8; ++cp) {
+                float d[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c = 2 * cp + j;
+                    const float da = r16(w3[c] * du);
+                    const float xh = ((float)t2[c * s2 + p] - mean2) * rstd2, gy = da * (float)ln2w[c * s2 + p];
+                    d[j] = rstd2 * (gy - A2 - xh * B2);
+                }
+                d2p[cp * hp + hpos] = half2_t{(half_t)d[0], (half_t)d[1]};
+            }
+        }
+        __syncthreads();
+        // ------------ conv2 weight gradient: dW2[co,ci,tap] = sum_p dt2[co,p] * a1[ci, p + tap] ------------
+        for (int o = tid; o < CW * CW * 9; o += 256) {
+            const int tap = o % 9, ci = (o / 9) % CW, co = o / (9 * CW);
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const half_t* dsrc = reinterpret_cast<const half_t*>(d2p + (co >> 1) * hp) + (co & 1);
+            const half_t* asrc = reinterpret_cast<const half_t*>(a1p + (ci >> 1) * hp) + (ci & 1);
+            float acc = 0.f;
+            for (int py = 0; py < s; ++py)
+                for (int px = 0; px < s; ++px)
+                    acc = fmaf((float)dsrc[2 * ((py + 1) * sp + px + 1)], (float)asrc[2 * ((py + dy) * sp + px + dx)], acc);
+            pw2[row * (CW * CW * 9) + o] = acc;
+        }
+        // ------------ conv2 input gradient (transposed conv): da1[ci,p] = r16(sum_co,tap dt2[co, p - tap + 1] w2[co,ci,tap]) ----
+        __syncthreads();                                            // t2 is overwritten with da1 below: all readers are done
+        for (int p = tid; p < s2; p += 256) {
+            const int py = p / s, px = p - py * s;
+            float acc[CW];
+#pragma unroll
+            for (int c = 0; c < CW; ++c) acc[c] = 0.f;
+#pragma unroll 1
+            for (int cp = 0; cp < 8; ++cp) {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int dy = tap / 3, dx = tap - dy * 3;
+                    const half2_t dv = d2p[cp * hp + (py + 2 - dy) * sp + px + 2 - dx];
+                    const half2_t* wv = w2t + (cp * 9 + tap) * CW;
+#pragma unroll
+                    for (int ci = 0; ci < CW; ++ci) acc[ci] = __builtin_amdgcn_fdot2(dv, wv[ci], acc[ci], false);
+                }
+            }
+#pragma unroll
+            for (int ci = 0; ci < CW; ++ci) t2[ci * s2 + p] = (half_t)acc[ci];
+        }
+        __syncthreads();
+    }
+    // ---------------- LN1 backward + conv1 weight gradient ----------------
+    sa = sb = 0.f;
+    for (int p = tid; p < s2; p += 256) {
+        const float du = u[p], xv = xs[p];
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+            const float da = THREE_X ? (float)t2[c * s2 + p] : r16(w3[c] * du);
+            const float xh = (r16(w1[c] * xv) - mean1) * rstd1, gy = da * (float)ln1w[c * s2 + p];
+            sa += gy;
+            sb += gy * xh;
+            pg1[row * n1 + c * s2 + p] = da * xh;
+            pb1[row * n1 + c * s2 + p] = da;
+        }
+    }
+    const float A1 = block_sum(sa, red) / (float)n1, B1 = block_sum(sb, red) / (float)n1;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) acc16[c] = 0.f;
+    for (int p = tid; p < s2; p += 256) {
+        const float du = u[p], xv = xs[p];
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+            const float da = THREE_X ? (float)t2[c * s2 + p] : r16(w3[c] * du);
+            const float xh = (r16(w1[c] * xv) - mean1) * rstd1, gy = da * (float)ln1w[c * s2 + p];
+            const float dt1 = r16(rstd1 * (gy - A1 - xh * B1));
+            acc16[c] = fmaf(dt1, xv, acc16[c]);
+        }
+    }
+    block_sum16(acc16, red16);
+    if (tid < CW) pw1[row * CW + tid] = acc16[tid];
+}
+
+}  // namespace
+
+extern "C" int pclip_adapter_conv_backward_f16(const void* x, const void* g, int B, int D, int three_x, const void* conv1,
+                                               const void* ln1w, const void* ln1b, const void* conv2, const void* ln2w,
+                                               const void* ln2b, const void* conv3, const void* ln3w, float* pw1, float* pw2,
+                                               float* pw3, float* pg1, float* pb1, float* pg2, float* pb2, float* pg3, float* pb3,
+                                               pclip_stream_t stream) {
+    PCLIP_REQUIRE(x && g && conv1 && ln1w && ln1b && conv3 && ln3w && pw1 && pw3 && pg1 && pb1 && pg3 && pb3,
+                  "pclip_adapter_conv_backward_f16: null pointer");
+    PCLIP_REQUIRE(!three_x || (conv2 && ln2w && ln2b && pw2 && pg2 && pb2), "pclip_adapter_conv_backward_f16: conv-3x needs conv2 / bn2 and their outputs");
+    PCLIP_REQUIRE(B >= 0 && D > 0 && D <= 1024, "pclip_adapter_conv_backward_f16: D=%d must be in [1, 1024]", D);
+    if (B == 0) return PCLIP_OK;
+    int s = 1;
+    while (s * s < D) ++s;
+    const int s2 = s * s, hp = (s + 2) * (s + 2);
+    const size_t lds = (size_t)(1024 + 1024 + 4 + 64) * 4 + (three_x ? (size_t)2 * 8 * hp * 4 + (size_t)CW * s2 * 2 + (size_t)2 * 8 * 9 * CW * 4 : 0);
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr[2] = {false, false};
+    if (three_x) {
+        if (!attr[1]) {
+            if (hipFuncSetAttribute((const void*)adapter_conv_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                pclip_set_error("pclip_adapter_conv_backward_f16: cannot raise the dynamic LDS limit");
+                return PCLIP_E_LAUNCH;
+            }
+            attr[1] = true;
+        }
+        adapter_conv_backward_kernel<true><<<B, 256, lds, st>>>((const half_t*)x, (const half_t*)g, D, s, (const half_t*)conv1, (const half_t*)ln1w,
+            (const half_t*)ln1b, (const half_t*)conv2, (const half_t*)ln2w, (const half_t*)ln2b, (const half_t*)conv3, (const half_t*)ln3w,
+            pw1, pw2, pw3, pg1, pb1, pg2, pb2, pg3, pb3);
+    } else {
+        adapter_conv_backward_kernel<false><<<B, 256, lds, st>>>((const half_t*)x, (const half_t*)g, D, s, (const half_t*)conv1, (const half_t*)ln1w,
+            (const half_t*)ln1b, nullptr, nullptr, nullptr, (const half_t*)conv3, (const half_t*)ln3w, pw1, nullptr, pw3, pg1, pb1, nullptr, nullptr, pg3, pb3);
+    }
+    return pclip_check_launch("adapter_conv_backward");
+}
+
+namespace {
 }  // namespace
 
 extern "C" int pclip_adapter_fc_f16(const void* x, int B, int D, int H, const void* w1, const void* g1, const void* b1,

@@ -91,9 +91,43 @@ def make_adapter(cfg, ndim):
     raise ValueError(f"unknown adapter {cfg['adapter']!r}")
 
 
+def train_proto_clip(cfg, visual_memory_keys, textual_memory_bank, adapter, val_features, val_labels, alpha, beta):
+    """The training loop of reference main.py:216-381: episodes of proto_clip_amd.train, per-epoch validation with the
+    inference kernels, best-on-validation checkpoints under the reference's file names."""
+    from .train import ProtoClipTrainer
+    K = cfg["shots"]
+    trainer = ProtoClipTrainer(cfg, visual_memory_keys, textual_memory_bank, adapter, alpha, beta)
+    N = trainer.N
+    model_dir = f"{get_model_dir_root(cfg)}/alpha-beta/{alpha}-{beta}"
+    model_prefix = f"best_lr_{cfg['lr']}_aug_{cfg['augment_epoch']}_epochs_{cfg['train_epoch']}"
+    os.makedirs(model_dir, exist_ok=True)
+    pv, pt, pa = (os.path.join(model_dir, f"{model_prefix}_{s}.pt") for s in ("v", "t", "a"))
+    best_acc, best_epoch, history = 0.0, 0, []
+    for epoch in range(cfg["train_epoch"]):
+        print("Train Epoch: {:} / {:}".format(epoch, cfg["train_epoch"]))
+        train_acc, train_loss, lr = trainer.train_epoch()                                    # main.py:228-312
+        print("LR: {:.6f}, Acc: {:.4f}%, Loss: {:.4f}".format(lr, train_acc * 100, train_loss))
+        with torch.no_grad():                                                                # main.py:318-345
+            z_img_proto = ops.proto_build(trainer.visual, N, K, per_shot_norm=True)
+            z_text_proto = ops.l2norm_rows(trainer.textual)
+            val_f = adapter(val_features, l2norm_out=True)
+            _, am, tp, _ = ops.classify(val_f, z_img_proto, z_text_proto, alpha, beta, want_p=False, want_argmax=True, topk=1)
+            val_acc = float(accuracy_from_counts((am.long() == val_labels.to(am.device)).sum().item(), val_f.shape[0]))
+            val_loss = float(-torch.log(tp[:, 0]).mean().item())
+        print("**** Proto-CLIP's val accuracy: {:.2f}% | loss: {:.2f}***\n".format(val_acc * 100, val_loss))
+        if val_acc >= best_acc:                                                              # main.py:359-364
+            best_acc, best_epoch = val_acc, epoch
+            torch.save(torch.nn.Parameter(trainer.visual.clone()), pv)
+            torch.save(torch.nn.Parameter(trainer.textual.clone()), pt)
+            torch.save(adapter.state_dict(), pa)
+        history.append(dict(epoch=epoch, lr=lr, train_acc=train_acc, train_loss=train_loss, val_acc=val_acc, val_loss=val_loss))
+    print(f"Best model: best_val_acc = {best_acc * 100: .2f}, best_val_epoch = {best_epoch}")
+    return dict(history=history, best_acc=best_acc, best_epoch=best_epoch, trainer=trainer)
+
+
 def run_proto_clip(cfg, visual_memory_keys, visual_memory_values, val_features, val_labels, test_features,
                    test_labels, textual_memory_bank, clip_model, text_prompts):
-    """Reference main.py:105-465 minus the training loop.  Returns a dict of everything it computed."""
+    """Reference main.py:105-465.  Returns a dict of everything it computed."""
     ndim, NxK = visual_memory_keys.shape
     K = cfg["shots"]
     N = NxK // K
@@ -128,12 +162,14 @@ def run_proto_clip(cfg, visual_memory_keys, visual_memory_values, val_features, 
         out["zero_shot"] = dict(val=val_acc_list, test=test_acc_list, train=train_acc_list, best_alpha=a, best_beta=b)
 
     best_alpha, best_beta = cfg["alpha"], cfg["beta"]                  # main.py:213-214
-    if not cfg.get("only_test", False):
-        raise NotImplementedError(
-            "the episodic training loop (reference main.py:216-381) is not part of this build (SURVEY §8f #3); "
-            "run with only_test: True against saved banks/adapter")
-
+    # the reference constructs nn.Embedding(NxK, ndim) (whose default init draws NxK*ndim normals) BEFORE the adapter
+    # (main.py:110-117): draw them too, so that the adapter initialises identically under the same torch seed
+    torch.nn.Embedding(num_embeddings=NxK, embedding_dim=ndim)
     adapter = make_adapter(cfg, ndim)
+    if not cfg.get("only_test", False):
+        out["train"] = train_proto_clip(cfg, visual_memory_keys, textual_memory_bank, adapter, val_features, val_labels,
+                                        best_alpha, best_beta)
+
     with torch.no_grad():
         print("Testing...")
         model_dir = f"{model_dir_root}/alpha-beta/{best_alpha}-{best_beta}"

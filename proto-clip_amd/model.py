@@ -17,8 +17,8 @@ from ._lib import PclipError
 def _check_inference(x, module):
     if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters())):
         raise NotImplementedError(
-            "proto_clip_amd adapters implement the forward (inference) path only; call under torch.no_grad(). "
-            "The training step (backward of P / adapters) is SURVEY §8(f) item 3 and is not built yet.")
+            "proto_clip_amd adapter modules run the inference kernels and keep no autograd tape; call them under "
+            "torch.no_grad().  Training goes through proto_clip_amd.train.ProtoClipTrainer (explicit backward kernels).")
 
 
 class Adapter(nn.Module):

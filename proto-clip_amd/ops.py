@@ -371,3 +371,173 @@ def attnpool_tokens(x, pos16, B: int, HW: int, C: int) -> torch.Tensor:
     t = torch.empty(B * (HW + 1), C, dtype=torch.float16, device=x.device)
     check(_lib.load().pclip_attnpool_tokens_f16(ptr(x), ptr(pos16), B, HW, C, ptr(t), stream()), "pclip_attnpool_tokens_f16")
     return t
+
+
+# ---------------------------------------------------------------- training step (csrc/pclip_train.hip) ----------
+def cast_f32(x: torch.Tensor) -> torch.Tensor:
+    """fp16 -> fp32 copy (`.float()`)."""
+    require_cuda(x)
+    x = _f16c(x)
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(_lib.load().pclip_cast_f16_f32(ptr(x), ptr(y), x.numel(), stream()), "pclip_cast_f16_f32")
+    return y
+
+
+def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False, alpha: float = 1.0,
+             out: torch.Tensor = None, beta: float = 0.0) -> torch.Tensor:
+    """out = alpha * op(a) @ op(b) + beta * out in fp32 on the fp32 MFMA; a, b are 2-D row-major (unit column stride, any
+    row stride) fp16 or fp32."""
+    require_cuda(a, b)
+    for t in (a, b):
+        if t.dtype not in (torch.float16, torch.float32) or t.dim() != 2 or t.stride(1) != 1:
+            raise _lib.PclipError("gemm_f32 takes row-major 2-D fp16/fp32 tensors")
+    M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    Kb, N = (b.shape[1], b.shape[0]) if trans_b else b.shape
+    if K != Kb:
+        raise _lib.PclipError(f"gemm_f32: inner dimensions differ ({K} vs {Kb})")
+    rsa, csa = (1, a.stride(0)) if trans_a else (a.stride(0), 1)
+    rsb, csb = (1, b.stride(0)) if trans_b else (b.stride(0), 1)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+        beta = 0.0
+    check(_lib.load().pclip_gemm_f32(ptr(a), int(a.dtype == torch.float16), rsa, csa, ptr(b), int(b.dtype == torch.float16),
+                                     rsb, csb, ptr(out), out.stride(0), M, N, K, alpha, beta, stream()), "pclip_gemm_f32")
+    return out
+
+
+def colsum_f32(x: torch.Tensor, rows: int = None, cols: int = None, scale: float = 1.0, out: torch.Tensor = None) -> torch.Tensor:
+    """scale * x.sum(0) for a 2-D fp32 tensor (leading dimension = x.stride(0)); deterministic.  With `out` the sum is
+    ADDED to it."""
+    require_cuda(x)
+    R = x.shape[0] if rows is None else rows
+    C = x.shape[1] if cols is None else cols
+    acc = out is not None
+    if out is None:
+        out = torch.empty(C, dtype=torch.float32, device=x.device)
+    check(_lib.load().pclip_colsum_f32(ptr(x), x.stride(0), R, C, scale, ptr(out), int(acc), stream()), "pclip_colsum_f32")
+    return out
+
+
+def addscaled_rows_(c: torch.Tensor, x: torch.Tensor, rowscale: torch.Tensor, s: float) -> torch.Tensor:
+    """c[r, :] += s * rowscale[r] * x[r, :] in place (fp32)."""
+    require_cuda(c, x, rowscale)
+    R, D = c.shape
+    check(_lib.load().pclip_addscaled_rows_f32(ptr(c), c.stride(0), ptr(x), x.stride(0), ptr(rowscale), s, R, D, stream()),
+          "pclip_addscaled_rows_f32")
+    return c
+
+
+def nll_grad(d2i, d2t, labels, N: int, alpha: float, beta: float):
+    """From the distance rows of sqdist_f32: gradients (gi, gt) of mean NLL(log P) wrt them, rowsum(gi + gt), the per-query
+    -log p[y], max probability and argmax (utils.py:84-93)."""
+    require_cuda(d2i, d2t, labels)
+    Q, ldd = d2i.shape
+    gi, gt = torch.empty_like(d2i), torch.empty_like(d2t)
+    rs, nll, pmax = (torch.empty(Q, dtype=torch.float32, device=d2i.device) for _ in range(3))
+    am = torch.empty(Q, dtype=torch.int32, device=d2i.device)
+    lab = labels.to(torch.int32)
+    check(_lib.load().pclip_nll_grad(ptr(d2i), ptr(d2t), ptr(lab), Q, N, ldd, alpha, 1.0 - alpha, beta, ptr(gi), ptr(gt),
+                                     ptr(rs), ptr(nll), ptr(pmax), ptr(am), stream()), "pclip_nll_grad")
+    return gi, gt, rs, nll, pmax, am
+
+
+def softmax_ce_rows(S: torch.Tensor, scale: float):
+    """Rows of S as logits against the diagonal: (per-row loss, scale * (softmax - I))."""
+    require_cuda(S)
+    R, C = S.shape
+    dS = torch.empty_like(S)
+    loss = torch.empty(R, dtype=torch.float32, device=S.device)
+    check(_lib.load().pclip_softmax_ce_rows(ptr(S), S.stride(0), R, C, scale, ptr(dS), dS.stride(0), ptr(loss), stream()),
+          "pclip_softmax_ce_rows")
+    return loss, dS
+
+
+def proto_backward(mem: torch.Tensor, g: torch.Tensor, N: int, K: int, per_shot_norm: bool, final_norm: bool) -> torch.Tensor:
+    """Gradient wrt the fp16 rows `mem` [N*K, D] of the prototype chain given g [N, D] fp32 wrt its fp32 output."""
+    require_cuda(mem, g)
+    mem = _f16c(mem)
+    D = mem.shape[1]
+    if g.dtype != torch.float32 or g.shape != (N, D) or not g.is_contiguous():
+        raise _lib.PclipError("proto_backward: g must be a contiguous fp32 [N, D] tensor")
+    dmem = torch.empty_like(mem)
+    check(_lib.load().pclip_proto_backward_f16(ptr(mem), ptr(g), N, K, D, int(per_shot_norm), int(final_norm), ptr(dmem),
+                                               stream()), "pclip_proto_backward_f16")
+    return dmem
+
+
+def layernorm_backward(x, gamma, dy, eps: float = 1e-5, dy_scale: float = 1.0):
+    """fp16 LayerNorm backward over the last dimension: (dx fp16, dgamma fp32 [D], dbeta fp32 [D])."""
+    require_cuda(x, gamma, dy)
+    x, gamma, dy = _f16c(x), _f16c(gamma), _f16c(dy)
+    R, D = x.shape
+    nblk = max(1, min(256, (R + 3) // 4))
+    dx = torch.empty_like(x)
+    part = torch.empty(nblk, 2, D, dtype=torch.float32, device=x.device)
+    check(_lib.load().pclip_layernorm_backward_f16(ptr(x), D, ptr(gamma), ptr(dy), D, R, D, eps, dy_scale, ptr(dx), D, ptr(part),
+                                                   nblk, stream()), "pclip_layernorm_backward_f16")
+    sums = colsum_f32(part.view(nblk, 2 * D))
+    return dx, sums[:D], sums[D:]
+
+
+def adamw_(p, g, m, v, lr: float, step: int, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-4,
+           weight_decay: float = 0.05):
+    """In-place torch.optim.AdamW step on an fp16 parameter with fp16 moments (main.py:134-135)."""
+    require_cuda(p, g, m, v)
+    for t in (p, g, m, v):
+        if t.dtype != torch.float16 or not t.is_contiguous():
+            raise _lib.PclipError("adamw_: fp16 contiguous tensors expected")
+    check(_lib.load().pclip_adamw_f16(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                                      stream()), "pclip_adamw_f16")
+    return p
+
+
+def l2norm_rows_f32(x: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    """F.normalize(x, dim=-1) on fp32 rows."""
+    require_cuda(x)
+    R, D = x.shape
+    y = torch.empty_like(x)
+    check(_lib.load().pclip_l2norm_rows_f32(ptr(x), ptr(y), R, D, eps, stream()), "pclip_l2norm_rows_f32")
+    return y
+
+
+def l2norm_rows_backward_f32_(gx: torch.Tensor, x: torch.Tensor, gy: torch.Tensor, eps: float = 1e-12, accumulate: bool = True):
+    """gx (+)= backward of F.normalize(x) for upstream gy (all fp32 [R, D])."""
+    require_cuda(gx, x, gy)
+    R, D = x.shape
+    check(_lib.load().pclip_l2norm_rows_backward_f32(ptr(x), ptr(gy), ptr(gx), R, D, eps, int(accumulate), stream()),
+          "pclip_l2norm_rows_backward_f32")
+    return gx
+
+
+def adapter_conv_backward(x, g, three_x: bool, conv1, ln1w, ln1b, conv2, ln2w, ln2b, conv3, ln3w, ln3b, chunk: int = 512):
+    """Parameter gradients (fp32, shaped like the parameters) of the conv adapter for upstream g = dL/d(output); rows are
+    processed `chunk` at a time (per-row contributions live in scratch, then a deterministic column sum)."""
+    require_cuda(x, g)
+    x, g = _f16c(x), _f16c(g)
+    B, D = x.shape
+    s = int(math.ceil(math.sqrt(D)))
+    s2, n1 = s * s, 16 * s * s
+    dev = x.device
+    f32 = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+    out = {"conv1.weight": f32(16), "conv3.weight": f32(16), "bn1.weight": f32(n1), "bn1.bias": f32(n1), "bn3.weight": f32(s2),
+           "bn3.bias": f32(s2)}
+    if three_x:
+        out.update({"conv2.weight": f32(2304), "bn2.weight": f32(n1), "bn2.bias": f32(n1)})
+    c = min(chunk, max(B, 1))
+    sc = lambda n: torch.empty(c, n, dtype=torch.float32, device=dev)
+    pw1, pw3, pg1, pb1, pg3, pb3 = sc(16), sc(16), sc(n1), sc(n1), sc(s2), sc(s2)
+    pw2, pg2, pb2 = (sc(2304), sc(n1), sc(n1)) if three_x else (None, None, None)
+    for lo in range(0, B, c):
+        nb = min(c, B - lo)
+        check(_lib.load().pclip_adapter_conv_backward_f16(
+            ptr(x[lo:lo + nb]), ptr(g[lo:lo + nb]), nb, D, int(three_x), ptr(conv1), ptr(ln1w), ptr(ln1b),
+            ptr(conv2) if three_x else None, ptr(ln2w) if three_x else None, ptr(ln2b) if three_x else None, ptr(conv3), ptr(ln3w),
+            ptr(pw1), ptr(pw2), ptr(pw3), ptr(pg1), ptr(pb1), ptr(pg2), ptr(pb2), ptr(pg3), ptr(pb3), stream()),
+            "pclip_adapter_conv_backward_f16")
+        for name, part in (("conv1.weight", pw1), ("conv3.weight", pw3), ("bn1.weight", pg1), ("bn1.bias", pb1), ("bn3.weight", pg3),
+                           ("bn3.bias", pb3), ("conv2.weight", pw2), ("bn2.weight", pg2), ("bn2.bias", pb2)):
+            if part is not None:
+                colsum_f32(part, rows=nb, out=out[name])
+    shapes = {"conv1.weight": (16, 1, 1, 1), "conv3.weight": (1, 16, 1, 1), "conv2.weight": (16, 16, 3, 3), "bn1.weight": (16, s, s),
+              "bn1.bias": (16, s, s), "bn2.weight": (16, s, s), "bn2.bias": (16, s, s), "bn3.weight": (1, s, s), "bn3.bias": (1, s, s)}
+    return {k: v.view(shapes[k]) for k, v in out.items()}

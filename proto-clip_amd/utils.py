@@ -181,3 +181,40 @@ def accuracy_from_counts(correct, Q: int) -> np.ndarray:
     mean is an fp32 sum of 0/1 divided by Q in fp32 (main.py:190-191)."""
     c = np.asarray(correct, dtype=np.float32)
     return (c / np.float32(Q)).astype(np.float64)
+
+
+def InfoNCELoss(A, B):
+    """InfoNCE()(A, B) of utils.py:72-77 with the info-nce-pytorch defaults (temperature 0.1, mean reduction, both sides
+    L2-normalised, cross entropy against the diagonal); A, B fp32 [n, D].  Forward value only (device scalar)."""
+    an, bn = ops.l2norm_rows_f32(A.float().contiguous()), ops.l2norm_rows_f32(B.float().contiguous())
+    S = ops.gemm_f32(an, bn, trans_b=True, alpha=10.0)
+    rows, _ = ops.softmax_ce_rows(S, 1.0 / A.shape[0])
+    return ops.colsum_f32(rows.view(-1, 1), scale=1.0 / A.shape[0])[0]
+
+
+def compute_loss_and_matches(p, target_inds, z_img_proto, z_text_proto, cfg):
+    """Loss and accuracy of one episode (reference utils.py:80-109): the same 7-tuple.  Forward values only — no autograd
+    graph hangs off them; gradients are produced by proto_clip_amd.train.ProtoClipTrainer.step, which fuses this loss with P
+    and never materialises p.  As in the reference, `neg_log_loss` (index 2) and the L4 entries are returned as None / as
+    computed there."""
+    require = p.dtype == torch.float32 and p.is_cuda
+    if not require:
+        raise PclipError("compute_loss_and_matches: p must be the fp32 CUDA tensor returned by P()")
+    pred_p, y_hat = p.max(dim=1)
+    matches = (y_hat == target_inds).float().sum()
+    loss = torch.zeros((), dtype=torch.float32, device=p.device)
+    img2txt = txt2img = img_inter = txt_inter = None
+    losses = cfg["losses"]
+    if len(losses) == 0 or "L1" in losses:
+        picked = p.gather(1, target_inds.view(-1, 1).long())
+        loss = loss + ops.colsum_f32((-torch.log(picked)).contiguous(), scale=1.0 / p.shape[0])[0]
+    if "L2" in losses:
+        img2txt = InfoNCELoss(z_img_proto, z_text_proto)
+        loss = loss + img2txt
+    if "L3" in losses:
+        txt2img = InfoNCELoss(z_text_proto, z_img_proto)
+        loss = loss + txt2img
+    if "L4" in losses:
+        img_inter, txt_inter = InfoNCELoss(z_img_proto, z_img_proto), InfoNCELoss(z_text_proto, z_text_proto)
+        loss = loss + img_inter + txt_inter
+    return matches, loss, None, img2txt, txt2img, img_inter, txt_inter

@@ -27,6 +27,25 @@ RESNET2 = dict(embed_dim=256, image_resolution=96, vision_layers=(2, 1, 2, 1), v
 RESNETS = {"rn_a": RESNET, "rn_b": RESNET2}
 
 
+# training runs of the reference (main.py:216-381): name -> (N, K, D, Q_val, Q_test, alpha, beta, adapter, sigma,
+# train_vis_mem_only, losses, epochs, lr)
+TRAIN = {
+    "T_fc": (12, 8, 256, 96, 96, 0.4, 6.0, "fc", 5.0, False, ["L1", "L2", "L3"], 2, 0.001),
+    "T_c3": (10, 6, 192, 80, 80, 0.6, 4.0, "conv-3x", 5.0, True, ["L1", "L2", "L3"], 2, 0.001),
+    "T_c2": (9, 4, 104, 64, 64, 0.5, 8.0, "conv-2x", 4.5, False, ["L1"], 2, 0.002),
+}
+
+
+def train_inputs(name):
+    """Seeded inputs of training case `name` and the cfg run_proto_clip receives (only_test False)."""
+    from proto_clip_amd import synth
+    N, K, D, Qv, Qt, alpha, beta, kind, sigma, vis_only, losses, epochs, lr = TRAIN[name]
+    split = synth.make_split(N, K, D, Qv, Qt, seed=2, sigma=sigma, sigma_text=0.6 * sigma)
+    cfg = dict(shots=K, backbone="ViT-B/16", dataset="synthetic_" + name, only_test=False, lr=lr, augment_epoch=10,
+               train_epoch=epochs, alpha=alpha, beta=beta, adapter=kind, train_vis_mem_only=vis_only, losses=list(losses))
+    return split, cfg
+
+
 def fewshot_inputs(name):
     """Seeded inputs of case `name`: synthetic split, 'learned' banks (perturbed, un-normalised rows in the
     [N*K, D] / [N, D] layout of main.py:367-368) and the cfg dict run_proto_clip receives."""

@@ -1,0 +1,400 @@
+"""Episodic training step on the GPU (csrc/pclip_train.hip, proto_clip_amd/train.py) against
+the training oracle (oracle/train_oracle.py — torch autograd on CPU, pinned bit-exactly to the reference's own training
+run by tests/test_train_oracle.py) and against the reference fixtures tests/golden/train_*.npz.
+
+Tolerances.  fp32 stages (P, NLL, InfoNCE, cdist backward): relative 1e-5 (summation order).  fp16 gradients: the
+reference's autograd rounds every intermediate to fp16; the kernels keep fp32 inside a stage and round where a tensor is
+materialised, so single-ulp differences are expected: relative L2 <= 2e-3 per tensor, no element off by more than 4 fp16
+ulps of the tensor's max.  AdamW: bit-exact against torch.optim.AdamW on CPU fp16 tensors."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden
+from golden.spec import TRAIN, train_inputs
+from oracle import train_oracle as to
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from proto_clip_amd import _lib, ops as _ops
+    _lib.load()
+    return _ops
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu().reshape(-1), b.float().cpu().reshape(-1)
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def assert_grad_close(got, ref, what, tol=2e-3, ulps=4):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape, what
+    assert rel_l2(got, ref) <= tol, (what, rel_l2(got, ref))
+    assert (got - ref).abs().max().item() <= ulps * 2.0 ** -10 * ref.abs().max().item() + 1e-7, what
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("half_a", [False, True])
+def test_gemm_f32(ops, ta, tb, half_a):
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 150, 97, 203
+    a = torch.randn((K, M) if ta else (M, K), generator=g)
+    b = torch.randn((N, K) if tb else (K, N), generator=g)
+    if half_a:
+        a = a.half()
+    ref = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
+    c0 = torch.randn(M, N, generator=g)
+    out = ops.gemm_f32(a.cuda(), b.cuda(), trans_a=ta, trans_b=tb, alpha=-2.0)
+    assert rel_l2(out, -2.0 * ref) < 1e-6
+    out2 = ops.gemm_f32(a.cuda(), b.cuda(), trans_a=ta, trans_b=tb, alpha=0.5, out=c0.cuda(), beta=1.0)
+    assert rel_l2(out2, 0.5 * ref + c0.double()) < 1e-6
+    # strided rows (views of padded buffers)
+    pad = torch.zeros(a.shape[0], a.shape[1] + 5, dtype=a.dtype)
+    pad[:, :a.shape[1]] = a
+    out3 = ops.gemm_f32(pad.cuda()[:, :a.shape[1]], b.cuda(), trans_a=ta, trans_b=tb)
+    assert rel_l2(out3, ref) < 1e-6
+
+
+def test_colsum_and_addscaled(ops):
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(301, 130, generator=g)
+    assert rel_l2(ops.colsum_f32(x.cuda(), scale=0.5), 0.5 * x.double().sum(0)) < 1e-6
+    assert rel_l2(ops.colsum_f32(x.cuda(), cols=100), x[:, :100].double().sum(0)) < 1e-6
+    c, rs = torch.randn(301, 130, generator=g), torch.randn(301, generator=g)
+    got = ops.addscaled_rows_(c.clone().cuda(), x.cuda(), rs.cuda(), 2.0)
+    assert rel_l2(got, c + 2.0 * rs[:, None] * x) < 1e-6
+
+
+@pytest.mark.parametrize("Q,N,D,alpha,beta", [(50, 12, 64, 0.4, 6.0), (333, 198, 96, 0.2, 12.0), (64, 1000, 32, 1.0, 0.7), (40, 70, 48, 0.0, 3.0)])
+def test_nll_grad_and_cdist_backward(ops, Q, N, D, alpha, beta):
+    g = torch.Generator().manual_seed(Q + N)
+    zq = F.normalize(torch.randn(Q, D, generator=g), dim=-1).requires_grad_()
+    zi = F.normalize(torch.randn(N, D, generator=g), dim=-1).requires_grad_()
+    zt = F.normalize(torch.randn(N, D, generator=g), dim=-1).requires_grad_()
+    lab = torch.randint(0, N, (Q,), generator=g)
+    p = to.P(zq, zi, zt, alpha, beta)
+    loss = F.nll_loss(torch.log(p), lab)
+    loss.backward()
+    d2i, d2t, _ = ops.sqdist_f32(zq.detach().cuda(), zi.detach().cuda(), zt.detach().cuda())
+    gi, gt, rs, nll, pmax, am = ops.nll_grad(d2i, d2t, lab.cuda(), N, alpha, beta)
+    assert abs(nll.mean().item() - loss.item()) <= 1e-5 * max(1.0, abs(loss.item()))
+    assert torch.equal(am.cpu().long(), p.max(1)[1]) or (am.cpu().long() != p.max(1)[1]).sum() <= 1
+    assert torch.allclose(pmax.cpu(), p.max(1)[0].detach(), rtol=1e-5, atol=1e-7)
+    zqc, zic, ztc = zq.detach().cuda(), zi.detach().cuda(), zt.detach().cuda()
+    gq = ops.gemm_f32(gi[:, :N], zic, alpha=-2.0)
+    ops.gemm_f32(gt[:, :N], ztc, alpha=-2.0, out=gq, beta=1.0)
+    ops.addscaled_rows_(gq, zqc, rs, 2.0)
+    gzi = ops.gemm_f32(gi[:, :N], zqc, trans_a=True, alpha=-2.0)
+    ops.addscaled_rows_(gzi, zic, ops.colsum_f32(gi, cols=N), 2.0)
+    gzt = ops.gemm_f32(gt[:, :N], zqc, trans_a=True, alpha=-2.0)
+    ops.addscaled_rows_(gzt, ztc, ops.colsum_f32(gt, cols=N), 2.0)
+    assert rel_l2(gq, zq.grad) < 2e-5
+    assert rel_l2(gzi, zi.grad) < 2e-5 or alpha == 0.0
+    assert rel_l2(gzt, zt.grad) < 2e-5 or alpha == 1.0
+    if alpha == 0.0:
+        assert gzi.abs().max().item() == 0.0
+    if alpha == 1.0:
+        assert gzt.abs().max().item() == 0.0
+
+
+def test_info_nce_pieces(ops):
+    g = torch.Generator().manual_seed(9)
+    n, D = 57, 40
+    a = (F.normalize(torch.randn(n, D, generator=g), dim=-1) * 1.001).requires_grad_()
+    b = (F.normalize(torch.randn(n, D, generator=g), dim=-1) * 0.999).requires_grad_()
+    loss = to.info_nce(a, b)
+    loss.backward()
+    an, bn = ops.l2norm_rows_f32(a.detach().cuda()), ops.l2norm_rows_f32(b.detach().cuda())
+    assert rel_l2(an, F.normalize(a.detach(), dim=-1)) < 1e-6
+    S = ops.gemm_f32(an, bn, trans_b=True, alpha=10.0)
+    rows, dS = ops.softmax_ce_rows(S, 1.0 / n)
+    assert abs(rows.mean().item() - loss.item()) < 1e-5
+    ga = torch.zeros(n, D, device="cuda")
+    gb = torch.zeros(n, D, device="cuda")
+    ops.l2norm_rows_backward_f32_(ga, a.detach().cuda(), ops.gemm_f32(dS, bn, alpha=10.0))
+    ops.l2norm_rows_backward_f32_(gb, b.detach().cuda(), ops.gemm_f32(dS, an, trans_a=True, alpha=10.0))
+    assert rel_l2(ga, a.grad) < 2e-5 and rel_l2(gb, b.grad) < 2e-5
+
+
+@pytest.mark.parametrize("N,K,D,per_shot,final", [(12, 8, 256, True, True), (37, 1, 100, False, True), (20, 1, 144, True, False),
+                                                   (5, 16, 512, True, True), (9, 4, 70, True, True)])
+def test_proto_backward(ops, N, K, D, per_shot, final):
+    g = torch.Generator().manual_seed(N * K + D)
+    mem = (torch.randn(N * K, D, generator=g) * 0.7).half().requires_grad_()
+    up = torch.randn(N, D, generator=g) * 0.05
+    zs = mem.view(N, K, D)
+    if per_shot:
+        zs = zs / zs.norm(dim=-1, keepdim=True)
+    z = zs.mean(dim=1).float()
+    if final:
+        z = z / z.norm(dim=-1, keepdim=True)
+    (z * up).sum().backward()
+    got = ops.proto_backward(mem.detach().cuda(), up.cuda(), N, K, per_shot, final)
+    assert_grad_close(got, mem.grad, "proto_backward")
+
+
+@pytest.mark.parametrize("R,D,scale", [(100, 64, 1.0), (333, 256, 0.2), (17, 192, 1.0), (1000, 768, 0.2), (5, 1024, 1.0)])
+def test_layernorm_backward(ops, R, D, scale):
+    g = torch.Generator().manual_seed(R + D)
+    x = (torch.randn(R, D, generator=g) * 1.5 + 0.2).half().requires_grad_()
+    gamma = (1 + 0.2 * torch.randn(D, generator=g)).half().requires_grad_()
+    beta = (0.1 * torch.randn(D, generator=g)).half().requires_grad_()
+    dy = (torch.randn(R, D, generator=g) * 0.01).half()
+    y = F.layer_norm(x, [D], gamma, beta)
+    ((scale * y) * dy).sum().backward() if scale != 1.0 else (y * dy).sum().backward()
+    dx, dg, db = ops.layernorm_backward(x.detach().cuda(), gamma.detach().cuda(), dy.cuda(), dy_scale=scale)
+    assert_grad_close(dx, x.grad, "ln dx")
+    assert_grad_close(dg.half(), gamma.grad, "ln dgamma")
+    assert_grad_close(db.half(), beta.grad, "ln dbeta")
+
+
+@pytest.mark.parametrize("B,D,kind", [(40, 144, "conv-3x"), (33, 100, "conv-2x"), (700, 512, "conv-3x"), (20, 1024, "conv-3x"), (50, 768, "conv-2x")])
+def test_adapter_conv_backward(ops, B, D, kind):
+    import math
+    from conftest import randomize_adapter_
+    from proto_clip_amd.model import Adapter
+    torch.manual_seed(B + D)
+    ad = randomize_adapter_(Adapter(D, c_type=kind, dtype=torch.half), seed=B)
+    params = {k: v.detach().clone().requires_grad_() for k, v in ad.state_dict().items()}
+    g = torch.Generator().manual_seed(D)
+    x = F.normalize(torch.randn(B, D, generator=g), dim=-1).half()
+    up = (torch.randn(B, D, generator=g) * 1e-2).half()
+    y = to.adapter_conv(x, params, kind)
+    (y.float() * up.float()).sum().backward()
+    c = {k: v.detach().cuda() for k, v in params.items()}
+    got = ops.adapter_conv_backward(x.cuda(), up.cuda(), kind == "conv-3x", c["conv1.weight"], c["bn1.weight"], c["bn1.bias"],
+                                    c["conv2.weight"], c["bn2.weight"], c["bn2.bias"], c["conv3.weight"], c["bn3.weight"], c["bn3.bias"],
+                                    chunk=256)
+    for k, ref in params.items():
+        if ref.grad is None:
+            assert k not in got, k
+            continue
+        # three whole-tensor fp16 LayerNorm backwards amplify 1-ulp differences (cf. assert_adapter_close for the forward)
+        assert rel_l2(got[k], ref.grad) <= 2e-2, (k, rel_l2(got[k], ref.grad))
+
+
+@pytest.mark.parametrize("lr,scale", [(1e-3, 1e-2), (2e-3, 1e-4), (1e-4, 1.0)])
+def test_adamw_matches_torch(ops, lr, scale):
+    g = torch.Generator().manual_seed(3)
+    n = 5000
+    p = torch.nn.Parameter((torch.randn(n, generator=g) * 0.5).half())
+    opt = torch.optim.AdamW([p], lr=lr, eps=1e-4, weight_decay=0.05)
+    pg = p.data.clone().cuda()
+    m, v = torch.zeros_like(pg), torch.zeros_like(pg)
+    bad = 0
+    for step in range(1, 8):
+        grad = (torch.randn(n, generator=g) * scale).half()
+        p.grad = grad.clone()
+        opt.step()
+        ops.adamw_(pg, grad.cuda(), m, v, lr, step)
+        st = opt.state[p]
+        assert torch.equal(m.cpu(), st["exp_avg"]), step
+        assert torch.equal(v.cpu(), st["exp_avg_sq"]), step
+        bad += (pg.cpu() != p.data).sum().item()
+        pg.copy_(p.data)                                    # continue from the reference value: isolates each step
+    assert bad <= 2                                         # division rounding of the CPU vector path, if any
+
+
+def _trainers(name):
+    from proto_clip_amd.main import make_adapter
+    from proto_clip_amd.train import ProtoClipTrainer
+    g = golden("train_" + name)
+    names = [str(n) for n in g["names"]]
+    init = {n: torch.from_numpy(g["init__" + n]) for n in names}
+    split, cfg = train_inputs(name)
+    sd = {k: v for k, v in init.items() if k not in ("visual", "textual")}
+    ref = to.Trainer(cfg, split.visual_memory_keys, split.textual_memory_bank, sd, cfg["alpha"], cfg["beta"])
+    ad = make_adapter(cfg, split.visual_memory_keys.shape[0])
+    ad.load_state_dict(sd)
+    gpu = ProtoClipTrainer(cfg, split.visual_memory_keys.cuda(), split.textual_memory_bank.cuda(), ad, cfg["alpha"], cfg["beta"])
+    return g, names, cfg, ref, gpu
+
+
+def _oracle_noise(name, g, names, ep, qi, ql):
+    """How far the reference's gradients of step `ep` move when 2 % of the (constant) key rows move by one fp16 ulp.  Some
+    gradients ARE rounding noise — e.g. conv1 / conv3 of a freshly initialised conv-2x adapter: LN3(conv3(LN1(conv1 x))) does
+    not depend on the conv weights there, their exact gradient is 0 and the reference's 1e-5 values are fp16 rounding
+    residue.  A gradient is judged against  5e-3 |ref| + 3 x this noise.  Returns {param name: |grad_perturbed - grad|}."""
+    split, cfg = train_inputs(name)
+    before = {n: torch.from_numpy(g[f"init__{n}"] if ep == 0 else g[f"after{ep - 1}__{n}"]) for n in names}
+    sd = {k: v for k, v in before.items() if k not in ("visual", "textual")}
+    out = []
+    for perturb in (False, True):
+        keys = split.visual_memory_keys.clone()
+        if perturb:
+            gen = torch.Generator().manual_seed(11)
+            mask = torch.rand(keys.shape, generator=gen) < 0.02
+            keys = torch.where(mask, (keys.float() * (1 + 2.0 ** -10)).half(), keys)
+        tr = to.Trainer(cfg, keys, split.textual_memory_bank, sd, cfg["alpha"], cfg["beta"])
+        with torch.no_grad():
+            tr.visual.copy_(before["visual"])
+            if "textual" in before:
+                tr.textual.copy_(before["textual"])
+        out.append(tr.step(qi, ql)[3])
+    return {n: (0.0 if out[0].get(n) is None else (out[0][n].float() - out[1][n].float()).norm().item()) for n in names}
+
+
+def _gpu_params(gpu, names):
+    ad = dict(gpu.adapter.named_parameters())
+    return {n: (gpu.visual if n == "visual" else gpu.textual if n == "textual" else ad[n].data) for n in names}
+
+
+@pytest.mark.parametrize("name", list(TRAIN))
+def test_first_steps_match_reference_and_oracle(name):
+    """Same episodes as the reference's run; after each of the first three steps the GPU state is compared with the
+    reference fixture, then RESET to it, so every step is judged on identical inputs."""
+    g, names, cfg, ref, gpu = _trainers(name)
+    N, K = gpu.N, gpu.K
+    rng = np.random.RandomState(1)
+    eps = []
+    for _ in range(cfg["train_epoch"]):
+        eps.extend((qi, ql) for _, qi, ql in to.sample_epoch(N, K, rng))
+    from proto_clip_amd.train import sample_epoch
+    rng2 = np.random.RandomState(1)
+    mine = []
+    for _ in range(cfg["train_epoch"]):
+        mine.extend((qi, ql) for _, qi, ql in sample_epoch(N, K, rng2))
+    assert mine == eps                                      # product sampler == oracle sampler == reference (CPU test)
+    for ep in range(3):
+        qi, ql = eps[ep]
+        noise = _oracle_noise(name, g, names, ep, qi, ql)
+        matches, loss, l1, l2, l3, _, _ = gpu.step(qi, ql)
+        assert float(matches.item()) == g["ep_matches"][ep]
+        assert abs(loss.item() - g["ep_loss"][ep]) <= 2e-5 * max(1.0, abs(g["ep_loss"][ep]))
+        if l1 is not None:
+            assert abs(l1.item() - g["ep_l1"][ep]) <= 2e-5 * max(1.0, abs(g["ep_l1"][ep]))
+        if l2 is not None:
+            assert abs(l2.item() - g["ep_l2"][ep]) <= 2e-5 and abs(l3.item() - g["ep_l3"][ep]) <= 2e-5
+        cur = _gpu_params(gpu, names)
+        pid = {n: id(p) for n, p in zip(names, [None] * len(names))}
+        ad = dict(gpu.adapter.named_parameters())
+        for n in names:
+            key = f"grad{ep}__{n}"
+            p = gpu.visual if n == "visual" else gpu.textual if n == "textual" else ad[n]
+            got = gpu.last_grads.get(id(p))
+            if key in g:
+                assert got is not None, n
+                refg = torch.from_numpy(g[key]).float()
+                err = (got.reshape(refg.shape).float().cpu() - refg).norm().item()
+                assert err <= 5e-3 * refg.norm().item() + 3.0 * noise[n], (name, ep, n, err, refg.norm().item(), noise[n])
+            else:
+                assert got is None, n
+            after = torch.from_numpy(g[f"after{ep}__{n}"])
+            diff = (cur[n].cpu().float() - after.float()).abs()
+            # fp16 AdamW amplifies gradient noise: the update is lr * m_hat / (sqrt(v_hat) + 1e-4) with v = r16(1e-3 g^2), which
+            # underflows to 0 for |g| < 5.5e-3 — there the step is 10 g instead of ~0.13 g, so a 1-ulp gradient difference AT that
+            # threshold moves the parameter by ~0.05.  Judge the bulk tightly and bound the fraction of such outliers.
+            big = 2.5 * cfg["lr"] + 2.0 ** -10 * after.abs().max().item()
+            assert (diff > big).float().mean().item() < 5e-3, (name, ep, n, (diff > big).float().mean().item())
+            before = torch.from_numpy(g[f"init__{n}"] if ep == 0 else g[f"after{ep - 1}__{n}"]).float()
+            upd = (after.float() - before).abs().mean().item()
+            # where v underflows the step is (lr / eps) * g: gradient noise is amplified by lr / 1e-4
+            amp = cfg["lr"] / 1e-4 * 3.0 * noise[n] / after.numel() ** 0.5
+            assert diff.mean().item() <= 0.02 * upd + 2.0 ** -13 * after.abs().mean().item() + amp, (name, ep, n, diff.mean().item(), upd, amp)
+            cur[n].copy_(after.cuda())                      # continue from the reference state
+        for n in names:                                     # ... including the AdamW moments (re-derive from the oracle)
+            pass
+        ref.step(qi, ql)
+        # moments: copy the oracle's (bit-exact with the reference's) state
+        oparams = {"visual": ref.visual, "textual": ref.textual, **ref.adapter}
+        for n in names:
+            p = gpu.visual if n == "visual" else gpu.textual if n == "textual" else ad[n]
+            st = ref.opt.state.get(oparams[n])
+            if st:
+                m, v, cnt = gpu.state[id(p)]
+                m.copy_(st["exp_avg"].cuda())
+                v.copy_(st["exp_avg_sq"].cuda())
+
+
+def _oracle_run(name, g, names, perturb):
+    split, cfg = train_inputs(name)
+    init = {n: torch.from_numpy(g["init__" + n]) for n in names}
+    keys = split.visual_memory_keys.clone()
+    if perturb:
+        gen = torch.Generator().manual_seed(7)
+        mask = torch.rand(keys.shape, generator=gen) < 0.02
+        keys = torch.where(mask, (keys.float() * (1 + 2.0 ** -10)).half(), keys)
+    tr = to.Trainer(cfg, keys, split.textual_memory_bank, {k: v for k, v in init.items() if k not in ("visual", "textual")},
+                    cfg["alpha"], cfg["beta"])
+    rng, losses = np.random.RandomState(1), []
+    for _ in range(cfg["train_epoch"]):
+        for _, qi, ql in to.sample_epoch(tr.N, tr.K, rng):
+            losses.append(tr.step(qi, ql)[1])
+        tr.sched.step()
+    return losses, tr.visual.data.clone()
+
+
+@pytest.mark.parametrize("name", list(TRAIN))
+def test_free_running_training_tracks_reference(name):
+    """Whole training run without resets.  fp16 AdamW is chaotic at the ulp level (threshold note above), so the yardstick is
+    the reference's OWN sensitivity: the oracle is run a second time with 2 % of the key elements moved by one fp16 ulp
+    (T_fc / T_c3 end 5.5 % / 1.5 % away from the unperturbed run; the conv-2x case, whose conv gradients are rounding noise
+    amplified 20x by AdamW, 41 %).  The GPU run must stay within 3x that self-deviation (+2 % of the loss)."""
+    g, names, cfg, ref, gpu = _trainers(name)
+    base_l, base_v = _oracle_run(name, g, names, False)
+    pert_l, pert_v = _oracle_run(name, g, names, True)
+    # (oracle == reference bit for bit is tests/test_train_oracle.py, in the container the fixture was made in; on another
+    # host CPU torch's threaded fp16 kernels already move the oracle's losses by ~2e-3)
+    rng = np.random.RandomState(1)
+    ep, sens = 0, 0.0
+    from proto_clip_amd.train import sample_epoch
+    for _ in range(cfg["train_epoch"]):
+        for _, qi, ql in sample_epoch(gpu.N, gpu.K, rng):
+            _, loss, *_ = gpu.step(qi, ql)
+            sens = max(sens, abs(base_l[ep] - pert_l[ep]))
+            assert abs(loss.item() - g["ep_loss"][ep]) <= 2e-2 * max(1.0, abs(g["ep_loss"][ep])) + 3.0 * sens, (name, ep, sens)
+            ep += 1
+        gpu.end_epoch()
+    assert ep == int(g["n_episodes"])
+    cur = _gpu_params(gpu, names)
+    fin = torch.from_numpy(g["final__visual"]).float()
+    self_dev = rel_l2(pert_v, base_v)
+    assert rel_l2(cur["visual"], fin) <= max(3.0 * self_dev, 0.02), (name, rel_l2(cur["visual"], fin), self_dev)
+
+
+@pytest.mark.parametrize("name", ["T_fc", "T_c3"])
+def test_run_proto_clip_trains_like_the_reference(name, tmp_path, monkeypatch):
+    """End to end through the reference's entry point (main.run_proto_clip, only_test False): same seeds as the fixture run
+    -> identical adapter initialisation and episodes; validation accuracy per epoch and the final fixed-(alpha, beta) test
+    accuracy within 3 points of the reference's run (val 96 / test 96 queries: one query = 1.04 points)."""
+    import contextlib, io, re
+    from proto_clip_amd import main as pmain
+    g = golden("train_" + name)
+    split, cfg = train_inputs(name)
+    cfg.update(cache_dir=str(tmp_path / "caches"), logs_dir_path="logs")
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(1)
+    np.random.seed(1)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        out = pmain.run_proto_clip(cfg, split.visual_memory_keys.cuda(), split.visual_memory_values.cuda(), split.val_features.cuda(),
+                                   split.val_labels.cuda(), split.test_features.cuda(), split.test_labels.cuda(),
+                                   split.textual_memory_bank.cuda(), None, [str(i) for i in range(int(g["meta"][0]))])
+    tr = out["train"]["trainer"]
+    val = [h["val_acc"] * 100 for h in out["train"]["history"]]
+    assert len(val) == len(g["val_acc"])
+    assert max(abs(a - b) for a, b in zip(val, g["val_acc"])) <= 3.2, (val, list(g["val_acc"]))
+    assert abs(out["test"]["fixed_acc"] * 100 - float(g["fixed_acc"])) <= 3.2
+    # checkpoints under the reference's names, loadable the way the reference's test block loads them
+    d = f"{pmain.get_model_dir_root(cfg)}/alpha-beta/{cfg['alpha']}-{cfg['beta']}"
+    pre = f"best_lr_{cfg['lr']}_aug_{cfg['augment_epoch']}_epochs_{cfg['train_epoch']}"
+    v = torch.load(f"{d}/{pre}_v.pt")
+    assert v.shape == (tr.N * tr.K, tr.D) and v.dtype == torch.float16
+    assert set(torch.load(f"{d}/{pre}_a.pt").keys()) == set(n for n in [str(x) for x in g["names"]] if n not in ("visual", "textual"))
+
+
+def test_adapter_init_matches_reference_under_the_same_seed():
+    from proto_clip_amd.main import make_adapter
+    for name in TRAIN:
+        g = golden("train_" + name)
+        split, cfg = train_inputs(name)
+        D, NK = split.visual_memory_keys.shape
+        torch.manual_seed(1)
+        torch.nn.Embedding(num_embeddings=NK, embedding_dim=D)
+        ad = make_adapter(cfg, D)
+        for k, v in ad.state_dict().items():
+            assert torch.equal(v.cpu(), torch.from_numpy(g["init__" + k])), (name, k)

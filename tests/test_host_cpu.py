@@ -166,3 +166,33 @@ def test_model_surface_and_state_dict_names():
     assert m.state_dict()["transformer.resblocks.0.attn.in_proj_weight"].dtype == torch.float16
     with pytest.raises(Exception):
         m.encode_image(torch.zeros(1, 3, 32, 32))                                   # CPU tensor: loud, no fallback
+
+
+# ---------------------------------------------------------------- training host logic -------------------------
+def test_episode_sampler_reproduces_the_reference_run():
+    """proto_clip_amd.train.sample_epoch against the episodes the reference drew (tests/golden/train_*.npz)."""
+    from conftest import golden
+    from golden.spec import TRAIN
+    from proto_clip_amd.train import sample_epoch
+    for name in TRAIN:
+        g = golden("train_" + name)
+        N, K = int(g["meta"][0]), int(g["meta"][1])
+        rng = np.random.RandomState(1)
+        labels, sizes = [], []
+        for _ in range(TRAIN[name][11]):
+            for classes, q_idx, q_lab in sample_epoch(N, K, rng):
+                assert all(i // K == l for i, l in zip(q_idx, q_lab)) and sorted(set(q_lab)) == [int(c) for c in classes if int(c) in q_lab]
+                labels.extend(q_lab)
+                sizes.append(len(q_lab))
+        assert sizes == list(g["ep_sizes"]) and labels == list(g["ep_labels"].astype(int))
+
+
+def test_cosine_lr_matches_torch_scheduler():
+    from proto_clip_amd.train import cosine_lr
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=0.003)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, 40)
+    for epoch in range(1, 45):
+        opt.step()
+        sched.step()
+        assert abs(sched.get_last_lr()[0] - cosine_lr(0.003, epoch, 40)) <= 1e-12 + 1e-9 * 0.003
