@@ -216,8 +216,9 @@ int pclip_addscaled_rows_f32(float* C, int ldc, const float* X, int ldx, const f
 
 /* L = mean_q -log p[q, y_q] with p as in pclip_fuse_probs (utils.py:90-93 `NLLLoss()(torch.log(p), target)`): per-query terms
  * nll[q] = -log p[q,y_q], pmax[q], argmax[q] (utils.py:84-85) and the gradients gi/gt [Q, ldd] of L wrt the two squared-distance
- * rows; rowsum[q] = sum_c (gi + gt)[q, c]. */
-int pclip_nll_grad(const float* d2i, const float* d2t, const int32_t* labels, int Q, int N, int ldd, float alpha,
+ * rows; rowsum[q] = sum_c (gi + gt)[q, c].  q_total >= Q is the number of queries the mean runs over (> Q when the queries of a
+ * step are sharded over ranks). */
+int pclip_nll_grad(const float* d2i, const float* d2t, const int32_t* labels, int Q, int q_total, int N, int ldd, float alpha,
                    float one_minus_alpha, float beta, float* gi, float* gt, float* rowsum, float* nll, float* pmax,
                    int32_t* argmax, pclip_stream_t stream);
 

@@ -105,8 +105,9 @@ __global__ __launch_bounds__(256) void addscaled_rows_kernel(float* __restrict__
 //   dL/dd_x[c] = beta * w_x * (s_x[c] * s_x[y] - [c == y] s_x[y]) ... written as  g_x[c] = k_x * ([c==y] - s_x[c]),
 //   k_x = weight_x * beta * s_x[y] / (Q p_y).
 __global__ __launch_bounds__(256) void nll_grad_kernel(const float* __restrict__ d2i, const float* __restrict__ d2t,
-                                                       const int32_t* __restrict__ labels, int Q, int N, int ldd, float alpha,
-                                                       float oma, float beta, float* __restrict__ gi, float* __restrict__ gt,
+                                                       const int32_t* __restrict__ labels, int Q, int q_total, int N, int ldd,
+                                                       float alpha, float oma, float beta, float* __restrict__ gi,
+                                                       float* __restrict__ gt,
                                                        float* __restrict__ rowsum, float* __restrict__ nll,
                                                        float* __restrict__ pmax, int32_t* __restrict__ argmax) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void nll_grad_kernel(const float* __restrict__
         wave_argmax(best, bi);
         const float siy = expf(__fsub_rn(__fmul_rn(beta, -ri[y]), mxi)) / si, sty = expf(__fsub_rn(__fmul_rn(beta, -rt[y]), mxt)) / st;
         const float py = __fadd_rn(__fmul_rn(alpha, siy), __fmul_rn(oma, sty));
-        const float gy = -1.f / ((float)Q * py);                       // dL/dp at the label
+        const float gy = -1.f / ((float)q_total * py);                 // dL/dp at the label (mean over ALL queries of the step)
         // softmax backward with a one-hot upstream gradient: du[c] = s[c] * (g[c] - g_y s_y), then dd = -beta du
         const float kiy = alpha * gy * siy, kty = oma * gy * sty;       // g_y * s_y per bank
         float rs = 0.f;
@@ -422,13 +423,13 @@ extern "C" int pclip_addscaled_rows_f32(float* C, int ldc, const float* X, int l
     return pclip_check_launch("addscaled_rows_f32");
 }
 
-extern "C" int pclip_nll_grad(const float* d2i, const float* d2t, const int32_t* labels, int Q, int N, int ldd, float alpha,
-                              float one_minus_alpha, float beta, float* gi, float* gt, float* rowsum, float* nll, float* pmax,
-                              int32_t* argmax, pclip_stream_t stream) {
+extern "C" int pclip_nll_grad(const float* d2i, const float* d2t, const int32_t* labels, int Q, int q_total, int N, int ldd,
+                              float alpha, float one_minus_alpha, float beta, float* gi, float* gt, float* rowsum, float* nll,
+                              float* pmax, int32_t* argmax, pclip_stream_t stream) {
     PCLIP_REQUIRE(d2i && d2t && labels && gi && gt && rowsum && nll && pmax && argmax, "pclip_nll_grad: null pointer");
-    PCLIP_REQUIRE(Q >= 0 && N > 0 && ldd >= N, "pclip_nll_grad: bad Q=%d N=%d ldd=%d", Q, N, ldd);
+    PCLIP_REQUIRE(Q >= 0 && q_total >= Q && N > 0 && ldd >= N, "pclip_nll_grad: bad Q=%d q_total=%d N=%d ldd=%d", Q, q_total, N, ldd);
     if (Q == 0) return PCLIP_OK;
-    nll_grad_kernel<<<row_grid(Q, 8192), 256, 0, (hipStream_t)stream>>>(d2i, d2t, labels, Q, N, ldd, alpha, one_minus_alpha, beta,
+    nll_grad_kernel<<<row_grid(Q, 8192), 256, 0, (hipStream_t)stream>>>(d2i, d2t, labels, Q, q_total, N, ldd, alpha, one_minus_alpha, beta,
                                                                        gi, gt, rowsum, nll, pmax, argmax);
     return pclip_check_launch("nll_grad");
 }

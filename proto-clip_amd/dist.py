@@ -16,6 +16,29 @@ import torch
 import torch.distributed as dist
 
 
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank(group=None) -> int:
+    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+
+
+def allreduce_sum_(tensors, group=None):
+    """In-place sum over ranks of a list of same-dtype tensors with ONE all-reduce of their concatenation (the training
+    step's gradients are a few MB: latency-bound on xGMI, so one message beats one per tensor).  Returns `tensors`."""
+    if not (dist.is_available() and dist.is_initialized()) or not tensors:
+        return tensors                                      # (a 1-rank group still goes through RCCL: exercised on one GPU)
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view(t.shape))
+        off += n
+    return tensors
+
+
 def shard_bounds(n_items: int, rank: int, world: int):
     """Contiguous slab [lo, hi) of rank `rank` (sizes differ by at most one)."""
     base, rem = divmod(n_items, world)

@@ -55,9 +55,12 @@ def populate_cfg_using_args(cfg, args):
     return cfg
 
 
-def hp_grid():
-    """alpha in {0, .1, ..., 1} (rounded), beta in {.1...0.9} U {1...20} (main.py:142-146)."""
-    alpha_list = np.arange(0, 1 + 0.1, 0.1).round(1)
+def hp_grid(rounded: bool = True):
+    """alpha in {0, .1, ..., 1} (rounded in main.py:142-144, left as np.arange yields them in main.qt.py:110-111),
+    beta in {.1...0.9} U {1...20} (main.py:145-146)."""
+    alpha_list = np.arange(0, 1 + 0.1, 0.1)
+    if rounded:
+        alpha_list = alpha_list.round(1)
     beta_list = np.concatenate((np.arange(0.1, 1, 0.1), np.arange(1, 21, 1.0)))
     return alpha_list, beta_list
 
@@ -91,21 +94,22 @@ def make_adapter(cfg, ndim):
     raise ValueError(f"unknown adapter {cfg['adapter']!r}")
 
 
-def train_proto_clip(cfg, visual_memory_keys, textual_memory_bank, adapter, val_features, val_labels, alpha, beta):
+def train_proto_clip(cfg, visual_memory_keys, textual_memory_bank, adapter, val_features, val_labels, alpha, beta,
+                     clip_model=None, train_loader_F=None, subdir="alpha-beta"):
     """The training loop of reference main.py:216-381: episodes of proto_clip_amd.train, per-epoch validation with the
     inference kernels, best-on-validation checkpoints under the reference's file names."""
     from .train import ProtoClipTrainer
     K = cfg["shots"]
     trainer = ProtoClipTrainer(cfg, visual_memory_keys, textual_memory_bank, adapter, alpha, beta)
     N = trainer.N
-    model_dir = f"{get_model_dir_root(cfg)}/alpha-beta/{alpha}-{beta}"
+    model_dir = f"{get_model_dir_root(cfg)}/{subdir}/{alpha}-{beta}"
     model_prefix = f"best_lr_{cfg['lr']}_aug_{cfg['augment_epoch']}_epochs_{cfg['train_epoch']}"
     os.makedirs(model_dir, exist_ok=True)
     pv, pt, pa = (os.path.join(model_dir, f"{model_prefix}_{s}.pt") for s in ("v", "t", "a"))
     best_acc, best_epoch, history = 0.0, 0, []
     for epoch in range(cfg["train_epoch"]):
         print("Train Epoch: {:} / {:}".format(epoch, cfg["train_epoch"]))
-        train_acc, train_loss, lr = trainer.train_epoch()                                    # main.py:228-312
+        train_acc, train_loss, lr = trainer.train_epoch(clip_model=clip_model, train_loader_F=train_loader_F)   # main.py:228-312
         print("LR: {:.6f}, Acc: {:.4f}%, Loss: {:.4f}".format(lr, train_acc * 100, train_loss))
         with torch.no_grad():                                                                # main.py:318-345
             z_img_proto = ops.proto_build(trainer.visual, N, K, per_shot_norm=True)
@@ -126,12 +130,14 @@ def train_proto_clip(cfg, visual_memory_keys, textual_memory_bank, adapter, val_
 
 
 def run_proto_clip(cfg, visual_memory_keys, visual_memory_values, val_features, val_labels, test_features,
-                   test_labels, textual_memory_bank, clip_model, text_prompts):
+                   test_labels, textual_memory_bank, clip_model, text_prompts, train_loader_F=None, variant="main"):
     """Reference main.py:105-465.  Returns a dict of everything it computed."""
     ndim, NxK = visual_memory_keys.shape
     K = cfg["shots"]
     N = NxK // K
-    alpha_list, beta_list = hp_grid()
+    qt = variant == "qt"                                               # main.qt.py: queries from the image loader
+    subdir = "best-alpha-beta" if qt else "alpha-beta"                 # main.qt.py:292, 327
+    alpha_list, beta_list = hp_grid(rounded=not qt)
     model_dir_root = get_model_dir_root(cfg)
     os.makedirs(model_dir_root, exist_ok=True)
     tag = f"{beautify(cfg['backbone'])}_K_{cfg['shots']}"
@@ -167,12 +173,15 @@ def run_proto_clip(cfg, visual_memory_keys, visual_memory_values, val_features, 
     torch.nn.Embedding(num_embeddings=NxK, embedding_dim=ndim)
     adapter = make_adapter(cfg, ndim)
     if not cfg.get("only_test", False):
+        if qt and train_loader_F is None:
+            raise ValueError("the main.qt.py variant trains on images: pass train_loader_F")
         out["train"] = train_proto_clip(cfg, visual_memory_keys, textual_memory_bank, adapter, val_features, val_labels,
-                                        best_alpha, best_beta)
+                                        best_alpha, best_beta, clip_model=clip_model, train_loader_F=train_loader_F if qt else None,
+                                        subdir=subdir)
 
     with torch.no_grad():
         print("Testing...")
-        model_dir = f"{model_dir_root}/alpha-beta/{best_alpha}-{best_beta}"
+        model_dir = f"{model_dir_root}/{subdir}/{best_alpha}-{best_beta}"
         model_prefix = f"best_lr_{cfg['lr']}_aug_{cfg['augment_epoch']}_epochs_{cfg['train_epoch']}"
         pv, pt, pa = (os.path.join(model_dir, f"{model_prefix}_{s}.pt") for s in ("v", "t", "a"))
         try:

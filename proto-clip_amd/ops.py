@@ -427,7 +427,7 @@ def addscaled_rows_(c: torch.Tensor, x: torch.Tensor, rowscale: torch.Tensor, s:
     return c
 
 
-def nll_grad(d2i, d2t, labels, N: int, alpha: float, beta: float):
+def nll_grad(d2i, d2t, labels, N: int, alpha: float, beta: float, q_total: int = None):
     """From the distance rows of sqdist_f32: gradients (gi, gt) of mean NLL(log P) wrt them, rowsum(gi + gt), the per-query
     -log p[y], max probability and argmax (utils.py:84-93)."""
     require_cuda(d2i, d2t, labels)
@@ -436,7 +436,7 @@ def nll_grad(d2i, d2t, labels, N: int, alpha: float, beta: float):
     rs, nll, pmax = (torch.empty(Q, dtype=torch.float32, device=d2i.device) for _ in range(3))
     am = torch.empty(Q, dtype=torch.int32, device=d2i.device)
     lab = labels.to(torch.int32)
-    check(_lib.load().pclip_nll_grad(ptr(d2i), ptr(d2t), ptr(lab), Q, N, ldd, alpha, 1.0 - alpha, beta, ptr(gi), ptr(gt),
+    check(_lib.load().pclip_nll_grad(ptr(d2i), ptr(d2t), ptr(lab), Q, Q if q_total is None else q_total, N, ldd, alpha, 1.0 - alpha, beta, ptr(gi), ptr(gt),
                                      ptr(rs), ptr(nll), ptr(pmax), ptr(am), stream()), "pclip_nll_grad")
     return gi, gt, rs, nll, pmax, am
 

@@ -16,6 +16,7 @@ import math
 import numpy as np
 import torch
 
+from . import dist as pdist
 from . import ops
 from ._lib import PclipError
 from .model import Adapter, Adapter_FC
@@ -114,6 +115,7 @@ class ProtoClipTrainer:
         self.state = {id(p): (torch.zeros_like(p.data if hasattr(p, "data") else p), torch.zeros_like(p.data if hasattr(p, "data") else p), [0])
                       for p in params}
         self.epoch = 0
+        self._param_index = {id(p): i for i, p in enumerate(adapter.parameters())}
 
     # -- forward pieces shared with evaluation ------------------------------------------------------------
     def adapter_forward(self, x):
@@ -145,29 +147,71 @@ class ProtoClipTrainer:
         return ops.colsum_f32(loss_rows.view(n, 1), scale=1.0 / n)                           # [1] device scalar
 
     def step(self, query_index, zq_labels):
-        """One episode: forward, backward, AdamW.  Returns the 7-tuple of utils.compute_loss_and_matches (device scalars;
-        entries the configured `losses` do not produce are None)."""
+        """One episode of main.py (queries = rows `query_index` of the constant key bank, main.py:265-266): forward,
+        backward, AdamW.  Returns the 7-tuple of utils.compute_loss_and_matches (device scalars; entries the configured
+        `losses` do not produce are None).  Under torch.distributed every rank draws the same episode (same numpy seed) and
+        takes its contiguous slab of the queries."""
+        dev = self.visual.device
+        q_total = len(query_index)
+        if pdist.world_size() > 1:
+            lo, hi = pdist.shard_bounds(q_total, pdist.rank(), pdist.world_size())
+            query_index, zq_labels = query_index[lo:hi], zq_labels[lo:hi]
+        qi = torch.as_tensor(query_index, device=dev, dtype=torch.long)
+        return self.step_features(self.keys_rows[qi], torch.as_tensor(zq_labels, device=dev, dtype=torch.long), q_total=q_total)
+
+    def step_features(self, xq, labels, q_total=None):
+        """One step on explicit query features xq [Q, D] fp16 with labels [Q] — the Proto-CLIP-F-Q^T variant (main.qt.py:198-
+        209) feeds `clip_model.encode_image(images)` of the training loader here.
+
+        Data parallel: xq / labels are THIS rank's queries, q_total the number over all ranks (all-reduced when
+        None).  The query-dependent gradients — fp32 gradients wrt the two prototype matrices and the adapter parameters,
+        plus the loss / match sums — are summed over ranks in ONE all-reduce (RCCL) before the replicated tail (alignment
+        losses, prototype-chain backward, fp16 rounding, AdamW), so every rank applies the identical update."""
         N, K = self.N, self.K
         dev = self.visual.device
-        qi = torch.as_tensor(query_index, device=dev)
-        labels = torch.as_tensor(zq_labels, device=dev)
-        Q = qi.numel()
+        xq = xq.to(dev).contiguous()
+        labels = labels.to(dev)
+        Q = xq.shape[0]
+        if q_total is None:
+            q_total = Q if not pdist.dist.is_initialized() else int(pdist.allreduce_sum_([torch.tensor([float(Q)], device=dev)])[0].item())
         # ---- forward ----
         z_img = ops.proto_build(self.visual, N, K, per_shot_norm=True, fp32_out=True)        # 260-264
-        xq = self.keys_rows[qi]                                                              # 266
-        a, saved = self.adapter_forward(xq)                                                  # 267
-        zq = ops.proto_build(a, Q, 1, per_shot_norm=False, fp32_out=True)                    # .float(); / norm (267, 274)
         z_txt = ops.cast_f32(ops.l2norm_rows(self.textual))                                  # 272-279
-        d2i, d2t, _ = ops.sqdist_f32(zq, z_img, z_txt)                                       # P (utils.py:225-244)
-        gi, gt, rs, nll, _, am = ops.nll_grad(d2i, d2t, labels, N, self.alpha, self.beta)
-        matches = (am.long() == labels).float().sum()                                        # utils.py:84-85
         g_img = torch.zeros(N, self.D, dtype=torch.float32, device=dev)
         g_txt = torch.zeros(N, self.D, dtype=torch.float32, device=dev)
+        sums = torch.zeros(2, dtype=torch.float32, device=dev)                               # [sum_q nll / q_total, matches]
+        use_l1 = len(self.losses) == 0 or "L1" in self.losses                                # utils.py:90
+        ad_grads = {}
+        if Q > 0:
+            a, saved = self.adapter_forward(xq)                                              # 267
+            zq = ops.proto_build(a, Q, 1, per_shot_norm=False, fp32_out=True)                # .float(); / norm (267, 274)
+            d2i, d2t, _ = ops.sqdist_f32(zq, z_img, z_txt)                                   # P (utils.py:225-244)
+            gi, gt, rs, nll, _, am = ops.nll_grad(d2i, d2t, labels, N, self.alpha, self.beta, q_total=q_total)
+            sums[1] = (am.long() == labels).float().sum()                                    # utils.py:84-85
+            if use_l1:
+                sums[0:1] = ops.colsum_f32(nll.view(Q, 1), scale=1.0 / q_total)
+                gi_v, gt_v = gi[:, :N], gt[:, :N]                                            # views of the padded rows
+                # cdist backward: dq = sum_c 2 G[q,c] (q - z_c), dz_c = sum_q 2 G[q,c] (z_c - q)
+                gq = ops.gemm_f32(gi_v, z_img, alpha=-2.0)
+                ops.gemm_f32(gt_v, z_txt, alpha=-2.0, out=gq, beta=1.0)
+                ops.addscaled_rows_(gq, zq, rs, 2.0)
+                ops.gemm_f32(gi_v, zq, trans_a=True, alpha=-2.0, out=g_img, beta=1.0)
+                ops.gemm_f32(gt_v, zq, trans_a=True, alpha=-2.0, out=g_txt, beta=1.0)
+                ops.addscaled_rows_(g_img, z_img, ops.colsum_f32(gi, cols=N), 2.0)
+                ops.addscaled_rows_(g_txt, z_txt, ops.colsum_f32(gt, cols=N), 2.0)
+                da = ops.proto_backward(a, gq, Q, 1, per_shot_norm=False, final_norm=True)   # fp16, dL/d adapter(x)
+                ad_grads = self.adapter_backward(saved, da)                                  # fp32, parameter-shaped
+        if pdist.dist.is_initialized():
+            if use_l1:                                                                       # a rank without queries still contributes zeros
+                for p in self.adapter_params_with_grad():
+                    ad_grads.setdefault(p, torch.zeros(p.shape, dtype=torch.float32, device=dev))
+            order = sorted(ad_grads, key=lambda p: self._param_index[id(p)])
+            pdist.allreduce_sum_([sums, g_img, g_txt] + [ad_grads[p] for p in order])
+        matches = sums[1]
         total = torch.zeros(1, dtype=torch.float32, device=dev)
         l1 = l2 = l3 = l4i = l4t = None
-        use_l1 = len(self.losses) == 0 or "L1" in self.losses                                # utils.py:90
         if use_l1:
-            l1 = ops.colsum_f32(nll.view(Q, 1), scale=1.0 / Q)
+            l1 = sums[0:1].clone()
             total += l1
         if "L2" in self.losses:
             l2 = self._info_nce(z_img, z_txt, g_img, g_txt)
@@ -180,21 +224,8 @@ class ProtoClipTrainer:
             l4t = self._info_nce(z_txt, z_txt, g_txt, g_txt)
             total += l4i
             total += l4t
-        # ---- backward ----
-        grads = {}
-        if use_l1:
-            gi_v, gt_v = gi[:, :N], gt[:, :N]                                                # views of the padded rows
-            # cdist backward: dq = sum_c 2 G[q,c] (q - z_c), dz_c = sum_q 2 G[q,c] (z_c - q)
-            gq = ops.gemm_f32(gi_v, z_img, alpha=-2.0)
-            ops.gemm_f32(gt_v, z_txt, alpha=-2.0, out=gq, beta=1.0)
-            ops.addscaled_rows_(gq, zq, rs, 2.0)
-            ops.gemm_f32(gi_v, zq, trans_a=True, alpha=-2.0, out=g_img, beta=1.0)
-            ops.gemm_f32(gt_v, zq, trans_a=True, alpha=-2.0, out=g_txt, beta=1.0)
-            ops.addscaled_rows_(g_img, z_img, ops.colsum_f32(gi, cols=N), 2.0)
-            ops.addscaled_rows_(g_txt, z_txt, ops.colsum_f32(gt, cols=N), 2.0)
-            da = ops.proto_backward(a, gq, Q, 1, per_shot_norm=False, final_norm=True)       # fp16, dL/d adapter(x)
-            for p, g in self.adapter_backward(saved, da).items():
-                grads[id(p)] = g
+        # ---- replicated tail of the backward ----
+        grads = {id(p): g for p, g in ad_grads.items()}
         grads[id(self.visual)] = ops.proto_backward(self.visual, g_img, N, K, per_shot_norm=True, final_norm=True)
         if not self.train_vis_mem_only:
             grads[id(self.textual)] = ops.proto_backward(self.textual, g_txt, N, 1, per_shot_norm=True, final_norm=False)
@@ -211,18 +242,36 @@ class ProtoClipTrainer:
         self.last_grads = grads
         return matches, total, l1, l2, l3, l4i, l4t
 
+    def adapter_params_with_grad(self):
+        """Adapter parameters the loss reaches (conv-2x never uses conv2 / bn2: SURVEY fact 7)."""
+        named = dict(self.adapter.named_parameters())
+        skip = ("conv2.weight", "bn2.weight", "bn2.bias") if getattr(self.adapter, "c_type", None) == "conv-2x" else ()
+        return [p for n, p in named.items() if n not in skip]
+
     def end_epoch(self):
         """scheduler.step() (main.py:312)."""
         self.epoch += 1
         self.lr = cosine_lr(self.base_lr, self.epoch, self.t_max)
         return self.lr
 
-    def train_epoch(self, rng=np.random):
+    def train_epoch(self, rng=np.random, clip_model=None, train_loader_F=None):
+        """One epoch: the episodes of main.py:228-310, or — with a loader — one step per batch of freshly encoded training
+        images (main.qt.py:198-250).  Returns (train accuracy, mean loss, learning rate after scheduler.step())."""
         correct, seen, losses = 0.0, 0, []
-        for _, query_index, zq_labels in sample_epoch(self.N, self.K, rng):
-            matches, loss, *_ = self.step(query_index, zq_labels)
-            correct += float(matches.item())
-            seen += len(zq_labels)
-            losses.append(float(loss.item()))
+
+        def book(result, n):
+            nonlocal correct, seen
+            correct += float(result[0].item())
+            seen += n
+            losses.append(float(result[1].item()))
+
+        if train_loader_F is not None:
+            for images, target in train_loader_F:
+                with torch.no_grad():
+                    feats = clip_model.encode_image(images.cuda())                           # main.qt.py:199-201
+                book(self.step_features(feats, target), len(target))
+        else:
+            for _, query_index, zq_labels in sample_epoch(self.N, self.K, rng):
+                book(self.step(query_index, zq_labels), len(zq_labels))
         lr = self.end_epoch()
         return correct / max(seen, 1), sum(losses) / max(len(losses), 1), lr

@@ -56,3 +56,66 @@ def test_sharded_prototypes_gloo(world, N, K):
     s = sum(range(1, world + 1))
     assert ret["counts"] == [[s, 2 * world], [3 * world, 4 * s]]
     assert ret["n"] == sum(10 + r for r in range(world))
+
+
+def _train_worker(rank, world, port, ret):
+    """Data-parallel training step (proto_clip_amd/train.py::step_features): every rank differentiates ITS slab of the
+    episode's queries with the loss normalised by the TOTAL query count; one flat all-reduce (dist.allreduce_sum_) sums the
+    fp32 gradients wrt the two prototype matrices and the adapter parameters.  The per-rank arithmetic is the oracle's
+    autograd (the HIP kernels need a GPU); under test: the decomposition, the slab bounds and the single-message layout."""
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        import torch.nn.functional as F
+        from golden.spec import train_inputs
+        from oracle import train_oracle as to
+        from proto_clip_amd.dist import allreduce_sum_, shard_bounds
+        from proto_clip_amd.train import sample_epoch
+        split, cfg = train_inputs("T_fc")
+        g = np.load(os.path.join(REPO, "tests", "golden", "train_T_fc.npz"))
+        N, K = int(g["meta"][0]), int(g["meta"][1])
+        _, q_idx, q_lab = next(iter(sample_epoch(N, K, np.random.RandomState(1))))       # same episode on every rank
+        keys_rows = split.visual_memory_keys.t().contiguous()
+        ad = {str(n): torch.from_numpy(g["init__" + str(n)]).clone().requires_grad_() for n in g["names"] if str(n).startswith("fc.")}
+
+        def grads(idx, lab, q_total):
+            for p in ad.values():
+                p.grad = None
+            z_img = F.normalize(keys_rows.view(N, K, -1).float().mean(1), dim=-1).requires_grad_()
+            z_txt = F.normalize(split.textual_memory_bank.t().float(), dim=-1).requires_grad_()
+            if len(idx):
+                zq = to.adapter_fc(keys_rows[torch.as_tensor(idx)], ad).float()
+                zq = zq / zq.norm(dim=-1, keepdim=True)
+                p = to.P(zq, z_img, z_txt, cfg["alpha"], cfg["beta"])
+                loss = -torch.log(p[torch.arange(len(idx)), torch.as_tensor(lab)]).sum() / q_total
+                loss.backward()
+            zero = lambda t: torch.zeros_like(t, dtype=torch.float32)
+            out = [zero(z_img) if z_img.grad is None else z_img.grad.clone(), zero(z_txt) if z_txt.grad is None else z_txt.grad.clone()]
+            out += [zero(v) if v.grad is None else v.grad.float().clone() for v in ad.values()]
+            return out
+
+        lo, hi = shard_bounds(len(q_idx), rank, world)
+        mine = allreduce_sum_(grads(q_idx[lo:hi], q_lab[lo:hi], len(q_idx)))
+        full = grads(q_idx, q_lab, len(q_idx))
+        if rank == 0:
+            ret["rel"] = [((a - b).norm() / b.norm().clamp_min(1e-20)).item() for a, b in zip(mine, full)]
+            ret["slabs"] = [shard_bounds(len(q_idx), r, world) for r in range(world)]
+            ret["n"] = len(q_idx)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_data_parallel_training_gradients_gloo(world):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_train_worker, args=(world, port, ret), nprocs=world, join=True)
+    slabs = ret["slabs"]
+    assert slabs[0][0] == 0 and slabs[-1][1] == ret["n"] and all(a[1] == b[0] for a, b in zip(slabs, slabs[1:]))
+    # fp32 prototype gradients: summation order only; fp16 adapter gradients: each rank's autograd rounds its partial to fp16
+    assert ret["rel"][0] < 1e-5 and ret["rel"][1] < 1e-5, ret["rel"]
+    assert max(ret["rel"][2:]) < 2e-2, ret["rel"]

@@ -398,3 +398,41 @@ def test_adapter_init_matches_reference_under_the_same_seed():
         ad = make_adapter(cfg, D)
         for k, v in ad.state_dict().items():
             assert torch.equal(v.cpu(), torch.from_numpy(g["init__" + k])), (name, k)
+
+
+def test_qt_variant_trains_on_encoded_images(tmp_path, monkeypatch):
+    """main.qt.py path: queries = encode_image(batch) of a training image loader.  With a stub encoder that returns the key
+    rows of the requested samples, a loader that replays the reference's episodes makes the run identical to main.py's —
+    so the reference fixture of T_fc applies to the variant's plumbing (loader -> encode -> step_features -> checkpoints)."""
+    import contextlib, io, types
+    from proto_clip_amd import main_qt
+    from proto_clip_amd.train import sample_epoch
+    name = "T_fc"
+    g = golden("train_" + name)
+    split, cfg = train_inputs(name)
+    cfg.update(cache_dir=str(tmp_path / "caches"), logs_dir_path="logs")
+    monkeypatch.chdir(tmp_path)
+    N, K = int(g["meta"][0]), int(g["meta"][1])
+    keys_rows = split.visual_memory_keys.t().contiguous().cuda()
+
+    class Loader:                                            # one "image" = its sample index; shuffled per epoch like the episodes
+        def __init__(self):
+            self.rng = np.random.RandomState(1)
+
+        def __iter__(self):
+            for _, qi, ql in sample_epoch(N, K, self.rng):
+                yield torch.tensor(qi).view(-1, 1, 1, 1), torch.tensor(ql)
+
+    clip_stub = types.SimpleNamespace(dtype=torch.float16, encode_image=lambda img: keys_rows[img.view(-1).long()])
+    torch.manual_seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        out = main_qt.run_proto_clip(cfg, split.visual_memory_keys.cuda(), split.visual_memory_values.cuda(), split.val_features.cuda(),
+                                     split.val_labels.cuda(), split.test_features.cuda(), split.test_labels.cuda(),
+                                     split.textual_memory_bank.cuda(), clip_stub, [str(i) for i in range(N)], Loader())
+    val = [h["val_acc"] * 100 for h in out["train"]["history"]]
+    assert max(abs(a - b) for a, b in zip(val, g["val_acc"])) <= 3.2
+    assert abs(out["test"]["fixed_acc"] * 100 - float(g["fixed_acc"])) <= 3.2
+    import os
+    d = f"{main_qt._main.get_model_dir_root(cfg)}/best-alpha-beta/{cfg['alpha']}-{cfg['beta']}"
+    assert os.path.exists(f"{d}/best_lr_{cfg['lr']}_aug_{cfg['augment_epoch']}_epochs_{cfg['train_epoch']}_v.pt")
+    assert out["zero_shot"]["val"][3 * 29, 0] == np.arange(0, 1.1, 0.1)[3]          # un-rounded alpha grid (0.30000000000000004)
