@@ -115,3 +115,28 @@ class ProtoClipClassifier:
             return ti, tp
         names = [[self.class_names[int(x)].replace("_", " ") for x in row] for row in ti.cpu()]
         return names, tp
+
+
+def test_ood_performance(cfg, test_loader, clip_model=None, memory_bank_v_path=None, memory_bank_t_path=None, adapter_type=None,
+                         adapter_weights_path=None):
+    """Accuracy (percent) of trained banks + adapter on an out-of-distribution test split (reference toolkit
+    ood_utils.py:58-111).  The reference builds the ImageNet-V2 / ImageNet-Sketch datasets itself (torchvision /
+    imagenetv2_pytorch: out of scope); here the caller passes the loader of pre-processed `[B,3,R,R]` batches."""
+    from .utils import pre_load_features
+    if clip_model is None:
+        from . import clip
+        clip_model, _ = clip.load(cfg["backbone"])
+    clip_model.eval()
+    test_features, test_labels = pre_load_features(cfg, "test", clip_model, test_loader)             # ood_utils.py:83
+    with torch.no_grad():
+        embeddings_v, embeddings_t, adapter = load_pretrained_mb_and_adapters(
+            memory_bank_v_path=memory_bank_v_path, memory_bank_t_path=memory_bank_t_path, adapter_type=adapter_type,
+            adapter_weights_path=adapter_weights_path)
+        K = cfg["shots"]
+        N = embeddings_v.shape[0] // K
+        z_img_proto = ops.proto_build(embeddings_v, N, K)                                            # 96-99
+        z_text_proto = ops.l2norm_rows(embeddings_t)                                                 # 101-102
+        feats = adapter(test_features, l2norm_out=True)                                              # 104-105
+        _, am, _, _ = ops.classify(feats, z_img_proto, z_text_proto, cfg["alpha"], cfg["beta"], want_p=False, want_argmax=True)
+        correct = (am.long() == test_labels.to(am.device)).sum().item()
+    return 100.0 * correct / max(test_features.shape[0], 1)

@@ -263,6 +263,17 @@ def test_serving_entry_eager_and_graph(ops, tmp_path):
     assert torch.equal(t2, e2) and torch.equal(i2, j2.long())
     names, probs = clf.classify_objects(imgs)
     assert names[0][0] == f"c {int(ti[0, 0])}" and torch.equal(probs, tp)
+    # out-of-distribution evaluation entry (toolkit ood_utils.py:58-111) over a list-of-batches loader
+    from proto_clip_amd.serving import test_ood_performance as ood
+    labels = torch.from_numpy(synth.randint(8, N, 3, 77)).long()
+    imgs8 = synth.make_images(8, 32, seed=12, n_class=N)
+    cfg = dict(cache_dir=str(tmp_path / "ood"), backbone="tiny", shots=K, alpha=0.3, beta=7.0)
+    acc = ood(cfg, [(imgs8[:5], labels[:5]), (imgs8[5:], labels[5:])], clip_model=model, memory_bank_v_path=str(tmp_path / "v.pt"),
+              memory_bank_t_path=str(tmp_path / "t.pt"), adapter_type="conv-3x", adapter_weights_path=str(tmp_path / "a.pt"))
+    with torch.no_grad():
+        a8 = adapter(ops.l2norm_rows(model.encode_image(imgs8.cuda())), l2norm_out=True)
+    p8 = po.P(a8.cpu(), po.proto_build(emb_v, N, K), po.l2norm_rows(emb_t), 0.3, 7.0)
+    assert abs(acc - 100.0 * (p8.max(1)[1] == labels).float().mean().item()) < 1e-4
 
 
 def test_resnet_building_blocks(ops):
