@@ -260,6 +260,23 @@ int pclip_adapter_conv_backward_f16(const void* x, const void* g, int B, int D, 
 int pclip_adamw_f16(void* p, const void* g, void* m, void* v, size_t n, double lr, double beta1, double beta2, double eps,
                     double weight_decay, int step, pclip_stream_t stream);
 
+/* ---- image pre-processing (clip/clip.py:77-84 `_transform`; datasets/imagenet.py:8-23 `get_random_train_tfm`) ------------- */
+
+/* A batch of decoded RGB images (uint8, HWC, device memory; srcs = device array of B pointers) -> normalised CHW tensors
+ * out [B, 3, n_px, n_px] (fp32, or fp16 when out_f16: the cast encode_image applies first, clip/model.py:339).  Per image a
+ * 16-int32 descriptor (device array desc [B][16]):
+ *   0 h, 1 w                  source size
+ *   2 box_top, 3 box_left, 4 box_h, 5 box_w   region that is resized (whole image for Resize; the RandomResizedCrop box)
+ *   6 rs_h, 7 rs_w            size the box is resized to (PIL bicubic with antialiasing, bit-identical to Image.resize)
+ *   8 win_top, 9 win_left     n_px x n_px window of the resized box that is kept (CenterCrop offsets; 0, 0 for the train tfm)
+ *   10 flip                   horizontal flip of the window (RandomHorizontalFlip)
+ *   11 coef_off               offset (int32 units) of this image's coefficient tables in ws: n_px*(2+ks_h) + n_px*(2+ks_v) ints
+ *   12 tmp_off                offset (bytes) of its box_h x n_px x 3 uint8 scratch image in ws
+ *   13 ks_h, 14 ks_v          taps per output: ceil(2 * max(box / rs, 1)) * 2 + 1 per axis (1 when box == rs)
+ * max_box_h = max over the batch of box_h.  mean / std: Normalize constants. */
+int pclip_preprocess_u8(const void* const* srcs, const int32_t* desc, int B, int n_px, int max_box_h, float mean0, float mean1,
+                        float mean2, float std0, float std1, float std2, void* out, int out_f16, void* ws, pclip_stream_t stream);
+
 /* ---- workspace sizing -------------------------------------------------------------------- */
 #define PCLIP_OP_SQDIST 1
 #define PCLIP_OP_CLASSIFY 2

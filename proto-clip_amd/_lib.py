@@ -67,6 +67,7 @@ _SIGS = {
     "pclip_proto_backward_f16": [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P],
     "pclip_layernorm_backward_f16": [_P, c_int, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, c_int, _P, c_int, _P],
     "pclip_adamw_f16": [_P, _P, _P, _P, c_size_t, c_double, c_double, c_double, c_double, c_double, c_int, _P],
+    "pclip_preprocess_u8": [_P, _P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, _P, c_int, _P, _P],
     "pclip_workspace_bytes": [c_int, c_int, c_int, c_int],
 }
 _RESTYPES = {"pclip_last_error": c_char_p, "pclip_workspace_bytes": c_size_t, "pclip_gemm_kernel_launches": c_long}

@@ -51,21 +51,18 @@ def load(name: str, device: Union[str, torch.device] = "cuda", jit: bool = False
 
 
 def _transform(n_px):
-    """Resize(bicubic) -> CenterCrop -> RGB -> ToTensor -> Normalize (clip/clip.py:77-84).  Host-side PIL
-    work, outside the accelerated path; built lazily so that importing this module needs no torchvision."""
-    def preprocess(image):
-        import numpy as np
-        from PIL import Image
-        w, h = image.size
-        s = n_px / min(w, h)
-        image = image.resize((max(n_px, round(w * s)), max(n_px, round(h * s))), Image.BICUBIC).convert("RGB")
-        w, h = image.size
-        l, t = (w - n_px) // 2, (h - n_px) // 2
-        a = np.asarray(image.crop((l, t, l + n_px, t + n_px)), dtype=np.float32) / 255.0
-        mean = np.array((0.48145466, 0.4578275, 0.40821073), dtype=np.float32)
-        std = np.array((0.26862954, 0.26130258, 0.27577711), dtype=np.float32)
-        return torch.from_numpy(((a - mean) / std).transpose(2, 0, 1).copy())
-    return preprocess
+    """Resize(bicubic) -> CenterCrop -> RGB -> ToTensor -> Normalize (clip/clip.py:77-84) on the GPU: the returned callable takes
+    a PIL image or a uint8 HWC array and returns the normalised `[3, n_px, n_px]` fp32 tensor (on the device — the callers'
+    `.cuda()` becomes a no-op); `.batch(list)` processes many images in three launches.  Bit-identical to PIL + torchvision
+    (proto_clip_amd/preprocess.py)."""
+    from ..preprocess import ClipPreprocess
+
+    class _Preprocess(ClipPreprocess):
+        def batch(self, images):
+            import numpy as np
+            return super().batch([np.asarray(im.convert("RGB")) if hasattr(im, "convert") else im for im in images])
+
+    return _Preprocess(n_px)
 
 
 def tokenize(texts: Union[str, List[str]], context_length: int = 77, truncate: bool = False) -> torch.LongTensor:

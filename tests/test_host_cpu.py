@@ -196,3 +196,20 @@ def test_cosine_lr_matches_torch_scheduler():
         opt.step()
         sched.step()
         assert abs(sched.get_last_lr()[0] - cosine_lr(0.003, epoch, 40)) <= 1e-12 + 1e-9 * 0.003
+
+
+def test_preprocess_host_rules_match_the_oracle():
+    """Resize(int) output size, CenterCrop offsets and tap counts computed by the host wrapper (proto_clip_amd/preprocess.py)
+    against the oracle's restatement of torchvision / Pillow."""
+    from oracle import preprocess_oracle as pp
+    from proto_clip_amd import preprocess as dp
+    for h, w, n in [(375, 500, 224), (500, 375, 224), (224, 224, 224), (227, 225, 224), (61, 60, 32), (1000, 37, 64)]:
+        assert dp.resize_output_size(h, w, n) == pp.resize_output_size(h, w, n)
+    for i, o in [(500, 224), (224, 224), (100, 224), (375, 298), (37, 64), (1000, 64)]:
+        ks = dp._ksize(i, o)
+        assert ks == (1 if i == o else pp.precompute_coeffs(i, o)[0])
+    t = dp.RandomTrainTransform(size=224)
+    torch.manual_seed(0)
+    for h, w in [(375, 500), (64, 64), (31, 257)]:
+        top, left, ch, cw = t.get_params(h, w)
+        assert 0 <= top and 0 <= left and top + ch <= h and left + cw <= w and ch > 0 and cw > 0
