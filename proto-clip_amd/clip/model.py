@@ -63,24 +63,35 @@ def _transformer(width, layers):
     return t
 
 
-def _run_blocks(x, blocks, B, L, heads, causal):
+def _run_blocks(x, blocks, B, L, heads, causal, select=None):
     """ResidualAttentionBlock.forward (clip/model.py:187-190) per layer on x [B*L, W] fp16.
     Each residual add is fused into the LayerNorm that reads its result, so the stream of a block is
         h = LN1(x [+ d])   qkv = in_proj(h)   a = attention(qkv)   d = out_proj(a)
         h = LN2(x += d)    f = QuickGELU(c_fc(h))                  d = c_proj(f)
-    Returns (x, d): the block stack's output is x + d, left for the caller's final LayerNorm to fuse."""
+    Returns (x, d): the block stack's output is x + d, left for the caller's final LayerNorm to fuse.
+
+    `select(t)` picks, from a [B*L, W] tensor, the B rows the caller reads after the stack (the class token of the vision
+    tower, clip/model.py:233; the EOT token of the text tower, :350).  The reference pushes every token through the last
+    block and then discards all but that row; here the last block's out_proj, LN2 and MLP run on those B rows only — the
+    same arithmetic for the rows that matter (a GEMM row does not depend on the other rows), 9/12 of one layer's linear
+    FLOPs saved (6 % of a 12-layer tower).  With `select`, x and d are returned as [B, W]."""
     d = None
-    for blk in blocks:
+    n = len(blocks)
+    for i, blk in enumerate(blocks):
         if d is None:
             h = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias)
         else:
             h = ops.add_layernorm(x, d, blk.ln_1.weight, blk.ln_1.bias)
         qkv = ops.gemm(h, blk.attn.in_proj_weight, blk.attn.in_proj_bias)
         a = ops.attention(qkv, B, L, heads, causal=causal)
+        if select is not None and i == n - 1:
+            a, x = select(a), select(x)                  # x already holds the residual stream entering this block's out_proj add
         d = ops.gemm(a, blk.attn.out_proj.weight, blk.attn.out_proj.bias)
         h = ops.add_layernorm(x, d, blk.ln_2.weight, blk.ln_2.bias)
         f = ops.gemm(h, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, act=1)
         d = ops.gemm(f, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)
+    if select is not None and n == 0:
+        x = select(x)
     return x, d
 
 
@@ -152,11 +163,12 @@ class VisionTransformer(nn.Module):
         patch = ops.gemm(cols, wconv)
         x = ops.vit_assemble_tokens(patch, cls16, pos16, B, G * G, W)       # clip/model.py:225-226
         x = ops.layernorm(x, self.ln_pre.weight, self.ln_pre.bias)          # 227
-        x, d = _run_blocks(x, self.transformer.resblocks, B, L, self.heads, causal=False)   # 229-231
+        pick_cls = lambda t: t.view(B, L, W)[:, 0, :].contiguous()          # x[:, 0, :], 233 (taken before the last block's tail)
+        x, d = _run_blocks(x, self.transformer.resblocks, B, L, self.heads, causal=False, select=pick_cls)   # 229-231
         if d is None:
-            cls = ops.layernorm(x, self.ln_post.weight, self.ln_post.bias, rows=B, ld=L * W)
+            cls = ops.layernorm(x, self.ln_post.weight, self.ln_post.bias)
         else:                                                               # ln_post((x + d)[:, 0, :]), 233
-            cls = ops.add_layernorm(x, d, self.ln_post.weight, self.ln_post.bias, update_x=False, rows=B, ld=L * W)
+            cls = ops.add_layernorm(x, d, self.ln_post.weight, self.ln_post.bias, update_x=False)
         return ops.gemm(cls, projT)                                         # x @ proj, 235-236
 
 
@@ -353,12 +365,12 @@ class CLIP(nn.Module):
         pos16 = self._cache.get("pos", self.positional_embedding, lambda t: t.half().contiguous())
         projT = self._cache.get("tprojT", self.text_projection, lambda t: t.t().contiguous())
         x = ops.text_embed(text, emb16, pos16)                                   # 342-344
-        x, d = _run_blocks(x, self.transformer.resblocks, B, L, self.transformer_heads, causal=True)   # 345-347
+        pick_eot = lambda t: ops.gather_eot(t, text, B, L, W)                    # x[arange, text.argmax(-1)], 350
+        x, d = _run_blocks(x, self.transformer.resblocks, B, L, self.transformer_heads, causal=True, select=pick_eot)   # 345-347
         if d is None:
-            x = ops.layernorm(x, self.ln_final.weight, self.ln_final.bias)       # 348
+            eot = ops.layernorm(x, self.ln_final.weight, self.ln_final.bias)     # 348 (row-wise: commutes with the gather)
         else:
-            x = ops.add_layernorm(x, d, self.ln_final.weight, self.ln_final.bias, update_x=False)
-        eot = ops.gather_eot(x, text, B, L, W)                                   # x[arange, text.argmax(-1)]
+            eot = ops.add_layernorm(x, d, self.ln_final.weight, self.ln_final.bias, update_x=False)
         return ops.gemm(eot, projT)                                              # @ text_projection, 352
 
     def forward(self, image, text):

@@ -127,6 +127,7 @@ def test_ood_performance(cfg, test_loader, clip_model=None, memory_bank_v_path=N
         from . import clip
         clip_model, _ = clip.load(cfg["backbone"])
     clip_model.eval()
+    os.makedirs(get_model_dir_root(cfg), exist_ok=True)                                               # feature cache directory
     test_features, test_labels = pre_load_features(cfg, "test", clip_model, test_loader)             # ood_utils.py:83
     with torch.no_grad():
         embeddings_v, embeddings_t, adapter = load_pretrained_mb_and_adapters(
