@@ -12,7 +12,7 @@ for m, n, k in shapes:
     if os.environ.get("DATA") == "zero": a.zero_(); w.zero_()
     if os.environ.get("DATA") == "small": a.mul_(1e-3); w.mul_(1e-3)
     bias = torch.randn(n, device="cuda").half(); out = torch.empty(m, n, device="cuda", dtype=torch.float16)
-    for name, f in {"plain": lambda: ops.gemm(a, w, None, 0, None, out), "bias+gelu": lambda: ops.gemm(a, w, bias, 1, None, out)}.items():
+    for name, f in {"plain": lambda: ops.gemm(a, w, None, 0, None, out), "bias": lambda: ops.gemm(a, w, bias, 0, None, out), "bias+gelu": lambda: ops.gemm(a, w, bias, 1, None, out)}.items():
         os.environ["PCLIP_GEMM_CFG"] = "1"; ref = f().clone()
         res = {c: [] for c in cfgs}
         for c in cfgs:
