@@ -62,3 +62,13 @@ def test_preprocess_feeds_the_encoder():
         f32 = model.encode_image(x32)
         f16 = model.encode_image(ClipPreprocess(n, out_dtype=torch.float16).batch(imgs))
     assert torch.equal(f32, f16)
+
+
+def test_preprocess_empty_batch_and_bad_input():
+    from proto_clip_amd._lib import PclipError
+    from proto_clip_amd.preprocess import ClipPreprocess, preprocess_batch
+    assert ClipPreprocess(32).batch([]).shape == (0, 3, 32, 32)
+    with pytest.raises(PclipError):
+        ClipPreprocess(32).batch([np.zeros((40, 40), dtype=np.uint8)])            # not HWC RGB
+    with pytest.raises(PclipError):
+        preprocess_batch([_img(40, 40, 1)], [(0, 0, 50, 40)], [(32, 32)], [(0, 0)], [False], 32)     # box outside the image

@@ -436,3 +436,39 @@ def test_qt_variant_trains_on_encoded_images(tmp_path, monkeypatch):
     d = f"{main_qt._main.get_model_dir_root(cfg)}/best-alpha-beta/{cfg['alpha']}-{cfg['beta']}"
     assert os.path.exists(f"{d}/best_lr_{cfg['lr']}_aug_{cfg['augment_epoch']}_epochs_{cfg['train_epoch']}_v.pt")
     assert out["zero_shot"]["val"][3 * 29, 0] == np.arange(0, 1.1, 0.1)[3]          # un-rounded alpha grid (0.30000000000000004)
+
+
+def test_one_shot_episode_and_feature_step_match_autograd():
+    """K = 1 (Caltech-101 1-shot, BASELINE configs[0] shapes): the sampler re-uses the single shot as the query (main.py:249-
+    250) and the prototype chain degenerates to a normalise of each row; also exercises step_features with explicit features
+    (the main.qt.py entry).  One step from identical state against the oracle's autograd."""
+    from proto_clip_amd import synth
+    from proto_clip_amd.main import make_adapter
+    from proto_clip_amd.train import ProtoClipTrainer, sample_epoch
+    N, K, D = 20, 1, 128
+    split = synth.make_split(N, K, D, 8, 8, seed=9, sigma=3.0)
+    cfg = dict(shots=K, lr=1e-3, train_epoch=1, adapter="conv-3x", train_vis_mem_only=False, losses=["L1", "L2", "L3", "L4"], alpha=0.3, beta=5.0)
+    torch.manual_seed(4)
+    ad = make_adapter(cfg, D)
+    sd = {k: v.detach().cpu().clone() for k, v in ad.state_dict().items()}
+    gpu = ProtoClipTrainer(cfg, split.visual_memory_keys.cuda(), split.textual_memory_bank.cuda(), ad, cfg["alpha"], cfg["beta"])
+    ref = to.Trainer(cfg, split.visual_memory_keys, split.textual_memory_bank, sd, cfg["alpha"], cfg["beta"])
+    eps = list(sample_epoch(N, K, np.random.RandomState(3)))
+    assert eps and all(len(qi) == len(cls) for cls, qi, _ in eps)           # one query per sampled class
+    _, qi, ql = eps[0]
+    feats = gpu.keys_rows[torch.as_tensor(qi, device="cuda")]
+    matches, loss, l1, l2, l3, l4i, l4t = gpu.step_features(feats, torch.as_tensor(ql))
+    m_ref, loss_ref, terms, grads = ref.step(qi, ql)
+    assert float(matches.item()) == m_ref
+    assert abs(loss.item() - loss_ref) <= 2e-5 * max(1.0, abs(loss_ref))
+    for got, key in ((l1, "L1"), (l2, "L2"), (l3, "L3"), (l4i, "L4i"), (l4t, "L4t")):
+        assert abs(got.item() - terms[key]) <= 2e-5 * max(1.0, abs(terms[key])), key
+    params = dict(gpu.adapter.named_parameters())
+    for name, g_ref in grads.items():
+        p = gpu.visual if name == "visual" else gpu.textual if name == "textual" else params[name]
+        got = gpu.last_grads.get(id(p))
+        if g_ref is None:
+            assert got is None, name
+        else:
+            tol = 2e-2 if name not in ("visual", "textual") else 3e-3
+            assert rel_l2(got.reshape(g_ref.shape), g_ref) <= tol, (name, rel_l2(got.reshape(g_ref.shape), g_ref))
