@@ -11,8 +11,20 @@ for name, N, K, D, Q in (("EuroSAT C2", 10, 16, 512, 8100), ("Caltech-101", 100,
     q = torch.nn.functional.normalize(torch.randn(Q, D, device="cuda"), dim=-1).half()
     zt = torch.nn.functional.normalize(torch.randn(N, D, device="cuda"), dim=-1).half()
     zi, zi_sq = ops.proto_build(mem, N, K, want_sq=True)
-    t_pb = timeit(lambda: ops.proto_build(mem, N, K), iters=50)
-    t_cl = timeit(lambda: ops.classify(q, zi, zt, 0.5, 12.0, want_p=False, want_argmax=True), iters=50)
+    def gpu_time(fn, reps=20):
+        """Device time per call: `reps` calls recorded into one hipGraph, so host launch overhead (~25 us per Python call) is out."""
+        fn(); torch.cuda.synchronize()
+        side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                fn()
+        return timeit(g.replay, iters=20) / reps
+    t_pb = gpu_time(lambda: ops.proto_build(mem, N, K))
+    t_cl = gpu_time(lambda: ops.classify(q, zi, zt, 0.5, 12.0, want_p=False, want_argmax=True))
     byts = Q * D * 2 + 2 * N * D * 2 + Q * 4
     print(f"{name:12s} N={N:4d} D={D:4d} Q={Q:5d}: proto_build {t_pb*1e6:6.1f} us | classify(argmax) {t_cl*1e6:7.1f} us "
           f"= {Q/t_cl/1e6:7.1f} M queries/s, {byts/t_cl/1e9:7.1f} GB/s of {byts/1e6:.2f} MB algorithmic", flush=True)
