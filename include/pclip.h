@@ -222,6 +222,11 @@ int pclip_nll_grad(const float* d2i, const float* d2t, const int32_t* labels, in
                    float one_minus_alpha, float beta, float* gi, float* gt, float* rowsum, float* nll, float* pmax,
                    int32_t* argmax, pclip_stream_t stream);
 
+/* The same per-query terms from a materialised p [Q, N] (leading dimension ldp): utils.compute_loss_and_matches as a
+ * forward-only drop-in (utils.py:84-93). */
+int pclip_nll_rows(const float* p, int ldp, const int32_t* labels, int Q, int N, float* nll, float* pmax, int32_t* argmax,
+                   pclip_stream_t stream);
+
 /* Cross entropy of the rows of S [R, C>=R] against the diagonal (InfoNCE of utils.py:72-77 with the info-nce-pytorch
  * defaults): loss[r] = logsumexp(S[r,:]) - S[r,r], dS[r,c] = scale * (softmax(S[r,:])[c] - [c == r]). */
 int pclip_softmax_ce_rows(const float* S, int lds, int R, int C, float scale, float* dS, int ldds, float* loss,

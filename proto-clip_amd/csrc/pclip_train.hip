@@ -161,6 +161,26 @@ __global__ __launch_bounds__(256) void nll_grad_kernel(const float* __restrict__
     }
 }
 
+// ---- utils.py:84-93 on a materialised p [Q, N]: pred_p, y_hat = p.max(1); nll[q] = -log p[q, y_q] ---------------------------
+__global__ __launch_bounds__(256) void nll_rows_kernel(const float* __restrict__ p, int ldp, const int32_t* __restrict__ labels, int Q,
+                                                       int N, float* __restrict__ nll, float* __restrict__ pmax,
+                                                       int32_t* __restrict__ argmax) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int q = blockIdx.x * 4 + wave; q < Q; q += gridDim.x * 4) {
+        const float* row = p + (size_t)q * ldp;
+        float best = -3.4e38f;
+        int bi = 0x7fffffff;
+        for (int c = lane; c < N; c += 64)
+            if (row[c] > best) { best = row[c]; bi = c; }
+        wave_argmax(best, bi);
+        if (lane == 0) {
+            nll[q] = -logf(row[labels[q]]);
+            pmax[q] = best;
+            argmax[q] = bi;
+        }
+    }
+}
+
 // ---- cross entropy against the diagonal (InfoNCE, info-nce-pytorch defaults): rows of S are logits -----------
 // loss[r] = logsumexp(S[r,:]) - S[r,r];  dS[r,c] = scale * (softmax(S[r,:])[c] - [c == r])
 __global__ __launch_bounds__(256) void softmax_ce_rows_kernel(const float* __restrict__ S, int lds, int R, int C, float scale,
@@ -432,6 +452,15 @@ extern "C" int pclip_nll_grad(const float* d2i, const float* d2t, const int32_t*
     nll_grad_kernel<<<row_grid(Q, 8192), 256, 0, (hipStream_t)stream>>>(d2i, d2t, labels, Q, q_total, N, ldd, alpha, one_minus_alpha, beta,
                                                                        gi, gt, rowsum, nll, pmax, argmax);
     return pclip_check_launch("nll_grad");
+}
+
+extern "C" int pclip_nll_rows(const float* p, int ldp, const int32_t* labels, int Q, int N, float* nll, float* pmax, int32_t* argmax,
+                              pclip_stream_t stream) {
+    PCLIP_REQUIRE(p && labels && nll && pmax && argmax, "pclip_nll_rows: null pointer");
+    PCLIP_REQUIRE(Q >= 0 && N > 0 && ldp >= N, "pclip_nll_rows: bad Q=%d N=%d ld=%d", Q, N, ldp);
+    if (Q == 0) return PCLIP_OK;
+    nll_rows_kernel<<<row_grid(Q, 8192), 256, 0, (hipStream_t)stream>>>(p, ldp, labels, Q, N, nll, pmax, argmax);
+    return pclip_check_launch("nll_rows");
 }
 
 extern "C" int pclip_softmax_ce_rows(const float* S, int lds, int R, int C, float scale, float* dS, int ldds, float* loss,

@@ -441,6 +441,19 @@ def nll_grad(d2i, d2t, labels, N: int, alpha: float, beta: float, q_total: int =
     return gi, gt, rs, nll, pmax, am
 
 
+def nll_rows(p: torch.Tensor, labels: torch.Tensor):
+    """(-log p[q, y_q], max_c p[q, c], argmax_c p[q, c]) per row of a materialised fp32 p [Q, N] (utils.py:84-93)."""
+    require_cuda(p, labels)
+    if p.dtype != torch.float32 or p.dim() != 2 or p.stride(1) != 1:
+        raise _lib.PclipError("nll_rows: p must be a row-major fp32 [Q, N] tensor")
+    Q, N = p.shape
+    nll, pmax = (torch.empty(Q, dtype=torch.float32, device=p.device) for _ in range(2))
+    am = torch.empty(Q, dtype=torch.int32, device=p.device)
+    lab = labels.to(torch.int32)
+    check(_lib.load().pclip_nll_rows(ptr(p), p.stride(0), ptr(lab), Q, N, ptr(nll), ptr(pmax), ptr(am), stream()), "pclip_nll_rows")
+    return nll, pmax, am
+
+
 def softmax_ce_rows(S: torch.Tensor, scale: float):
     """Rows of S as logits against the diagonal: (per-row loss, scale * (softmax - I))."""
     require_cuda(S)

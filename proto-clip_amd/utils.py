@@ -200,14 +200,13 @@ def compute_loss_and_matches(p, target_inds, z_img_proto, z_text_proto, cfg):
     require = p.dtype == torch.float32 and p.is_cuda
     if not require:
         raise PclipError("compute_loss_and_matches: p must be the fp32 CUDA tensor returned by P()")
-    pred_p, y_hat = p.max(dim=1)
-    matches = (y_hat == target_inds).float().sum()
+    nll, _, y_hat = ops.nll_rows(p, target_inds)
+    matches = (y_hat.long() == target_inds).float().sum()
     loss = torch.zeros((), dtype=torch.float32, device=p.device)
     img2txt = txt2img = img_inter = txt_inter = None
     losses = cfg["losses"]
     if len(losses) == 0 or "L1" in losses:
-        picked = p.gather(1, target_inds.view(-1, 1).long())
-        loss = loss + ops.colsum_f32((-torch.log(picked)).contiguous(), scale=1.0 / p.shape[0])[0]
+        loss = loss + ops.colsum_f32(nll.view(-1, 1), scale=1.0 / p.shape[0])[0]
     if "L2" in losses:
         img2txt = InfoNCELoss(z_img_proto, z_text_proto)
         loss = loss + img2txt

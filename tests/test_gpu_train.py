@@ -474,3 +474,25 @@ def test_one_shot_episode_and_feature_step_match_autograd():
         else:
             tol = 2e-2 if name not in ("visual", "textual") else 3e-3
             assert rel_l2(got.reshape(g_ref.shape), g_ref) <= tol, (name, rel_l2(got.reshape(g_ref.shape), g_ref))
+
+
+def test_compute_loss_and_matches_dropin():
+    """utils.compute_loss_and_matches / P on fp32 operands (the training-path call of main.py:281-285) against the oracle."""
+    from proto_clip_amd import utils as U
+    g = torch.Generator().manual_seed(2)
+    Q, N, D = 70, 23, 64
+    zq = F.normalize(torch.randn(Q, D, generator=g), dim=-1)
+    zi = F.normalize(torch.randn(N, D, generator=g), dim=-1)
+    zt = F.normalize(torch.randn(N, D, generator=g), dim=-1)
+    lab = torch.randint(0, N, (Q,), generator=g)
+    cfg = dict(losses=["L1", "L2", "L3", "L4"])
+    p = U.P(zq.cuda(), zi.cuda(), zt.cuda(), 0.3, 4.0)
+    out = U.compute_loss_and_matches(p, lab.cuda(), zi.cuda(), zt.cuda(), cfg)
+    p_ref = to.P(zq, zi, zt, 0.3, 4.0)
+    assert torch.allclose(p.cpu(), p_ref, rtol=1e-5, atol=1e-7)
+    ref = [F.nll_loss(torch.log(p_ref), lab), to.info_nce(zi, zt), to.info_nce(zt, zi), to.info_nce(zi, zi), to.info_nce(zt, zt)]
+    assert float(out[0].item()) == (p_ref.max(1)[1] == lab).float().sum().item()
+    assert abs(out[1].item() - sum(r.item() for r in ref)) <= 1e-4
+    assert out[2] is None
+    for got, r in zip(out[3:], ref[1:]):
+        assert abs(got.item() - r.item()) <= 2e-5
