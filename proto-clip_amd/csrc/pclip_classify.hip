@@ -3,6 +3,7 @@
 // 419-430).  Split in two stages so that the distance rows — which do not depend on alpha/beta
 //  — are produced once by the MFMA contraction and then consumed by cheap VALU passes.
 #include "pclip_gemm.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -28,32 +29,154 @@ __global__ __launch_bounds__(256, 2) void sqdist_kernel(const half_t* __restrict
     pgemm::mainloop<C>(q, D, bank ? zt : zi, D, Q, N, D, m0, n0, smem, acc, pbuf);
     const float* __restrict__ z_sq = bank ? zt_sq : zi_sq;
     float* __restrict__ out = bank ? d2t : d2i;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1, hi = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1, hi = lane >> 5;
+    // The fp32 tile (128 x 128 x 4 B = the whole 64 KiB of LDS, free after the K-loop) is staged so that the global stores
+    // are whole 512-byte row segments: from the MFMA layout a store instruction would touch 32 rows x 32 bytes.
+    // 16-byte units are XOR-swizzled with the row so that the 32 rows a wave writes at once land on different banks.
+    float* stg = reinterpret_cast<float*>(smem);
+    pgemm::lds_barrier();                                   // every wave is done reading the K-tiles
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wr * 64 + i * 32 + (lane & 31);
-        if (m >= Q) continue;
-        const float qs = q_sq[m];
+        const int ml = wr * 64 + i * 32 + (lane & 31);
+        const int m = m0 + ml;
+        const float qs = m < Q ? q_sq[m] : 0.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wc * 64 + j * 32 + 8 * g + 4 * hi;
+                const int nl = wc * 64 + j * 32 + 8 * g + 4 * hi;
                 float4_t o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float zs = n + e < N ? z_sq[n + e] : 0.f;
+                    const float zs = n0 + nl + e < N ? z_sq[n0 + nl + e] : 0.f;
                     const float v = __fadd_rn(__fadd_rn(-2.f * acc.v[i][j][4 * g + e], qs), zs);
                     const float d = sqrtf(fmaxf(v, 0.f));
                     o[e] = __fmul_rn(d, d);
                 }
-                float* dst = out + (size_t)m * ldd + n;
-                if (n + 3 < ldd) *reinterpret_cast<float4_t*>(dst) = o;      // columns in [N, ldd) are padding
-                else {
+                *reinterpret_cast<float4_t*>(stg + ml * 128 + (((nl >> 2) ^ (ml & 31)) << 2)) = o;
+            }
+    }
+    pgemm::lds_barrier();
+    const int u = tid & 31;                                 // 16-byte unit of the row: 32 units = 128 columns
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (n + e < ldd) dst[e] = o[e];
+    for (int ps = 0; ps < 16; ++ps) {
+        const int r = (tid >> 5) + ps * 8, m = m0 + r, n = n0 + 4 * u;
+        if (m >= Q) continue;
+        const float4_t o = *reinterpret_cast<const float4_t*>(stg + r * 128 + ((u ^ (r & 31)) << 2));
+        float* dst = out + (size_t)m * ldd + n;
+        if (n + 3 < ldd) *reinterpret_cast<float4_t*>(dst) = o;          // columns in [N, ldd) are padding
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (n + e < ldd) dst[e] = o[e];
+        }
+    }
+}
+
+// Large problems (ImageNet: 50 000 x 1000 x 512 per bank): the persistent 256x256 tile of the encoder GEMM — the 128x128
+// one-shot tiles above spend most of their 8 K-tiles waiting for LDS-DMA.  Tiles of both banks form one index space; the
+// fp32 result leaves through LDS in four 64-row slabs (64 x 256 x 4 B = one 64 KiB stage buffer) as whole 1 KiB row segments.
+__global__ __launch_bounds__(512, 2) void sqdist_big_kernel(const half_t* __restrict__ q, const half_t* __restrict__ zi,
+                                                            const half_t* __restrict__ zt, int Q, int N, int D,
+                                                            const float* __restrict__ q_sq, const float* __restrict__ zi_sq,
+                                                            const float* __restrict__ zt_sq, float* __restrict__ d2i,
+                                                            float* __restrict__ d2t, int ldd, int tiles_n, int tiles_per_bank,
+                                                            int ntiles) {
+    using C = pgemm::Cfg<256, 256, 2, 4>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int G = gridDim.x;
+    int tile = pgemm::xcd_remap(blockIdx.x, G);
+    if (tile >= ntiles) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / C::WN, wn = wave % C::WN, hi = lane >> 5;
+    int p = 0;
+    auto coords = [&](int t, int& bank, int& m0, int& n0) {
+        bank = t / tiles_per_bank;
+        const int r = t - bank * tiles_per_bank, tm = r / tiles_n;
+        m0 = tm * C::BM;
+        n0 = (r - tm * tiles_n) * C::BN;
+    };
+    {
+        int bank, m0, n0;
+        coords(tile, bank, m0, n0);
+        pgemm::stage_first<C>(q, D, bank ? zt : zi, D, Q, N, m0, n0, smem, p);
+    }
+    constexpr int NSTORE = 32;                                   // 16-byte stores per thread per tile: 4 slabs x 8 passes
+    // squared norms of the tile's 256 query rows / 256 prototypes travel by LDS-DMA too (an ordinary VGPR load beside the
+    // K-tile prefetch would make hipcc drain vmcnt(0) at its use); every wave copies both strips: uniform vmcnt bookkeeping.
+    // Q % 4 == 0 and N % 4 == 0 (checked by the launcher): a lane's four norms are all valid or all beyond the end (clamped).
+    float* norms = reinterpret_cast<float*>(smem + C::LDS_BYTES);          // [2][ q: 256 | z: 256 ]
+    bool prev_full = false;
+    int par = 0;
+    for (; tile < ntiles; tile += G, par ^= 1) {
+        int bank, m0, n0;
+        coords(tile, bank, m0, n0);
+        const half_t* z = bank ? zt : zi;
+        const float* __restrict__ z_sq = bank ? zt_sq : zi_sq;
+        float* __restrict__ out = bank ? d2t : d2i;
+        const bool full = m0 + C::BM <= Q && n0 + C::BN <= ldd;
+        float* qn = norms + par * 512;
+        float* zn = qn + 256;
+        {
+            int qi = m0 + 4 * lane, zi4 = n0 + 4 * lane;
+            qi = qi + 4 <= Q ? qi : Q - 4;
+            zi4 = zi4 + 4 <= N ? zi4 : N - 4;
+            __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(q_sq + qi), (pgemm::lds_ptr_t)qn, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(z_sq + zi4), (pgemm::lds_ptr_t)zn, 16, 0, 0);
+        }
+        pgemm::Acc<C> acc;
+        pgemm::mainloop<C, NSTORE + 2>(q, D, z, D, Q, N, D, m0, n0, smem, acc, p, prev_full);
+        pgemm::wait_vm<0>();
+        const int next = tile + G;
+        if (next < ntiles) {
+            int nb, nm0, nn0;
+            coords(next, nb, nm0, nn0);
+            pgemm::stage_first<C>(q, D, nb ? zt : zi, D, Q, N, nm0, nn0, smem, p);
+        }
+        float* stg = reinterpret_cast<float*>(smem + (p ^ 1) * C::STAGE_BYTES);
+        // wave (wm, wn) owns rows wm*128 + i*32 + (lane&31), i < 4: slab h (64 rows) = row tiles i = 2*(h&1), 2*(h&1)+1 of wm = h>>1
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            pgemm::lds_barrier();
+            if (wm == (h >> 1)) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int i = 2 * (h & 1) + ii;
+                    const int ml = ii * 32 + (lane & 31);          // row inside the slab
+                    const float qs = qn[h * 64 + ml];
+#pragma unroll
+                    for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int nl = wn * (C::BN / C::WN) + j * 32 + 8 * g + 4 * hi;
+                            float4_t o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float zs = zn[nl + e];
+                                const float v = __fadd_rn(__fadd_rn(-2.f * acc.v[i][j][4 * g + e], qs), zs);
+                                const float d = sqrtf(fmaxf(v, 0.f));
+                                o[e] = __fmul_rn(d, d);
+                            }
+                            *reinterpret_cast<float4_t*>(stg + ml * 256 + (((nl >> 2) ^ (ml & 63)) << 2)) = o;
+                        }
                 }
             }
+            pgemm::lds_barrier();
+            const int u = tid & 63;                              // 16-byte unit of the 1 KiB row: 64 units = 256 columns
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) {
+                const int r = (tid >> 6) + ps * 8, m = m0 + h * 64 + r, n = n0 + 4 * u;
+                const float4_t o = *reinterpret_cast<const float4_t*>(stg + r * 256 + ((u ^ (r & 63)) << 2));
+                if (full) *reinterpret_cast<float4_t*>(out + (size_t)m * ldd + n) = o;
+                else if (m < Q) {
+                    float* dst = out + (size_t)m * ldd + n;
+                    if (n + 3 < ldd) *reinterpret_cast<float4_t*>(dst) = o;
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (n + e < ldd) dst[e] = o[e];
+                    }
+                }
+            }
+        }
+        prev_full = full;
     }
 }
 
@@ -309,6 +432,31 @@ extern "C" int pclip_sqdist_f16(const void* q, const void* zi, const void* zt, i
         if (!q_sq) { if ((e = pclip_row_sqnorm_f16(q, Q, D, w.q_sq, stream))) return e; q_sq = w.q_sq; }
         if (!zi_sq) { if ((e = pclip_row_sqnorm_f16(zi, N, D, w.zi_sq, stream))) return e; zi_sq = w.zi_sq; }
         if (zt && !zt_sq) { if ((e = pclip_row_sqnorm_f16(zt, N, D, w.zt_sq, stream))) return e; zt_sq = w.zt_sq; }
+    }
+    {   // enough 256x256 tiles to fill the chip a few times over: persistent big-tile kernel
+        using CB = pgemm::Cfg<256, 256, 2, 4>;
+        const int tm = ceil_div(Q, CB::BM), tn = ceil_div(N, CB::BN), per_bank = tm * tn, ntiles = per_bank * (zt ? 2 : 1);
+        static int cus = 0;
+        static int big_ok = -1;
+        if (!cus) {
+            cus = pclip_device_cus();
+            if (cus <= 0) cus = 256;
+            const char* e = getenv("PCLIP_SQDIST_BIG");
+            big_ok = e ? atoi(e) : 1;
+        }
+        if (big_ok && ntiles >= 3 * cus && D >= 128 && Q % 4 == 0 && N % 4 == 0 && Q >= 4 && N >= 4) {
+            static bool attr = false;
+            if (!attr) {
+                if (hipFuncSetAttribute((const void*)sqdist_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CB::LDS_BYTES + 4096) != hipSuccess) {
+                    pclip_set_error("pclip_sqdist_f16: cannot raise the dynamic LDS limit to %d", CB::LDS_BYTES + 4096);
+                    return PCLIP_E_LAUNCH;
+                }
+                attr = true;
+            }
+            sqdist_big_kernel<<<ntiles < cus ? ntiles : cus, 512, CB::LDS_BYTES + 4096, s>>>((const half_t*)q, (const half_t*)zi, (const half_t*)zt, Q, N, D,
+                                                                                    q_sq, zi_sq, zt_sq, d2i, d2t, ldd, tn, per_bank, ntiles);
+            return pclip_check_launch("sqdist (big tile)");
+        }
     }
     const int tiles_m = ceil_div(Q, pgemm::CfgSmall::BM), tiles_n = ceil_div(N, pgemm::CfgSmall::BN);
     dim3 grid(tiles_m * tiles_n, zt ? 2 : 1);

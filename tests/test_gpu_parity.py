@@ -327,3 +327,22 @@ def test_full_size_properties_C3(ops):
     _, am1, _, _ = ops.fuse_probs(d2i, None, 1000, 1.0, 12.0, want_p=False, want_argmax=True)
     assert cnt[2, 1].item() == (am1.long().cpu() == split.test_labels).sum().item()
     assert acc_lo < cnt[1, 1].item() / 50000 < acc_hi, cnt
+
+
+def test_sqdist_big_tile_path_matches_small_tile_path_and_oracle():
+    """Problems with >= 3 x #CU tiles of 256x256 (ImageNet-sized grids) run the persistent big-tile kernel; a row subset of
+    the same problem runs the one-shot 128x128 kernel.  Same MFMA k-order -> the distances must agree bit for bit; a sample is
+    also checked against the oracle.  Q is a multiple of 4 but not of 256 (ragged last tile), N = 1000 (ragged last column tile)."""
+    from proto_clip_amd import ops
+    Q, N, D = 25004, 1000, 128
+    g = torch.Generator(device="cuda").manual_seed(12)
+    q = torch.nn.functional.normalize(torch.randn(Q, D, device="cuda", generator=g), dim=-1).half()
+    zi = torch.nn.functional.normalize(torch.randn(N, D, device="cuda", generator=g), dim=-1).half()
+    zt = (torch.nn.functional.normalize(torch.randn(N, D, device="cuda", generator=g), dim=-1) * 1.2).half()
+    d2i, d2t, ldd = ops.sqdist(q, zi, zt)
+    for lo, hi in ((0, 700), (12345, 12345 + 513), (Q - 300, Q)):
+        si, st, _ = ops.sqdist(q[lo:hi].contiguous(), zi, zt)
+        assert torch.equal(d2i[lo:hi, :N], si[:, :N]) and torch.equal(d2t[lo:hi, :N], st[:, :N]), (lo, hi)
+    ref_i, ref_t = po.sqdist(q[Q - 64:].cpu(), zi.cpu()), po.sqdist(q[Q - 64:].cpu(), zt.cpu())
+    torch.testing.assert_close(d2i[Q - 64:, :N].cpu(), ref_i, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(d2t[Q - 64:, :N].cpu(), ref_t, rtol=1e-5, atol=2e-5)
