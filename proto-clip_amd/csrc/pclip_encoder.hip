@@ -48,11 +48,24 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     int tile = pgemm::xcd_remap(blockIdx.x, G);
     if (tile >= ntiles) return;
     int p = 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave % C::WN, hi = lane >> 5;
+    // The bias enters as the INITIAL VALUE of the accumulators (fp32 copy of the fp16 bias: r16(bias + sum) instead of
+    // r16(sum + bias), same value up to fp32 summation order), so the epilogue has no bias pass.  Its strip is copied one
+    // tile ahead (double-buffered); every wave copies the same BN values: uniform vmcnt bookkeeping.
+    auto copy_bias = [&](int t, int par) {
+        const int tn = t - (t / tiles_n) * tiles_n;
+        if (lane < C::BN / 8)
+            __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(bias + tn * C::BN + lane * 8), (pgemm::lds_ptr_t)(bias_lds + par * C::BN), 16, 0, 0);
+    };
+    if (HAS_BIAS) {
+        copy_bias(tile, 0);
+        pgemm::wait_vm<0>();
+        pgemm::lds_barrier();
+    }
     {
         const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
         pgemm::stage_first<C>(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, smem, p);
     }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave % C::WN, hi = lane >> 5;
     constexpr int YOUNGER = C::NH * C::NPASS + (HAS_BIAS ? 1 : 0);
     bool prev_full = false;
     int parity = 0;
@@ -60,12 +73,23 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
         const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
         const bool full = m0 + C::BM <= M;                    // workgroup-uniform: every row of the tile exists
-        half_t* bl = bias_lds + parity * C::BN;
-        if (HAS_BIAS && lane < C::BN / 8)                     // every wave copies the same BN biases: uniform vmcnt bookkeeping
-            __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(bias + n0 + lane * 8), (pgemm::lds_ptr_t)bl, 16, 0, 0);
         pgemm::Acc<C> acc;
-        pgemm::mainloop<C, YOUNGER>(A, lda, B, ldb, M, N, K, m0, n0, smem, acc, p, prev_full);
-        pgemm::wait_vm<0>();                                  // free unless K == 64: the bias strip has landed
+        if (HAS_BIAS) {
+            const half_t* bl = bias_lds + parity * C::BN + wn * (C::BN / C::WN) + 4 * hi;
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const half4_t b = *reinterpret_cast<const half4_t*>(bl + j * 32 + 8 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < C::TM; ++i) acc.v[i][j][4 * g + e] = (float)b[e];
+                }
+            // next tile's strip (the last tile re-copies its own: the count of younger operations stays the same)
+            copy_bias(tile + G < ntiles ? tile + G : tile, parity ^ 1);
+        }
+        pgemm::mainloop<C, YOUNGER, !HAS_BIAS>(A, lda, B, ldb, M, N, K, m0, n0, smem, acc, p, prev_full);
         const int next = tile + G;
         if (next < ntiles) {                                  // buffer p is free: prefetch the next tile's K-tile 0
             const int tm = next / tiles_n, tn = next - tm * tiles_n;
@@ -73,12 +97,11 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         }
         char* stg = smem + (p ^ 1) * C::STAGE_BYTES;          // buffer of the last K-tile, reused after a barrier
         const int col = n0 + 8 * (tid % C::CPR);
-        auto pre = [&](int, int j, int g, float4_t v) {
-            half4_t h, b = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-            if (HAS_BIAS) b = *reinterpret_cast<const half4_t*>(bl + wn * (C::BN / C::WN) + j * 32 + 8 * g + 4 * hi);
+        auto pre = [&](int, int, int, float4_t v) {
+            half4_t h;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float x = r16(v[e] + (float)b[e]);
+                float x = r16(v[e]);
                 if (ACT == 1) x = quick_gelu16(x);
                 h[e] = (half_t)x;
             }

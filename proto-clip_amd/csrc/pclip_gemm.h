@@ -114,19 +114,21 @@ __device__ __forceinline__ void stage_first(const half_t* __restrict__ A, int ld
 // YOUNGER = number of vector-memory operations this wave issued AFTER the K-tile-0 staging and that may stay
 // in flight across the first barrier (epilogue stores of the previous tile, bias loads): the first wait is
 // vmcnt(YOUNGER) instead of a full drain.
-template <class C, int YOUNGER = 0>
+template <class C, int YOUNGER = 0, bool ZERO_ACC = true>
 __device__ __forceinline__ void mainloop(const half_t* __restrict__ A, int lda, const half_t* __restrict__ B, int ldb,
                                          int M, int N, int K, int m0, int n0, char* smem, Acc<C>& acc, int& p,
                                          bool counted_first = false) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / C::WN, wn = wave % C::WN;
     const int nt = K / BK;
+    if (ZERO_ACC) {                                        // otherwise the caller pre-loaded the accumulators (e.g. with the bias)
 #pragma unroll
-    for (int i = 0; i < C::TM; ++i)
+        for (int i = 0; i < C::TM; ++i)
 #pragma unroll
-        for (int j = 0; j < C::TN; ++j)
+            for (int j = 0; j < C::TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc.v[i][j][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc.v[i][j][e] = 0.f;
+    }
 
     for (int t = 0; t < nt; ++t) {
         // this wave's share of K-tile t has landed; the barrier then publishes every wave's share
