@@ -27,6 +27,23 @@ __device__ __forceinline__ float quick_gelu16(float v) {
     return r16(v * s);
 }
 
+// Four at a time with packed fp16 instructions where the arithmetic IS fp16: the two conversions are v_cvt_pk_f16_f32 and the
+// final product h * s of two fp16 values is one correctly rounded v_pk_mul_f16 (= r16 of the exact fp32 product).
+typedef float float2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ half4_t quick_gelu16x4(float4_t v) {
+    const half2_t h01 = __builtin_convertvector(float2_t{v[0], v[1]}, half2_t), h23 = __builtin_convertvector(float2_t{v[2], v[3]}, half2_t);
+    const half_t h[4] = {h01[0], h01[1], h23[0], h23[1]};
+    float s[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float t = r16(1.702f * (float)h[e]);
+        s[e] = __builtin_amdgcn_rcpf(1.f + __expf(-t));
+    }
+    const half2_t s01 = __builtin_convertvector(float2_t{s[0], s[1]}, half2_t), s23 = __builtin_convertvector(float2_t{s[2], s[3]}, half2_t);
+    const half2_t y01 = h01 * s01, y23 = h23 * s23;
+    return half4_t{y01[0], y01[1], y23[0], y23[1]};
+}
+
 // ---- fast kernel: N % BN == 0, 16-byte aligned C rows, no residual -----------------------------------------
 // Persistent: one launch = at most `slots` resident workgroups; each walks output tiles round by round
 // (round r covers tiles [r*G, (r+1)*G), XCD-remapped inside the round so that one XCD's L2 sees
@@ -98,13 +115,10 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         char* stg = smem + (p ^ 1) * C::STAGE_BYTES;          // buffer of the last K-tile, reused after a barrier
         const int col = n0 + 8 * (tid % C::CPR);
         auto pre = [&](int, int, int, float4_t v) {
+            if (ACT == 1) return quick_gelu16x4(v);
             half4_t h;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = r16(v[e]);
-                if (ACT == 1) x = quick_gelu16(x);
-                h[e] = (half_t)x;
-            }
+            for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
             return h;
         };
         if (full)
