@@ -141,6 +141,12 @@ int pclip_adapter_conv_f16(const void* x, int B, int D, int three_x, const void*
 int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                    const void* bias, int act, const void* residual, pclip_stream_t stream);
 
+/* Convolution-as-GEMM with the eval-mode BatchNorm (+ReLU) that follows it in the ModifiedResNet tower (clip/model.py:43-52,
+ * 138-142): C = relu?( r16( r16(A B^T) * scale[n] + shift[n] ) ), scale/shift fp32 [N] = the folded running statistics and
+ * affine.  Same rounding points as conv (fp16 tensor) followed by pclip_bn_act_f16. */
+int pclip_gemm_bn_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                      const float* scale, const float* shift, int relu, pclip_stream_t stream);
+
 /* LayerNorm over the last dim with fp32 statistics and fp32 affine parameters, fp16 in/out
  * (clip/model.py:155-161).  x rows are ld_x elements apart (lets ln_post read only the CLS rows). */
 int pclip_layernorm_f16(const void* x, int ld_x, const float* gamma, const float* beta, float eps, void* y,

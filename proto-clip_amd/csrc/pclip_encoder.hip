@@ -16,7 +16,9 @@ struct LinearEpi {
     const half_t* __restrict__ residual;
     half_t* __restrict__ C;
     int ldc;
-    int act;
+    int act;                          // 0 none, 1 QuickGELU, 2 per-column affine (eval BatchNorm), 3 affine + ReLU
+    const float* __restrict__ scale;  // act >= 2: y = r16(r16(acc) * scale[n] + shift[n])
+    const float* __restrict__ shift;
 };
 
 // QuickGELU with the reference's three fp16 roundings.  exp / reciprocal use the hardware approximations
@@ -57,10 +59,14 @@ template <class C, bool HAS_BIAS, int ACT>
 __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_t* __restrict__ A, int lda,
                                                                      const half_t* __restrict__ B, int ldb, int M, int N,
                                                                      int K, const half_t* __restrict__ bias,
+                                                                     const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift,
                                                                      half_t* __restrict__ Cout, int ldc, int tiles_n,
                                                                      int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* bias_lds = reinterpret_cast<half_t*>(smem + C::LDS_BYTES);       // [2][BN] fp16
+    float* affine_lds = reinterpret_cast<float*>(smem + C::LDS_BYTES);       // ACT >= 2: [2][ scale BN | shift BN ] fp32
+    constexpr bool AFFINE = ACT >= 2;
     const int G = gridDim.x;
     int tile = pgemm::xcd_remap(blockIdx.x, G);
     if (tile >= ntiles) return;
@@ -74,8 +80,17 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         if (lane < C::BN / 8)
             __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(bias + tn * C::BN + lane * 8), (pgemm::lds_ptr_t)(bias_lds + par * C::BN), 16, 0, 0);
     };
-    if (HAS_BIAS) {
-        copy_bias(tile, 0);
+    // eval-mode BatchNorm (+ReLU) of the ResNet tower (clip/model.py:43-52) as the epilogue of the convolution's GEMM: the
+    // per-column scale / shift strips travel like the bias strip, one tile ahead
+    auto copy_affine = [&](int t, int par) {
+        const int tn = t - (t / tiles_n) * tiles_n;
+        if (lane < C::BN / 4) {
+            __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(scale + tn * C::BN + lane * 4), (pgemm::lds_ptr_t)(affine_lds + par * 2 * C::BN), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(shift + tn * C::BN + lane * 4), (pgemm::lds_ptr_t)(affine_lds + par * 2 * C::BN + C::BN), 16, 0, 0);
+        }
+    };
+    if (HAS_BIAS || AFFINE) {
+        if (AFFINE) copy_affine(tile, 0); else copy_bias(tile, 0);
         pgemm::wait_vm<0>();
         pgemm::lds_barrier();
     }
@@ -83,7 +98,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
         pgemm::stage_first<C>(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, smem, p);
     }
-    constexpr int YOUNGER = C::NH * C::NPASS + (HAS_BIAS ? 1 : 0);
+    constexpr int YOUNGER = C::NH * C::NPASS + (AFFINE ? 2 : (HAS_BIAS ? 1 : 0));
     bool prev_full = false;
     int parity = 0;
     for (; tile < ntiles; tile += G, parity ^= 1) {
@@ -106,6 +121,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             // next tile's strip (the last tile re-copies its own: the count of younger operations stays the same)
             copy_bias(tile + G < ntiles ? tile + G : tile, parity ^ 1);
         }
+        if (AFFINE) copy_affine(tile + G < ntiles ? tile + G : tile, parity ^ 1);
         pgemm::mainloop<C, YOUNGER, !HAS_BIAS>(A, lda, B, ldb, M, N, K, m0, n0, smem, acc, p, prev_full);
         const int next = tile + G;
         if (next < ntiles) {                                  // buffer p is free: prefetch the next tile's K-tile 0
@@ -114,9 +130,20 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         }
         char* stg = smem + (p ^ 1) * C::STAGE_BYTES;          // buffer of the last K-tile, reused after a barrier
         const int col = n0 + 8 * (tid % C::CPR);
-        auto pre = [&](int, int, int, float4_t v) {
+        auto pre = [&](int, int j, int g, float4_t v) {
             if (ACT == 1) return quick_gelu16x4(v);
             half4_t h;
+            if (AFFINE) {
+                const float* st = affine_lds + parity * 2 * C::BN + wn * (C::BN / C::WN) + j * 32 + 8 * g + 4 * hi;
+                const float4_t sc = *reinterpret_cast<const float4_t*>(st), sh = *reinterpret_cast<const float4_t*>(st + C::BN);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float y = r16(r16(v[e]) * sc[e] + sh[e]);              // bn(conv(x)): the conv output is an fp16 tensor
+                    if (ACT == 3) y = fmaxf(y, 0.f);
+                    h[e] = (half_t)y;
+                }
+                return h;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
             return h;
@@ -161,6 +188,11 @@ __global__ __launch_bounds__(256, 2) void linear_generic_kernel(const half_t* __
                 if (bias) x += (float)bias[n + e < N ? n + e : N - 1];
                 x = r16(x);
                 if (act == 1) x = quick_gelu16(x);
+                if (act >= 2) {
+                    const int nn = n + e < N ? n + e : N - 1;
+                    x = r16(x * epi.scale[nn] + epi.shift[nn]);
+                    if (act == 3) x = fmaxf(x, 0.f);
+                }
                 h[e] = (half_t)x;
             }
             return h;
@@ -179,13 +211,14 @@ __global__ __launch_bounds__(256, 2) void linear_generic_kernel(const half_t* __
 
 using CfgBig = pgemm::Cfg<256, 256, 2, 4>;
 using CfgWide = pgemm::Cfg<256, 128, 4, 2>;
+using CfgNarrow = pgemm::Cfg<256, 64, 4, 2>;          // 64-channel convolutions of the ResNet tower
 using CfgSmall = pgemm::CfgSmall;
 
 template <class C, bool HAS_BIAS, int ACT>
 static int launch_fast2(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const LinearEpi& epi,
                         int slots, hipStream_t s) {
     static bool attr = false;
-    constexpr int LDS = C::LDS_BYTES + 2 * C::BN * 2;          // K-tile ring + double-buffered bias strip
+    constexpr int LDS = C::LDS_BYTES + (ACT >= 2 ? 2 * 2 * C::BN * 4 : 2 * C::BN * 2);   // K-tile ring + double-buffered bias / affine strips
     if (!attr) {
         if (hipFuncSetAttribute((const void*)linear_fast_kernel<C, HAS_BIAS, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS) != hipSuccess) {
@@ -197,13 +230,15 @@ static int launch_fast2(const void* A, int lda, const void* B, int ldb, int M, i
     const int tiles_m = ceil_div(M, C::BM), tiles_n = N / C::BN, ntiles = tiles_m * tiles_n;
     const int grid = ntiles < slots ? ntiles : slots;
     linear_fast_kernel<C, HAS_BIAS, ACT><<<grid, C::NTHREADS, LDS, s>>>(
-        (const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi.bias, epi.C, epi.ldc, tiles_n, ntiles);
+        (const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi.bias, epi.scale, epi.shift, epi.C, epi.ldc, tiles_n, ntiles);
     return pclip_check_launch("gemm_f16");
 }
 
 template <class C>
 static int launch_fast(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const LinearEpi& epi,
                        int slots, hipStream_t s) {
+    if (epi.act == 2) return launch_fast2<C, false, 2>(A, lda, B, ldb, M, N, K, epi, slots, s);
+    if (epi.act == 3) return launch_fast2<C, false, 3>(A, lda, B, ldb, M, N, K, epi, slots, s);
     if (epi.bias) {
         if (epi.act == 1) return launch_fast2<C, true, 1>(A, lda, B, ldb, M, N, K, epi, slots, s);
         return launch_fast2<C, true, 0>(A, lda, B, ldb, M, N, K, epi, slots, s);
@@ -605,7 +640,8 @@ extern "C" long pclip_gemm_kernel_launches(void) { return g_gemm_launches; }
 
 namespace {
 struct TileCfg { int bm, bn, wg_per_cu; double eff; };
-constexpr TileCfg kTileCfgs[3] = {{128, 128, 2, 0.85}, {256, 128, 1, 0.85}, {256, 256, 1, 1.0}};
+constexpr int kNumCfgs = 4;
+constexpr TileCfg kTileCfgs[kNumCfgs] = {{128, 128, 2, 0.85}, {256, 128, 1, 0.85}, {256, 256, 1, 1.0}, {256, 64, 1, 0.6}};
 constexpr double kLaunchCost = 0.5;          // extra launch of a split, in the same units
 
 inline double tile_cost(const TileCfg& c, long M, int N, int cus) {
@@ -616,7 +652,7 @@ inline double tile_cost(const TileCfg& c, long M, int N, int cus) {
 inline int best_cfg(long M, int N, int cus, double* cost_out) {
     int pick = -1;
     double best = 1e29;
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < kNumCfgs; ++i) {
         const double c = tile_cost(kTileCfgs[i], M, N, cus);
         if (c < best) { best = c; pick = i; }
     }
@@ -629,15 +665,15 @@ int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int
     const bool aligned = !epi.residual && epi.ldc % 8 == 0 && ((uintptr_t)epi.C & 15) == 0 && (!epi.bias || ((uintptr_t)epi.bias & 15) == 0);
     double cost = 1e30;
     int pick = aligned ? best_cfg(M, N, cus, &cost) : -1;
+    if (forced == -2) { may_split = false; pick = -1; }        // generic kernel
     if (forced >= 0) {
         may_split = false;
-        if (forced == 3) pick = -1;
-        else if (aligned && forced < 3 && N % kTileCfgs[forced].bn == 0) pick = forced;
+        if (aligned && forced < kNumCfgs && N % kTileCfgs[forced].bn == 0) pick = forced;
     }
     if (pick >= 0 && may_split) {
         long split_rows = 0;                                   // rows given to the full rounds of configuration split_cfg
         int split_cfg = -1;
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < kNumCfgs; ++i) {
             const TileCfg& c = kTileCfgs[i];
             if (N % c.bn) continue;
             const long slots = (long)c.wg_per_cu * cus, tiles_n = N / c.bn, nt = ((M + c.bm - 1) / c.bm) * tiles_n;
@@ -660,6 +696,7 @@ int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int
     if (pick == 2) return launch_fast<CfgBig>(A, lda, B, ldb, M, N, K, epi, cus, s);
     if (pick == 1) return launch_fast<CfgWide>(A, lda, B, ldb, M, N, K, epi, cus, s);
     if (pick == 0) return launch_fast<CfgSmall>(A, lda, B, ldb, M, N, K, epi, 2 * cus, s);
+    if (pick == 3) return launch_fast<CfgNarrow>(A, lda, B, ldb, M, N, K, epi, cus, s);
     const int tiles_m = ceil_div(M, 128), tiles_n = ceil_div(N, 128);
     linear_generic_kernel<<<tiles_m * tiles_n, 256, CfgSmall::LDS_BYTES, s>>>(A, lda, B, ldb, M, N, K, epi, tiles_n);
     return pclip_check_launch("gemm_f16 (generic)");
@@ -674,19 +711,35 @@ extern "C" int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, vo
     PCLIP_REQUIRE(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0, "pclip_gemm_f16: bad leading dims");
     PCLIP_REQUIRE(act == 0 || act == 1, "pclip_gemm_f16: unknown activation %d", act);
     if (M == 0) return PCLIP_OK;
-    LinearEpi epi{(const half_t*)bias, (const half_t*)residual, (half_t*)C, ldc, act};
+    LinearEpi epi{(const half_t*)bias, (const half_t*)residual, (half_t*)C, ldc, act, nullptr, nullptr};
     static int cus = 0;
     static int forced = -1;
     static bool live = false, nosplit = false;
     if (!cus || live) {
         cus = pclip_device_cus();
         if (cus <= 0) cus = 256;
-        const char* f = getenv("PCLIP_GEMM_CFG");          // tuning override: 0 small, 1 wide, 2 big, 3 generic
+        const char* f = getenv("PCLIP_GEMM_CFG");          // tuning override: 0 small, 1 wide, 2 big, 3 generic, 4 narrow (256x64)
         forced = f ? atoi(f) : -1;
+        if (forced == 3) forced = -2;                       // generic kernel
+        else if (forced == 4) forced = 3;                   // index of the 256x64 configuration
         live = getenv("PCLIP_GEMM_CFG_LIVE") != nullptr;   // tools/ab_cfg.py: re-read the overrides on every call
         nosplit = getenv("PCLIP_GEMM_NOSPLIT") != nullptr;
     }
     return gemm_dispatch((const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, cus, forced, !nosplit, (hipStream_t)stream);
+}
+
+extern "C" int pclip_gemm_bn_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                                 const float* scale, const float* shift, int relu, pclip_stream_t stream) {
+    PCLIP_REQUIRE(A && B && C && scale && shift, "pclip_gemm_bn_f16: null pointer");
+    PCLIP_REQUIRE(M >= 0 && N > 0 && K > 0, "pclip_gemm_bn_f16: bad shape M=%d N=%d K=%d", M, N, K);
+    PCLIP_REQUIRE(K % pgemm::BK == 0, "pclip_gemm_bn_f16: K=%d must be a multiple of %d", K, pgemm::BK);
+    PCLIP_REQUIRE(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0, "pclip_gemm_bn_f16: bad leading dims");
+    if (M == 0) return PCLIP_OK;
+    LinearEpi epi{nullptr, nullptr, (half_t*)C, ldc, relu ? 3 : 2, scale, shift};
+    int cus = pclip_device_cus();
+    if (cus <= 0) cus = 256;
+    const bool strips_ok = N % 4 == 0 && ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0;
+    return gemm_dispatch((const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, cus, strips_ok ? -1 : -2, true, (hipStream_t)stream);
 }
 
 #define DISPATCH_NCH(D, CALL)                                  \

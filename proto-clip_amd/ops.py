@@ -252,6 +252,20 @@ def gemm(a, w, bias=None, act: int = 0, residual=None, out=None):
     return out
 
 
+def gemm_bn(a, w, scale, shift, relu: bool = True, out=None):
+    """relu?(bn(a @ w.T)) with eval-mode BatchNorm folded to fp32 per-column scale / shift — conv + bn (+ relu) of the ResNet
+    tower in one launch (clip/model.py:43-52)."""
+    require_cuda(a, w, scale, shift)
+    a, w = _f16c(a), _f16c(w)
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float16, device=a.device)
+    check(_lib.load().pclip_gemm_bn_f16(ptr(a), K, ptr(w), w.shape[1], ptr(out), N, M, N, K, ptr(scale), ptr(shift), int(relu),
+                                        stream()), "pclip_gemm_bn_f16")
+    return out
+
+
 def layernorm(x, gamma, beta, eps: float = 1e-5, out=None, rows: int = None, ld: int = None):
     """fp16 in/out LayerNorm with fp32 statistics and fp32 affine (clip/model.py:155-161)."""
     require_cuda(x, gamma, beta)

@@ -331,3 +331,17 @@ def test_resnet_tower_against_reference(ops, tag):
     assert rel_err(f, clip_oracle.encode_image_resnet(sd, imgs, half=True)) <= 5e-3
     model.visual.chunk = 4                                 # chunked path == single pass
     assert torch.equal(model.encode_image(imgs.cuda()).cpu(), f.cpu())
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(5000, 64, 576, True), (3136 * 4, 64, 64, True), (2000, 32, 64, True), (4096, 256, 64, False),
+                                        (70000, 128, 1152, True), (777, 2048, 512, True), (50432, 512, 128, False)])
+def test_gemm_bn_equals_gemm_then_bn_act(ops, M, N, K, relu):
+    """conv + eval BatchNorm (+ ReLU) as one GEMM launch (scale / shift strips in the epilogue; 256x64 tiles for 64-channel
+    convolutions, the generic kernel for 32) must reproduce conv-GEMM followed by pclip_bn_act_f16 bit for bit."""
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    a = (torch.randn(M, K, device="cuda", generator=g) * 0.5).half()
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).half()
+    ss = torch.stack([1 + 0.3 * torch.randn(N, device="cuda", generator=g), 0.2 * torch.randn(N, device="cuda", generator=g)]).contiguous()
+    ref = ops.bn_act(ops.gemm(a, w), ss[0], ss[1], relu=relu)
+    got = ops.gemm_bn(a, w, ss[0], ss[1], relu=relu)
+    assert torch.equal(got, ref)
