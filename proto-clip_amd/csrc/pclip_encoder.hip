@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256, 2) void linear_generic_kernel(const half_t* __
 using CfgBig = pgemm::Cfg<256, 256, 2, 4>;
 using CfgWide = pgemm::Cfg<256, 128, 4, 2>;
 using CfgNarrow = pgemm::Cfg<256, 64, 4, 2>;          // 64-channel convolutions of the ResNet tower
+using CfgThin = pgemm::Cfg<256, 32, 4, 1>;            // its 32-channel stem (4 waves, two workgroups per CU)
 using CfgSmall = pgemm::CfgSmall;
 
 template <class C, bool HAS_BIAS, int ACT>
@@ -640,8 +641,8 @@ extern "C" long pclip_gemm_kernel_launches(void) { return g_gemm_launches; }
 
 namespace {
 struct TileCfg { int bm, bn, wg_per_cu; double eff; };
-constexpr int kNumCfgs = 4;
-constexpr TileCfg kTileCfgs[kNumCfgs] = {{128, 128, 2, 0.85}, {256, 128, 1, 0.85}, {256, 256, 1, 1.0}, {256, 64, 1, 0.6}};
+constexpr int kNumCfgs = 5;
+constexpr TileCfg kTileCfgs[kNumCfgs] = {{128, 128, 2, 0.85}, {256, 128, 1, 0.85}, {256, 256, 1, 1.0}, {256, 64, 1, 0.6}, {256, 32, 2, 0.4}};
 constexpr double kLaunchCost = 0.5;          // extra launch of a split, in the same units
 
 inline double tile_cost(const TileCfg& c, long M, int N, int cus) {
@@ -697,6 +698,7 @@ int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int
     if (pick == 1) return launch_fast<CfgWide>(A, lda, B, ldb, M, N, K, epi, cus, s);
     if (pick == 0) return launch_fast<CfgSmall>(A, lda, B, ldb, M, N, K, epi, 2 * cus, s);
     if (pick == 3) return launch_fast<CfgNarrow>(A, lda, B, ldb, M, N, K, epi, cus, s);
+    if (pick == 4) return launch_fast<CfgThin>(A, lda, B, ldb, M, N, K, epi, 2 * cus, s);
     const int tiles_m = ceil_div(M, 128), tiles_n = ceil_div(N, 128);
     linear_generic_kernel<<<tiles_m * tiles_n, 256, CfgSmall::LDS_BYTES, s>>>(A, lda, B, ldb, M, N, K, epi, tiles_n);
     return pclip_check_launch("gemm_f16 (generic)");

@@ -182,6 +182,7 @@ __device__ __forceinline__ void epilogue_f16(const Acc<C>& acc, char* stg, const
     const int wm = wave / C::WN, wn = wave % C::WN, hi = lane >> 5;
     constexpr int RB = C::BN * 2;                                    // bytes per staged row
     constexpr int WROWS = C::BM / C::WM;                             // rows per wave
+    constexpr int SWZ = C::BN / 4 >= 16 ? 15 : C::BN / 4 - 1;         // XOR mask of the 8-byte units (a row has BN / 4 of them)
 #pragma unroll
     for (int h = 0; h < C::NH; ++h) {
         slab(h);           // caller hook: e.g. issue this slab's residual loads so they fly during the staging
@@ -197,7 +198,7 @@ __device__ __forceinline__ void epilogue_f16(const Acc<C>& acc, char* stg, const
                         const int nl = wn * (C::BN / C::WN) + j * 32 + 8 * g + 4 * hi;
                         float4_t v = {acc.v[i][j][4 * g], acc.v[i][j][4 * g + 1], acc.v[i][j][4 * g + 2], acc.v[i][j][4 * g + 3]};
                         const half4_t hv = pre(i, j, g, v);
-                        const int unit = (nl >> 2) ^ (ml & 15);
+                        const int unit = (nl >> 2) ^ (ml & SWZ);
                         *reinterpret_cast<half4_t*>(stg + ml * RB + unit * 8) = hv;
                     }
             }
@@ -207,7 +208,7 @@ __device__ __forceinline__ void epilogue_f16(const Acc<C>& acc, char* stg, const
 #pragma unroll
         for (int ps = 0; ps < C::NPASS; ++ps) {
             const int r = tid / C::CPR + ps * C::ROWS_PER_PASS;       // row inside the slab
-            const int pair = c ^ ((r & 15) >> 1);
+            const int pair = c ^ ((r & SWZ) >> 1);
             half8_t hv = *reinterpret_cast<const half8_t*>(stg + r * RB + pair * 16);
             if (r & 1) hv = half8_t{hv[4], hv[5], hv[6], hv[7], hv[0], hv[1], hv[2], hv[3]};
             post(h * C::HR + r, c, h * C::NPASS + ps, hv);
