@@ -147,6 +147,13 @@ int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, void* C, int 
 int pclip_gemm_bn_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                       const float* scale, const float* shift, int relu, pclip_stream_t stream);
 
+/* 3x3 convolution, stride 1, padding 1, on NHWC fp16 activations x [B, H, W, Cin] + eval BatchNorm (+ReLU), as an implicit
+ * GEMM: the im2col matrix is never materialised (each K-tile is gathered by LDS-DMA; taps outside the image read
+ * `zero_line`, >= 128 zero bytes in device memory supplied by the caller).  w [Cout, 3, 3, Cin] fp16; y [B*H*W, Cout].
+ * Cin % 64 == 0, Cout % 64 == 0.  Identical to pclip_im2col3x3_f16 + pclip_gemm_bn_f16 (clip/model.py:20-22, 45-46). */
+int pclip_conv3x3_bn_f16(const void* x, const void* w, const void* zero_line, int B, int H, int W, int Cin, int Cout,
+                         const float* scale, const float* shift, int relu, void* y, pclip_stream_t stream);
+
 /* LayerNorm over the last dim with fp32 statistics and fp32 affine parameters, fp16 in/out
  * (clip/model.py:155-161).  x rows are ld_x elements apart (lets ln_post read only the CLS rows). */
 int pclip_layernorm_f16(const void* x, int ld_x, const float* gamma, const float* beta, float eps, void* y,

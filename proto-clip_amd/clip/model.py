@@ -256,8 +256,10 @@ class ModifiedResNet(nn.Module):
         return self._cache.get(("w3", key), conv.weight, prep)
 
     def _conv3_bn_relu(self, key, x, strides, B, H, W, C, conv, bn, stride=1):
-        cols = ops.im2col3x3(x, strides, B, H, W, C, stride)
         sc, sh = self._bn_affine(key, bn)
+        if stride == 1 and C % 64 == 0 and conv.weight.shape[0] % 64 == 0 and strides == (H * W * C, W * C, C, 1):
+            return ops.conv3x3_bn(x, self._w3x3(key, conv), sc, sh, B, H, W, C, relu=True)   # implicit GEMM: no im2col buffer
+        cols = ops.im2col3x3(x, strides, B, H, W, C, stride)
         return ops.gemm_bn(cols, self._w3x3(key, conv), sc, sh, relu=True)                   # relu(bn(conv3x3(x))) in one launch
 
     def _bottleneck(self, key, blk, x, B, H, W, Cin):

@@ -159,6 +159,82 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     }
 }
 
+// ---- 3x3 convolution (stride 1, pad 1, NHWC) + eval BatchNorm (+ReLU) as an implicit GEMM -----------------------------------
+// Same persistent structure as linear_fast_kernel; the A operand is gathered by pgemm::ConvGather instead of read from an
+// im2col matrix (clip/model.py:20-22, 45-46: conv2 / bn2 / relu of every bottleneck).  w is [Cout, ky, kx, Cin].
+template <class C, int ACT>
+__global__ __launch_bounds__(C::NTHREADS, 2) void conv3x3_fast_kernel(const half_t* __restrict__ x, const half_t* __restrict__ zero,
+                                                                      const half_t* __restrict__ w, int H, int W, int Cin, int M,
+                                                                      int N, const float* __restrict__ scale,
+                                                                      const float* __restrict__ shift, half_t* __restrict__ Cout,
+                                                                      int tiles_n, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* affine_lds = reinterpret_cast<float*>(smem + C::LDS_BYTES);       // [2][ scale BN | shift BN ] fp32
+    const int G = gridDim.x;
+    int tile = pgemm::xcd_remap(blockIdx.x, G);
+    if (tile >= ntiles) return;
+    const int K = 9 * Cin, ldb = K, nt = K / pgemm::BK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave % C::WN, hi = lane >> 5;
+    pgemm::ConvGather<C> ga{x, zero, H, W, Cin, M, {}, {}};
+    auto copy_affine = [&](int t, int par) {
+        const int tn = t - (t / tiles_n) * tiles_n;
+        if (lane < C::BN / 4) {
+            __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(scale + tn * C::BN + lane * 4), (pgemm::lds_ptr_t)(affine_lds + par * 2 * C::BN), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(shift + tn * C::BN + lane * 4), (pgemm::lds_ptr_t)(affine_lds + par * 2 * C::BN + C::BN), 16, 0, 0);
+        }
+    };
+    auto stage0 = [&](int t, int pbuf) {                       // K-tile 0 of tile t into buffer pbuf (ga prepared for t)
+        const int tm = t / tiles_n, tn = t - tm * tiles_n;
+        char* a = smem + pbuf * C::STAGE_BYTES;
+        ga.stage(0, a);
+        pgemm::stage_tile<C::BN, C::NWAVES>(w, ldb, tn * C::BN, N, 0, a + C::A_BYTES, wave, lane);
+    };
+    copy_affine(tile, 0);
+    pgemm::wait_vm<0>();
+    pgemm::lds_barrier();
+    int p = 0;
+    ga.prepare((tile / tiles_n) * C::BM);
+    stage0(tile, p);
+    constexpr int YOUNGER = C::NH * C::NPASS + 2;
+    bool prev_full = false;
+    int parity = 0;
+    for (; tile < ntiles; tile += G, parity ^= 1) {
+        const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+        const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
+        const bool full = m0 + C::BM <= M;
+        pgemm::Acc<C> acc;
+        copy_affine(tile + G < ntiles ? tile + G : tile, parity ^ 1);
+        pgemm::mainloop_g<C, YOUNGER, true>([&](int t, char* dst) { ga.stage(t, dst); }, w, ldb, N, nt, n0, smem, acc, p, prev_full);
+        const int next = tile + G;
+        if (next < ntiles) {                                  // buffer p is free: prefetch the next tile's K-tile 0
+            ga.prepare((next / tiles_n) * C::BM);
+            stage0(next, p);
+        }
+        char* stg = smem + (p ^ 1) * C::STAGE_BYTES;
+        const int col = n0 + 8 * (tid % C::CPR);
+        auto pre = [&](int, int j, int g, float4_t v) {
+            half4_t h;
+            const float* st = affine_lds + parity * 2 * C::BN + wn * (C::BN / C::WN) + j * 32 + 8 * g + 4 * hi;
+            const float4_t sc = *reinterpret_cast<const float4_t*>(st), sh = *reinterpret_cast<const float4_t*>(st + C::BN);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float y = r16(r16(v[e]) * sc[e] + sh[e]);
+                if (ACT == 3) y = fmaxf(y, 0.f);
+                h[e] = (half_t)y;
+            }
+            return h;
+        };
+        if (full)
+            pgemm::epilogue_f16<C>(acc, stg, [](int) {}, pre,
+                                   [&](int r, int, int, half8_t h) { st_half8(Cout + (size_t)(m0 + r) * N + col, h); });
+        else
+            pgemm::epilogue_f16<C>(acc, stg, [](int) {}, pre, [&](int r, int, int, half8_t h) {
+                if (m0 + r < M) st_half8(Cout + (size_t)(m0 + r) * N + col, h);
+            });
+        prev_full = full;
+    }
+}
+
 // ---- generic kernel: any M, N, leading dimensions; optional residual; one 128x128 tile per workgroup ------
 __global__ __launch_bounds__(256, 2) void linear_generic_kernel(const half_t* __restrict__ A, int lda,
                                                                 const half_t* __restrict__ B, int ldb, int M, int N,
@@ -742,6 +818,54 @@ extern "C" int pclip_gemm_bn_f16(const void* A, int lda, const void* B, int ldb,
     if (cus <= 0) cus = 256;
     const bool strips_ok = N % 4 == 0 && ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0;
     return gemm_dispatch((const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, cus, strips_ok ? -1 : -2, true, (hipStream_t)stream);
+}
+
+namespace {
+template <class C, int ACT>
+int launch_conv2(const void* x, const void* zero, const void* w, int B, int H, int W, int Cin, int Cout, const float* scale,
+                 const float* shift, void* y, int slots, hipStream_t s) {
+    static bool attr = false;
+    constexpr int LDS = C::LDS_BYTES + 2 * 2 * C::BN * 4;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)conv3x3_fast_kernel<C, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+            pclip_set_error("pclip_conv3x3_bn_f16: cannot raise the dynamic LDS limit to %d", LDS);
+            return PCLIP_E_LAUNCH;
+        }
+        attr = true;
+    }
+    const int M = B * H * W, tiles_m = ceil_div(M, C::BM), tiles_n = Cout / C::BN, ntiles = tiles_m * tiles_n;
+    conv3x3_fast_kernel<C, ACT><<<ntiles < slots ? ntiles : slots, C::NTHREADS, LDS, s>>>(
+        (const half_t*)x, (const half_t*)zero, (const half_t*)w, H, W, Cin, M, Cout, scale, shift, (half_t*)y, tiles_n, ntiles);
+    return pclip_check_launch("conv3x3_bn");
+}
+template <class C>
+int launch_conv(const void* x, const void* zero, const void* w, int B, int H, int W, int Cin, int Cout, const float* scale,
+                const float* shift, int relu, void* y, int slots, hipStream_t s) {
+    return relu ? launch_conv2<C, 3>(x, zero, w, B, H, W, Cin, Cout, scale, shift, y, slots, s)
+                : launch_conv2<C, 2>(x, zero, w, B, H, W, Cin, Cout, scale, shift, y, slots, s);
+}
+}  // namespace
+
+extern "C" int pclip_conv3x3_bn_f16(const void* x, const void* w, const void* zero_line, int B, int H, int W, int Cin, int Cout,
+                                    const float* scale, const float* shift, int relu, void* y, pclip_stream_t stream) {
+    PCLIP_REQUIRE(x && w && zero_line && scale && shift && y, "pclip_conv3x3_bn_f16: null pointer");
+    PCLIP_REQUIRE(B >= 0 && H > 0 && W > 0 && H < 32768 && W < 32768, "pclip_conv3x3_bn_f16: bad shape B=%d H=%d W=%d", B, H, W);
+    PCLIP_REQUIRE(Cin > 0 && Cin % 64 == 0, "pclip_conv3x3_bn_f16: Cin=%d must be a multiple of 64 (use im2col + pclip_gemm_bn_f16 otherwise)", Cin);
+    PCLIP_REQUIRE(Cout > 0 && Cout % 64 == 0, "pclip_conv3x3_bn_f16: Cout=%d must be a multiple of 64", Cout);
+    PCLIP_REQUIRE((long)B * H * W < (1L << 31) / 1, "pclip_conv3x3_bn_f16: too many output pixels");
+    PCLIP_REQUIRE(((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)x & 15) == 0,
+                  "pclip_conv3x3_bn_f16: pointers must be 16-byte aligned");
+    if (B == 0) return PCLIP_OK;
+    int cus = pclip_device_cus();
+    if (cus <= 0) cus = 256;
+    double cost;
+    int pick = best_cfg((long)B * H * W, Cout, cus, &cost);
+    if (pick == 4 || pick < 0) pick = 3;                        // the 4-wave thin tile has no gather variant; Cout % 64 == 0 always fits 256x64
+    hipStream_t s = (hipStream_t)stream;
+    if (pick == 2) return launch_conv<CfgBig>(x, zero_line, w, B, H, W, Cin, Cout, scale, shift, relu, y, cus, s);
+    if (pick == 1) return launch_conv<CfgWide>(x, zero_line, w, B, H, W, Cin, Cout, scale, shift, relu, y, cus, s);
+    if (pick == 0) return launch_conv<CfgSmall>(x, zero_line, w, B, H, W, Cin, Cout, scale, shift, relu, y, 2 * cus, s);
+    return launch_conv<CfgNarrow>(x, zero_line, w, B, H, W, Cin, Cout, scale, shift, relu, y, cus, s);
 }
 
 #define DISPATCH_NCH(D, CALL)                                  \

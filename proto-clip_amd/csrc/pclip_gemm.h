@@ -114,13 +114,12 @@ __device__ __forceinline__ void stage_first(const half_t* __restrict__ A, int ld
 // YOUNGER = number of vector-memory operations this wave issued AFTER the K-tile-0 staging and that may stay
 // in flight across the first barrier (epilogue stores of the previous tile, bias loads): the first wait is
 // vmcnt(YOUNGER) instead of a full drain.
-template <class C, int YOUNGER = 0, bool ZERO_ACC = true>
-__device__ __forceinline__ void mainloop(const half_t* __restrict__ A, int lda, const half_t* __restrict__ B, int ldb,
-                                         int M, int N, int K, int m0, int n0, char* smem, Acc<C>& acc, int& p,
-                                         bool counted_first = false) {
+// `stage_a(t, dst)` stages K-tile t of the tile's A operand (BM rows x 64 halves, swizzled as stage_tile does) into dst.
+template <class C, int YOUNGER = 0, bool ZERO_ACC = true, class StageA>
+__device__ __forceinline__ void mainloop_g(const StageA& stage_a, const half_t* __restrict__ B, int ldb, int N, int nt, int n0,
+                                           char* smem, Acc<C>& acc, int& p, bool counted_first = false) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / C::WN, wn = wave % C::WN;
-    const int nt = K / BK;
     if (ZERO_ACC) {                                        // otherwise the caller pre-loaded the accumulators (e.g. with the bias)
 #pragma unroll
         for (int i = 0; i < C::TM; ++i)
@@ -143,7 +142,7 @@ __device__ __forceinline__ void mainloop(const half_t* __restrict__ A, int lda, 
         auto stage_next = [&]() {
             if (t + 1 < nt) {
                 char* na = smem + (p ^ 1) * C::STAGE_BYTES;
-                stage_tile<C::BM, C::NWAVES>(A, lda, m0, M, (t + 1) * BK, na, wave, lane);
+                stage_a(t + 1, na);
                 stage_tile<C::BN, C::NWAVES>(B, ldb, n0, N, (t + 1) * BK, na + C::A_BYTES, wave, lane);
             }
         };
@@ -166,6 +165,53 @@ __device__ __forceinline__ void mainloop(const half_t* __restrict__ A, int lda, 
         p ^= 1;
     }
 }
+
+template <class C, int YOUNGER = 0, bool ZERO_ACC = true>
+__device__ __forceinline__ void mainloop(const half_t* __restrict__ A, int lda, const half_t* __restrict__ B, int ldb,
+                                         int M, int N, int K, int m0, int n0, char* smem, Acc<C>& acc, int& p,
+                                         bool counted_first = false) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    mainloop_g<C, YOUNGER, ZERO_ACC>([&](int t, char* dst) { stage_tile<C::BM, C::NWAVES>(A, lda, m0, M, t * BK, dst, wave, lane); },
+                                     B, ldb, N, K / BK, n0, smem, acc, p, counted_first);
+}
+
+// ---- implicit-GEMM gather for a 3x3 / stride 1 / pad 1 convolution on NHWC fp16 activations ------------------------------
+// Row m of the GEMM is output pixel (b, y, x); K-tile t covers tap = (t*64) / Cin and input channels c0 = (t*64) % Cin
+// (Cin % 64 == 0), i.e. the 128 contiguous bytes x[b, y+dy-1, x+dx-1, c0 .. c0+63] — or 128 zero bytes outside the image,
+// fetched from a caller-provided zero line, because an LDS-DMA cannot be predicated per lane without leaving stale LDS.
+// The im2col matrix (9x the activation) is never materialised.
+template <class C>
+struct ConvGather {
+    static constexpr int NR = C::BM / C::NWAVES / 8;       // A rows per lane
+    const half_t* __restrict__ x;
+    const half_t* __restrict__ zero;
+    int H, W, Cin, M;
+    int pix[NR], yx[NR];
+    __device__ __forceinline__ void prepare(int m0) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            int m = m0 + wave * (C::BM / C::NWAVES) + i * 8 + (lane >> 3);
+            m = m < M ? m : M - 1;                          // rows beyond M are never stored
+            const int b = m / (H * W), rem = m - b * H * W, y = rem / W, xx = rem - y * W;
+            pix[i] = m;                                     // (b*H + y)*W + x == m for stride 1 / pad 1
+            yx[i] = (y << 16) | xx;
+        }
+    }
+    __device__ __forceinline__ void stage(int t, char* dst) const {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int k0 = t * BK, tap = k0 / Cin, c0 = k0 - tap * Cin, dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = wave * (C::BM / C::NWAVES) + i * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ swz_key(r);
+            const int y = (yx[i] >> 16) + dy, xx = (yx[i] & 0xffff) + dx;
+            const bool in = (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const half_t* src = in ? x + ((size_t)(pix[i] + dy * W + dx) * Cin + c0 + c * 8) : zero + c * 8;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dst + (wave * (C::BM / C::NWAVES) + i * 8) * ROW_BYTES), 16, 0, 0);
+        }
+    }
+};
 
 // ---- fp16 output through an LDS-staged, fully coalesced epilogue -----------------------------------------
 // The BM x BN tile leaves in NH slabs of HR = 128 rows.  For slab h:

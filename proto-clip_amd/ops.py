@@ -266,6 +266,26 @@ def gemm_bn(a, w, scale, shift, relu: bool = True, out=None):
     return out
 
 
+_zero_line = {}
+
+
+def conv3x3_bn(x, w, scale, shift, B: int, H: int, W: int, Cin: int, relu: bool = True):
+    """relu?(bn(conv3x3(x))) (stride 1, pad 1) on NHWC rows x [B*H*W, Cin] with w [Cout, 9*Cin] in (ky, kx, Cin) order:
+    implicit GEMM, no im2col buffer.  Cin, Cout multiples of 64."""
+    require_cuda(x, w, scale, shift)
+    x, w = _f16c(x), _f16c(w)
+    Cout = w.shape[0]
+    if w.shape[1] != 9 * Cin or x.numel() != B * H * W * Cin:
+        raise _lib.PclipError("conv3x3_bn: shape mismatch")
+    z = _zero_line.get(x.device)
+    if z is None:
+        z = _zero_line[x.device] = torch.zeros(64, dtype=torch.float16, device=x.device)
+    y = torch.empty(B * H * W, Cout, dtype=torch.float16, device=x.device)
+    check(_lib.load().pclip_conv3x3_bn_f16(ptr(x), ptr(w), ptr(z), B, H, W, Cin, Cout, ptr(scale), ptr(shift), int(relu), ptr(y),
+                                           stream()), "pclip_conv3x3_bn_f16")
+    return y
+
+
 def layernorm(x, gamma, beta, eps: float = 1e-5, out=None, rows: int = None, ld: int = None):
     """fp16 in/out LayerNorm with fp32 statistics and fp32 affine (clip/model.py:155-161)."""
     require_cuda(x, gamma, beta)

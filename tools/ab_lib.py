@@ -19,8 +19,8 @@ for m, n, k in shapes:
             rc = libs[x].pclip_gemm_f16(P(a.data_ptr()), k, P(w.data_ptr()), k, P(out[x].data_ptr()), n, m, n, k, P(b.data_ptr()), act, None, st)
             assert rc == 0
         res = {x: [] for x in libs}
-        for r in range(5):
-            for x in libs:
-                res[x].append(timeit(lambda: call(x), iters=6, warm=1) * 1e6)
+        for r in range(6):                                     # ABBA order: whichever build runs first in a round pays the clock ramp
+            for x in (list(libs) if r % 2 == 0 else list(libs)[::-1]):
+                res[x].append(timeit(lambda: call(x), iters=6, warm=2) * 1e6)
         same = torch.equal(out["new"], out["old"])
-        print(f"{m}x{n}x{k} {name:9s} " + " | ".join(f"{x} {sorted(res[x])[2]:7.1f} us" for x in libs) + f" | identical {same}", flush=True)
+        print(f"{m}x{n}x{k} {name:9s} " + " | ".join(f"{x} {sorted(res[x])[len(res[x]) // 2]:7.1f} us" for x in libs) + f" | identical {same}", flush=True)
