@@ -172,6 +172,12 @@ int pclip_add_layernorm_f16(const void* x, const void* delta, int ld, void* x_ou
 int pclip_attention_f16(const void* qkv, void* out, int B, int L, int H, int dh, int causal,
                         pclip_stream_t stream);
 
+/* The same attention with separate operands: queries = the first Lq tokens of every sequence (q + b*q_batch_stride + row*ldq,
+ * head h at column h*64), keys / values in kv [B*L rows, row stride ldkv] at column offsets k_off / v_off; out [B*Lq, H*64].
+ * Lq < L serves the last vision block, whose output is only read at the class token (clip/model.py:233); causal needs Lq == L. */
+int pclip_attention_q_f16(const void* q, int ldq, long q_batch_stride, const void* kv, int ldkv, int k_off, int v_off, void* out,
+                          int B, int L, int Lq, int H, int dh, int causal, pclip_stream_t stream);
+
 /* ViT stem (clip/model.py:222-227): patch-conv as an im2col gather of [B,3,R,R] fp16 images into
  * [B*G*G, ld >= 3*P*P] rows, zero beyond 3*P*P (the GEMM against conv1.weight follows), and the token assembly
  * x = [class_emb ; patches] + pos -> fp16 [B, 1+G*G, W]. */

@@ -63,7 +63,7 @@ def _transformer(width, layers):
     return t
 
 
-def _run_blocks(x, blocks, B, L, heads, causal, select=None):
+def _run_blocks(x, blocks, B, L, heads, causal, select=None, first_token=False):
     """ResidualAttentionBlock.forward (clip/model.py:187-190) per layer on x [B*L, W] fp16.
     Each residual add is fused into the LayerNorm that reads its result, so the stream of a block is
         h = LN1(x [+ d])   qkv = in_proj(h)   a = attention(qkv)   d = out_proj(a)
@@ -74,7 +74,9 @@ def _run_blocks(x, blocks, B, L, heads, causal, select=None):
     tower, clip/model.py:233; the EOT token of the text tower, :350).  The reference pushes every token through the last
     block and then discards all but that row; here the last block's out_proj, LN2 and MLP run on those B rows only — the
     same arithmetic for the rows that matter (a GEMM row does not depend on the other rows), 9/12 of one layer's linear
-    FLOPs saved (6 % of a 12-layer tower).  With `select`, x and d are returned as [B, W]."""
+    FLOPs saved (6 % of a 12-layer tower).  With `select`, x and d are returned as [B, W].  `first_token` (vision tower: the
+    selected row is token 0 of every sequence) additionally projects the last block's QUERIES for those B rows only and runs
+    its attention for that one query per image (keys / values still come from every token)."""
     d = None
     n = len(blocks)
     for i, blk in enumerate(blocks):
@@ -82,10 +84,17 @@ def _run_blocks(x, blocks, B, L, heads, causal, select=None):
             h = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias)
         else:
             h = ops.add_layernorm(x, d, blk.ln_1.weight, blk.ln_1.bias)
-        qkv = ops.gemm(h, blk.attn.in_proj_weight, blk.attn.in_proj_bias)
-        a = ops.attention(qkv, B, L, heads, causal=causal)
-        if select is not None and i == n - 1:
-            a, x = select(a), select(x)                  # x already holds the residual stream entering this block's out_proj add
+        if select is not None and i == n - 1 and first_token and not causal:
+            W = h.shape[1]
+            w, bias = blk.attn.in_proj_weight, blk.attn.in_proj_bias
+            kv = ops.gemm(h, w[W:], bias[W:])                                     # keys | values of every token
+            q = ops.gemm(select(h), w[:W], bias[:W])                              # queries of the class tokens
+            a, x = ops.attention_first_queries(q, kv, B, L, 1, heads), select(x)
+        else:
+            qkv = ops.gemm(h, blk.attn.in_proj_weight, blk.attn.in_proj_bias)
+            a = ops.attention(qkv, B, L, heads, causal=causal)
+            if select is not None and i == n - 1:
+                a, x = select(a), select(x)              # x already holds the residual stream entering this block's out_proj add
         d = ops.gemm(a, blk.attn.out_proj.weight, blk.attn.out_proj.bias)
         h = ops.add_layernorm(x, d, blk.ln_2.weight, blk.ln_2.bias)
         f = ops.gemm(h, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, act=1)
@@ -164,7 +173,7 @@ class VisionTransformer(nn.Module):
         x = ops.vit_assemble_tokens(patch, cls16, pos16, B, G * G, W)       # clip/model.py:225-226
         x = ops.layernorm(x, self.ln_pre.weight, self.ln_pre.bias)          # 227
         pick_cls = lambda t: t.view(B, L, W)[:, 0, :].contiguous()          # x[:, 0, :], 233 (taken before the last block's tail)
-        x, d = _run_blocks(x, self.transformer.resblocks, B, L, self.heads, causal=False, select=pick_cls)   # 229-231
+        x, d = _run_blocks(x, self.transformer.resblocks, B, L, self.heads, causal=False, select=pick_cls, first_token=True)   # 229-231
         if d is None:
             cls = ops.layernorm(x, self.ln_post.weight, self.ln_post.bias)
         else:                                                               # ln_post((x + d)[:, 0, :]), 233

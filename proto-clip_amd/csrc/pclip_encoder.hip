@@ -478,15 +478,22 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const half_t* __rest
 constexpr int ATT_DH = 64;
 constexpr int ATT_MAX_L = 288;
 
-__global__ __launch_bounds__(256, 2) void attention_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
-                                                           int L, int H, int causal, int NT, int LV) {
+// General operand form: queries q [B][Lq rows, row stride ldq] (the FIRST Lq tokens of each sequence), keys / values in
+// kv [B*L rows, row stride ldkv] at column offsets k_off / v_off; the fused-QKV case is q = kv = qkv, ldq = ldkv = 3W,
+// k_off = W, v_off = 2W, Lq = L.  Lq < L serves the last vision block, whose output is only read at the class token.
+__global__ __launch_bounds__(256, 2) void attention_kernel(const half_t* __restrict__ qp, int ldq, long q_batch,
+                                                           const half_t* __restrict__ kvp, int ldkv, int k_off, int v_off,
+                                                           half_t* __restrict__ out, int L, int Lq, int H, int causal, int NT,
+                                                           int LV) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int LP = NT * 32;
     half_t* Ks = reinterpret_cast<half_t*>(smem);             // [LP][64], 16-byte chunks XOR-swizzled by swz_key(row)
     half_t* Vt = Ks + LP * ATT_DH;                            // [64][LV]: V transposed, (LV/4) odd -> conflict-free b64 reads
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int W = H * ATT_DH;
-    const half_t* base = qkv + (size_t)b * L * 3 * W + h * ATT_DH;
+    const half_t* kbase = kvp + (size_t)b * L * ldkv + h * ATT_DH + k_off;
+    const half_t* vbase = kvp + (size_t)b * L * ldkv + h * ATT_DH + v_off;
+    const half_t* qbase = qp + (size_t)b * q_batch + h * ATT_DH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // K: global_load_lds, 8 rows x 128 B per wave instruction, swizzle on the source chunk (as the GEMM tiles)
@@ -494,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const half_t* __restr
         const int r = r0 + (lane >> 3);
         const int c = (lane & 7) ^ pgemm::swz_key(r);
         const int rc = r < L ? r : L - 1;                     // rows >= L are masked in the scores
-        __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(base + (size_t)rc * 3 * W + W + c * 8),
+        __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(kbase + (size_t)rc * ldkv + c * 8),
                                          (pgemm::lds_ptr_t)(Ks + r0 * ATT_DH), 16, 0, 0);
     }
     // V^T: each thread transposes a 4-key x 8-dim block: 4 x 16-byte loads -> 8 x ds_write_b64
@@ -504,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const half_t* __restr
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int r = kg * 4 + u;
-            if (r < L) v[u] = ld_half8(base + (size_t)r * 3 * W + 2 * W + c * 8);
+            if (r < L) v[u] = ld_half8(vbase + (size_t)r * ldkv + c * 8);
             else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[u][j] = (half_t)0.f;     // padded keys must contribute exact zeros
@@ -519,12 +526,13 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const half_t* __restr
     __syncthreads();
 
     const int hi = lane >> 5, ql = lane & 31;
-    for (int qb = wave; qb < NT; qb += 4) {
+    const int NTq = (Lq + 31) >> 5;
+    for (int qb = wave; qb < NTq; qb += 4) {
         const int q = qb * 32 + ql;                     // this lane's query row
-        const int qc = q < L ? q : L - 1;
+        const int qc = q < Lq ? q : Lq - 1;
         half8_t qf[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = ld_half8(base + (size_t)qc * 3 * W + s * 16 + hi * 8);
+        for (int s = 0; s < 4; ++s) qf[s] = ld_half8(qbase + (size_t)qc * ldq + s * 16 + hi * 8);
         float16_t o[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -607,9 +615,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const half_t* __restr
         for (; t + 1 < tend; t += 2) tiles(std::integral_constant<int, 2>{}, t);
         if (t < tend) tiles(std::integral_constant<int, 1>{}, t);
         // O^T tile: column q = lane & 31 (this lane's query), rows d = j*32 + 8*(e>>2) + 4*hi + (e&3)
-        if (q < L) {
+        if (q < Lq) {
             const float inv = 1.f / lrun;
-            half_t* orow = out + ((size_t)b * L + q) * W + h * ATT_DH;
+            half_t* orow = out + ((size_t)b * Lq + q) * W + h * ATT_DH;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -914,12 +922,15 @@ int pclip_layernorm_f16p(const void* x, const void* gamma, const void* beta, flo
     return pclip_check_launch("layernorm_f16p");
 }
 
-extern "C" int pclip_attention_f16(const void* qkv, void* out, int B, int L, int H, int dh, int causal,
-                                   pclip_stream_t stream) {
-    PCLIP_REQUIRE(qkv && out, "pclip_attention_f16: null pointer");
-    PCLIP_REQUIRE(dh == ATT_DH, "pclip_attention_f16: head dim %d unsupported (must be 64)", dh);
-    PCLIP_REQUIRE(B >= 0 && H > 0 && L > 0 && L <= ATT_MAX_L, "pclip_attention_f16: bad B=%d H=%d L=%d (L <= %d)",
-                  B, H, L, ATT_MAX_L);
+extern "C" int pclip_attention_q_f16(const void* q, int ldq, long q_batch_stride, const void* kv, int ldkv, int k_off, int v_off,
+                                     void* out, int B, int L, int Lq, int H, int dh, int causal, pclip_stream_t stream) {
+    PCLIP_REQUIRE(q && kv && out, "pclip_attention_q_f16: null pointer");
+    PCLIP_REQUIRE(dh == ATT_DH, "pclip_attention_q_f16: head dim %d unsupported (must be 64)", dh);
+    PCLIP_REQUIRE(B >= 0 && H > 0 && L > 0 && L <= ATT_MAX_L && Lq > 0 && Lq <= L, "pclip_attention_q_f16: bad B=%d H=%d L=%d Lq=%d (L <= %d)",
+                  B, H, L, Lq, ATT_MAX_L);
+    PCLIP_REQUIRE(!causal || Lq == L, "pclip_attention_q_f16: the causal mask needs all queries (Lq == L)");
+    PCLIP_REQUIRE(ldq % 8 == 0 && ldkv % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 && q_batch_stride % 8 == 0,
+                  "pclip_attention_q_f16: strides / offsets must be multiples of 8 halves");
     if (B == 0) return PCLIP_OK;
     const int NT = ceil_div(L, 32), LP = NT * 32;
     const int LV = (LP / 4) % 2 ? LP : LP + 4;
@@ -932,8 +943,17 @@ extern "C" int pclip_attention_f16(const void* qkv, void* out, int B, int L, int
         }
         attr_set = true;
     }
-    attention_kernel<<<B * H, 256, lds, (hipStream_t)stream>>>((const half_t*)qkv, (half_t*)out, L, H, causal, NT, LV);
+    attention_kernel<<<B * H, 256, lds, (hipStream_t)stream>>>((const half_t*)q, ldq, q_batch_stride, (const half_t*)kv, ldkv, k_off, v_off,
+                                                                (half_t*)out, L, Lq, H, causal, NT, LV);
     return pclip_check_launch("attention");
+}
+
+extern "C" int pclip_attention_f16(const void* qkv, void* out, int B, int L, int H, int dh, int causal,
+                                   pclip_stream_t stream) {
+    PCLIP_REQUIRE(qkv && out, "pclip_attention_f16: null pointer");
+    PCLIP_REQUIRE(H > 0 && L > 0, "pclip_attention_f16: bad H=%d L=%d", H, L);
+    const int W = H * dh;
+    return pclip_attention_q_f16(qkv, 3 * W, (long)L * 3 * W, qkv, 3 * W, W, 2 * W, out, B, L, L, H, dh, causal, stream);
 }
 
 extern "C" int pclip_im2col_patches_f16(const void* img, int B, int R, int P, void* cols, int ld,

@@ -324,6 +324,17 @@ def attention(qkv, B: int, L: int, H: int, causal: bool = False, out=None):
     return out
 
 
+def attention_first_queries(q, kv, B: int, L: int, Lq: int, H: int):
+    """Attention output of the first Lq tokens only: q [B*Lq, W] (projected queries of those tokens), kv [B*L, 2W] (keys |
+    values of every token).  Same arithmetic per query row as `attention`."""
+    require_cuda(q, kv)
+    W = H * 64
+    out = torch.empty(B * Lq, W, dtype=torch.float16, device=q.device)
+    check(_lib.load().pclip_attention_q_f16(ptr(q), W, Lq * W, ptr(kv), 2 * W, 0, W, ptr(out), B, L, Lq, H, 64, 0, stream()),
+          "pclip_attention_q_f16")
+    return out
+
+
 def cast_f16(x: torch.Tensor) -> torch.Tensor:
     require_cuda(x)
     x = x.contiguous()

@@ -370,3 +370,17 @@ def test_conv3x3_implicit_gemm_equals_im2col_path(ops, B, H, W, Cin, Cout, relu)
             y = y.clamp_min(0)
         yt = y.permute(0, 2, 3, 1).reshape(B * H * W, Cout)
         assert (got.float().cpu() - yt).abs().max().item() <= 2e-2 * yt.abs().max().item()
+
+
+@pytest.mark.parametrize("B,L,H,Lq", [(5, 197, 12, 1), (3, 50, 12, 1), (2, 257, 16, 1), (4, 197, 12, 40), (2, 77, 8, 77)])
+def test_attention_first_queries_matches_full_attention(ops, B, L, H, Lq):
+    """Separate-operand attention (queries of the first Lq tokens, keys / values of all tokens) against the fused-QKV kernel:
+    the rows it produces must be bit-identical to the same rows of the full attention."""
+    W = H * 64
+    g = torch.Generator(device="cuda").manual_seed(L + H)
+    qkv = torch.randn(B * L, 3 * W, device="cuda", generator=g).half()
+    full = ops.attention(qkv, B, L, H).view(B, L, W)
+    q = qkv.view(B, L, 3 * W)[:, :Lq, :W].contiguous().view(B * Lq, W)
+    kv = qkv[:, W:].contiguous()
+    got = ops.attention_first_queries(q, kv, B, L, Lq, H).view(B, Lq, W)
+    assert torch.equal(got, full[:, :Lq])
