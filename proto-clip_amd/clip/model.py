@@ -10,8 +10,8 @@ fused bias/QuickGELU/residual epilogues, fp32-statistics LayerNorm, whole-sequen
 Precision follows `convert_weights` (clip/model.py:373-394): Linear/conv/projection weights fp16,
 LayerNorm and embedding parameters fp32, activations fp16 with fp32 accumulation.
 Both vision towers are built: VisionTransformer (ViT-B/32, ViT-B/16, ViT-L/14) and ModifiedResNet (RN50 /
-RN101: NHWC activations, 1x1 convs as GEMMs, 3x3 convs as im2col + GEMM, eval BatchNorm folded to a streaming
-scale/shift pass)."""
+RN101: NHWC activations, 1x1 convs as GEMMs and 3x3 convs as implicit GEMMs with the eval BatchNorm (+ReLU) in their
+epilogue; im2col + GEMM only for the 3 / 32-channel stem)."""
 import os
 from collections import OrderedDict
 
@@ -321,9 +321,11 @@ class ModifiedResNet(nn.Module):
         bqkv = self._cache.get("apb", ap.q_proj.bias, lambda _: torch.cat([ap.q_proj.bias, ap.k_proj.bias, ap.v_proj.bias]).detach().contiguous())
         L = H * W + 1
         tok = ops.attnpool_tokens(x, pos16, B, H * W, C)
-        qkv = ops.gemm(tok, wqkv, bqkv)
-        a = ops.attention(qkv, B, L, self.heads, causal=False)
-        a0 = a.view(B, L * C)[:, :C]                                   # token 0 of every image (row stride L*C)
+        # only the pooled (mean) token's output is returned (clip/model.py:91 `x[0]`): project queries for token 0 only and
+        # run a one-query attention per (image, head); keys / values still come from all HW + 1 tokens
+        kv = ops.gemm(tok, wqkv[C:], bqkv[C:])
+        q0 = ops.gemm(tok.view(B, L * C)[:, :C].contiguous(), wqkv[:C], bqkv[:C])
+        a0 = ops.attention_first_queries(q0, kv, B, L, 1, self.heads)
         return ops.gemm(a0, ap.c_proj.weight, ap.c_proj.bias)
 
 
