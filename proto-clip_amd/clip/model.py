@@ -239,7 +239,7 @@ class ModifiedResNet(nn.Module):
             setattr(self.attnpool, nm, _linear(embed, embed))
         self.attnpool.c_proj = _linear(output_dim, embed)
         self._cache = _Cached()
-        self.chunk = int(os.environ.get("PCLIP_RN_CHUNK", "256"))     # images per pass (3.2 GB of im2col scratch at 256; 32: 11.2 k, 256: 16.8 k img/s)
+        self.chunk = int(os.environ.get("PCLIP_RN_CHUNK", "256"))     # images per pass: small passes are launch-bound (32: 11.2 k img/s, 256: 16.8 k, measured before the conv fusions)
 
     # -- helpers ---------------------------------------------------------------------------------------------------
     def _bn_affine(self, key, bn):
