@@ -107,6 +107,9 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         const bool full = m0 + C::BM <= M;                    // workgroup-uniform: every row of the tile exists
         pgemm::Acc<C> acc;
         if (HAS_BIAS) {
+            // the strip of this tile was copied one tile ago; with two or more K-tiles the K-loop's vmcnt(0) + barrier in
+            // between made it visible, a single K-tile (K = 64) only has the counted wait: close that case explicitly
+            if (K == pgemm::BK) { pgemm::wait_vm<0>(); pgemm::lds_barrier(); }
             const half_t* bl = bias_lds + parity * C::BN + wn * (C::BN / C::WN) + 4 * hi;
 #pragma unroll
             for (int j = 0; j < C::TN; ++j)
