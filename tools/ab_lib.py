@@ -9,7 +9,7 @@ libs = {n: ctypes.CDLL(os.path.join(root, f)) for n, f in (("new", "libpclip.so"
 P = ctypes.c_void_p
 for l in libs.values():
     l.pclip_gemm_f16.argtypes = [P, ctypes.c_int, P, ctypes.c_int, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, P, ctypes.c_int, P, P]
-shapes = [(201728, 3072, 768), (201728, 2304, 768), (201728, 768, 768), (201728, 768, 3072)]
+shapes = [tuple(int(v) for v in x.split("x")) for x in os.environ["SHAPES"].split(",")] if "SHAPES" in os.environ else [(201728, 3072, 768), (201728, 2304, 768), (201728, 768, 768), (201728, 768, 3072)]
 for m, n, k in shapes:
     a = torch.randn(m, k, device="cuda").half(); w = (torch.randn(n, k, device="cuda") * k ** -0.5).half()
     bias = torch.randn(n, device="cuda").half(); out = {x: torch.empty(m, n, device="cuda", dtype=torch.float16) for x in libs}
