@@ -384,3 +384,43 @@ def test_attention_first_queries_matches_full_attention(ops, B, L, H, Lq):
     kv = qkv[:, W:].contiguous()
     got = ops.attention_first_queries(q, kv, B, L, Lq, H).view(B, Lq, W)
     assert torch.equal(got, full[:, :Lq])
+
+
+def test_full_size_vit_b16_against_oracle():
+    """The real ViT-B/16 architecture (12 layers x 768, 197 tokens; random-init weights) on 6 images against the oracle in both
+    of the reference's precisions: depth-12 amplification of the fp16 rounding differences stays inside the fp16 <-> fp32 gap."""
+    from proto_clip_amd.clip.model import BACKBONES
+    kw = BACKBONES["ViT-B/16"]
+    sd = random_state_dict(seed=21, **kw)
+    model = build_model({k: v.clone() for k, v in sd.items()}).cuda()
+    imgs = synth.make_images(6, 224, seed=8, n_class=6)
+    with torch.no_grad():
+        f = model.encode_image(imgs.cuda()).float().cpu()
+    o16 = clip_oracle.encode_image(sd, imgs, half=True).float()
+    o32 = clip_oracle.encode_image(sd, imgs, half=False).float()
+    gap = rel_err(o16, o32)
+    assert rel_err(f, o16) <= max(2 * gap, 3e-3), (rel_err(f, o16), gap)
+    assert rel_err(f, o32) <= max(2 * gap, 3e-3), (rel_err(f, o32), gap)
+    # the class-token shortcut of the last block and the one-pass batch must not depend on the batch: same rows alone
+    with torch.no_grad():
+        f1 = model.encode_image(imgs[2:3].cuda()).float().cpu()
+    assert torch.equal(f1[0], f[2])
+
+
+def test_full_size_rn50_against_oracle():
+    """The real RN50 tower (3-4-6-3 bottlenecks, 224 px, attention pool with 32 heads) on 4 images against the oracle: fused
+    conv+BN launches, implicit-GEMM 3x3 convolutions, narrow tiles and the one-query attention pool all in play."""
+    from proto_clip_amd.clip.model import BACKBONES
+    kw = BACKBONES["RN50"]
+    sd = random_state_dict(seed=22, **kw)
+    model = build_model({k: v.clone() for k, v in sd.items()}).cuda()
+    imgs = synth.make_images(4, 224, seed=9, n_class=4)
+    with torch.no_grad():
+        f = model.encode_image(imgs.cuda()).float().cpu()
+    o16 = clip_oracle.encode_image_resnet(sd, imgs, half=True).float()
+    o32 = clip_oracle.encode_image_resnet(sd, imgs, half=False).float()
+    gap = rel_err(o16, o32)
+    assert rel_err(f, o16) <= max(2 * gap, 5e-3), (rel_err(f, o16), gap)
+    with torch.no_grad():
+        f1 = model.encode_image(imgs[1:2].cuda()).float().cpu()
+    assert torch.equal(f1[0], f[1])
