@@ -424,3 +424,29 @@ def test_full_size_rn50_against_oracle():
     with torch.no_grad():
         f1 = model.encode_image(imgs[1:2].cuda()).float().cpu()
     assert torch.equal(f1[0], f[1])
+
+
+def test_full_size_text_tower_against_oracle():
+    """The real ViT-B/16 text tower (12 layers x 512, 8 heads, 77 tokens, vocabulary 49408) on 10 synthetic prompts of varying
+    length against the oracle in both precisions (causal attention, EOT gather before the last block's tail)."""
+    from proto_clip_amd.clip.model import BACKBONES
+    kw = BACKBONES["ViT-B/16"]
+    sd = random_state_dict(seed=23, **kw)
+    model = build_model({k: v.clone() for k, v in sd.items()}).cuda()
+    V = kw["vocab_size"]
+    g = torch.Generator().manual_seed(4)
+    toks = torch.zeros(10, 77, dtype=torch.long)
+    for i in range(10):
+        n = int(torch.randint(1, 74, (1,), generator=g))
+        toks[i, 0] = V - 2
+        toks[i, 1:1 + n] = torch.randint(1, V - 2, (n,), generator=g)
+        toks[i, 1 + n] = V - 1                                       # EOT = highest id (the argmax gather, clip/model.py:350)
+    with torch.no_grad():
+        f = model.encode_text(toks.cuda()).float().cpu()
+    o16 = clip_oracle.encode_text(sd, toks, half=True).float()
+    o32 = clip_oracle.encode_text(sd, toks, half=False).float()
+    gap = rel_err(o16, o32)
+    assert rel_err(f, o16) <= max(2 * gap, 3e-3), (rel_err(f, o16), gap)
+    with torch.no_grad():
+        f1 = model.encode_text(toks[3:4].cuda()).float().cpu()
+    assert torch.equal(f1[0], f[3])
