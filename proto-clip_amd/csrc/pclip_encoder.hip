@@ -55,7 +55,7 @@ __device__ __forceinline__ half4_t quick_gelu16x4(float4_t v) {
 // Every vector-memory operation of this kernel is an LDS-DMA or a store (the bias row of the tile also
 // travels by global_load_lds into a small double-buffered LDS strip), because hipcc answers any ordinary
 // VGPR load issued beside an LDS-DMA with a full vmcnt(0) drain at its use (guide §5, trap (b)).
-template <class C, bool HAS_BIAS, int ACT>
+template <class C, bool HAS_BIAS, int ACT, bool M16 = false>
 __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_t* __restrict__ A, int lda,
                                                                      const half_t* __restrict__ B, int ldb, int M, int N,
                                                                      int K, const half_t* __restrict__ bias,
@@ -110,12 +110,13 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             // the strip of this tile was copied one tile ago; with two or more K-tiles the K-loop's vmcnt(0) + barrier in
             // between made it visible, a single K-tile (K = 64) only has the counted wait: close that case explicitly
             if (K == pgemm::BK) { pgemm::wait_vm<0>(); pgemm::lds_barrier(); }
-            const half_t* bl = bias_lds + parity * C::BN + wn * (C::BN / C::WN) + 4 * hi;
+            const half_t* bl = bias_lds + parity * C::BN + wn * (C::BN / C::WN);
 #pragma unroll
             for (int j = 0; j < C::TN; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const half4_t b = *reinterpret_cast<const half4_t*>(bl + j * 32 + 8 * g);
+                    const int coff = M16 ? (g & 1) * 16 + 4 * (lane >> 4) : 8 * g + 4 * hi;      // columns of elements 4g .. 4g+3
+                    const half4_t b = *reinterpret_cast<const half4_t*>(bl + j * 32 + coff);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             copy_bias(tile + G < ntiles ? tile + G : tile, parity ^ 1);
         }
         if (AFFINE) copy_affine(tile + G < ntiles ? tile + G : tile, parity ^ 1);
-        pgemm::mainloop<C, YOUNGER, !HAS_BIAS>(A, lda, B, ldb, M, N, K, m0, n0, smem, acc, p, prev_full);
+        pgemm::mainloop<C, YOUNGER, !HAS_BIAS, M16>(A, lda, B, ldb, M, N, K, m0, n0, smem, acc, p, prev_full);
         const int next = tile + G;
         if (next < ntiles) {                                  // buffer p is free: prefetch the next tile's K-tile 0
             const int tm = next / tiles_n, tn = next - tm * tiles_n;
@@ -133,11 +134,11 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         }
         char* stg = smem + (p ^ 1) * C::STAGE_BYTES;          // buffer of the last K-tile, reused after a barrier
         const int col = n0 + 8 * (tid % C::CPR);
-        auto pre = [&](int, int j, int g, float4_t v) {
+        auto pre = [&](int, int j, int coff, float4_t v) {
             if (ACT == 1) return quick_gelu16x4(v);
             half4_t h;
             if (AFFINE) {
-                const float* st = affine_lds + parity * 2 * C::BN + wn * (C::BN / C::WN) + j * 32 + 8 * g + 4 * hi;
+                const float* st = affine_lds + parity * 2 * C::BN + wn * (C::BN / C::WN) + j * 32 + coff;
                 const float4_t sc = *reinterpret_cast<const float4_t*>(st), sh = *reinterpret_cast<const float4_t*>(st + C::BN);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -152,10 +153,10 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             return h;
         };
         if (full)
-            pgemm::epilogue_f16<C>(acc, stg, [](int) {}, pre,
-                                   [&](int r, int, int, half8_t h) { st_half8(Cout + (size_t)(m0 + r) * ldc + col, h); });
+            pgemm::epilogue_f16<C, M16>(acc, stg, [](int) {}, pre,
+                                        [&](int r, int, int, half8_t h) { st_half8(Cout + (size_t)(m0 + r) * ldc + col, h); });
         else
-            pgemm::epilogue_f16<C>(acc, stg, [](int) {}, pre, [&](int r, int, int, half8_t h) {
+            pgemm::epilogue_f16<C, M16>(acc, stg, [](int) {}, pre, [&](int r, int, int, half8_t h) {
                 if (m0 + r < M) st_half8(Cout + (size_t)(m0 + r) * ldc + col, h);
             });
         prev_full = full;
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv3x3_fast_kernel(const half
         const bool full = m0 + C::BM <= M;
         pgemm::Acc<C> acc;
         copy_affine(tile + G < ntiles ? tile + G : tile, parity ^ 1);
-        pgemm::mainloop_g<C, YOUNGER, true>([&](int t, char* dst) { ga.stage(t, dst); }, w, ldb, N, nt, n0, smem, acc, p, prev_full);
+        pgemm::mainloop_g<C, YOUNGER, true, true>([&](int t, char* dst) { ga.stage(t, dst); }, w, ldb, N, nt, n0, smem, acc, p, prev_full);
         const int next = tile + G;
         if (next < ntiles) {                                  // buffer p is free: prefetch the next tile's K-tile 0
             ga.prepare((next / tiles_n) * C::BM);
@@ -215,9 +216,9 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv3x3_fast_kernel(const half
         }
         char* stg = smem + (p ^ 1) * C::STAGE_BYTES;
         const int col = n0 + 8 * (tid % C::CPR);
-        auto pre = [&](int, int j, int g, float4_t v) {
+        auto pre = [&](int, int j, int coff, float4_t v) {
             half4_t h;
-            const float* st = affine_lds + parity * 2 * C::BN + wn * (C::BN / C::WN) + j * 32 + 8 * g + 4 * hi;
+            const float* st = affine_lds + parity * 2 * C::BN + wn * (C::BN / C::WN) + j * 32 + coff;
             const float4_t sc = *reinterpret_cast<const float4_t*>(st), sh = *reinterpret_cast<const float4_t*>(st + C::BN);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -228,10 +229,10 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv3x3_fast_kernel(const half
             return h;
         };
         if (full)
-            pgemm::epilogue_f16<C>(acc, stg, [](int) {}, pre,
+            pgemm::epilogue_f16<C, true>(acc, stg, [](int) {}, pre,
                                    [&](int r, int, int, half8_t h) { st_half8(Cout + (size_t)(m0 + r) * N + col, h); });
         else
-            pgemm::epilogue_f16<C>(acc, stg, [](int) {}, pre, [&](int r, int, int, half8_t h) {
+            pgemm::epilogue_f16<C, true>(acc, stg, [](int) {}, pre, [&](int r, int, int, half8_t h) {
                 if (m0 + r < M) st_half8(Cout + (size_t)(m0 + r) * N + col, h);
             });
         prev_full = full;
@@ -258,8 +259,8 @@ __global__ __launch_bounds__(256, 2) void linear_generic_kernel(const half_t* __
     const int col = n0 + 8 * (tid % C::CPR);
     pgemm::epilogue_f16<C>(
         acc, smem + (p ^ 1) * C::STAGE_BYTES, [](int) {},
-        [&](int, int j, int g, float4_t v) {
-            const int n = n0 + wn * (C::BN / C::WN) + j * 32 + 8 * g + 4 * hi;
+        [&](int, int j, int coff, float4_t v) {
+            const int n = n0 + wn * (C::BN / C::WN) + j * 32 + coff;
             half4_t h;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -294,13 +295,13 @@ using CfgNarrow = pgemm::Cfg<256, 64, 4, 2>;          // 64-channel convolutions
 using CfgThin = pgemm::Cfg<256, 32, 4, 1>;            // its 32-channel stem (4 waves, two workgroups per CU)
 using CfgSmall = pgemm::CfgSmall;
 
-template <class C, bool HAS_BIAS, int ACT>
+template <class C, bool HAS_BIAS, int ACT, bool M16 = false>
 static int launch_fast2(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const LinearEpi& epi,
                         int slots, hipStream_t s) {
     static bool attr = false;
     constexpr int LDS = C::LDS_BYTES + (ACT >= 2 ? 2 * 2 * C::BN * 4 : 2 * C::BN * 2);   // K-tile ring + double-buffered bias / affine strips
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)linear_fast_kernel<C, HAS_BIAS, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)linear_fast_kernel<C, HAS_BIAS, ACT, M16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS) != hipSuccess) {
             pclip_set_error("pclip_gemm_f16: cannot raise the dynamic LDS limit to %d", LDS);
             return PCLIP_E_LAUNCH;
@@ -309,22 +310,33 @@ static int launch_fast2(const void* A, int lda, const void* B, int ldb, int M, i
     }
     const int tiles_m = ceil_div(M, C::BM), tiles_n = N / C::BN, ntiles = tiles_m * tiles_n;
     const int grid = ntiles < slots ? ntiles : slots;
-    linear_fast_kernel<C, HAS_BIAS, ACT><<<grid, C::NTHREADS, LDS, s>>>(
+    linear_fast_kernel<C, HAS_BIAS, ACT, M16><<<grid, C::NTHREADS, LDS, s>>>(
         (const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi.bias, epi.scale, epi.shift, epi.C, epi.ldc, tiles_n, ntiles);
     return pclip_check_launch("gemm_f16");
 }
 
+static bool g_m16 = true;                                     // PCLIP_GEMM_M16=0: fall back to 32x32x16 MFMAs (A/B switch)
+
+template <class C, bool M16>
+static int launch_fast_m(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const LinearEpi& epi,
+                         int slots, hipStream_t s) {
+    if (epi.act == 2) return launch_fast2<C, false, 2, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
+    if (epi.act == 3) return launch_fast2<C, false, 3, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
+    if (epi.bias) {
+        if (epi.act == 1) return launch_fast2<C, true, 1, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
+        return launch_fast2<C, true, 0, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
+    }
+    if (epi.act == 1) return launch_fast2<C, false, 1, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
+    return launch_fast2<C, false, 0, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
+}
+
+// 16x16x32 MFMAs by default: same FLOPs per cycle as 32x32x16 but a quarter of the accumulator-register traffic per FLOP, and
+// the kernel sits at the socket power cap — 8192^3: 1060 -> 1165 TFLOP/s, bench 46.5 -> 45.8 ms/step (same-box A/B).
 template <class C>
 static int launch_fast(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const LinearEpi& epi,
                        int slots, hipStream_t s) {
-    if (epi.act == 2) return launch_fast2<C, false, 2>(A, lda, B, ldb, M, N, K, epi, slots, s);
-    if (epi.act == 3) return launch_fast2<C, false, 3>(A, lda, B, ldb, M, N, K, epi, slots, s);
-    if (epi.bias) {
-        if (epi.act == 1) return launch_fast2<C, true, 1>(A, lda, B, ldb, M, N, K, epi, slots, s);
-        return launch_fast2<C, true, 0>(A, lda, B, ldb, M, N, K, epi, slots, s);
-    }
-    if (epi.act == 1) return launch_fast2<C, false, 1>(A, lda, B, ldb, M, N, K, epi, slots, s);
-    return launch_fast2<C, false, 0>(A, lda, B, ldb, M, N, K, epi, slots, s);
+    return g_m16 ? launch_fast_m<C, true>(A, lda, B, ldb, M, N, K, epi, slots, s)
+                 : launch_fast_m<C, false>(A, lda, B, ldb, M, N, K, epi, slots, s);
 }
 
 // ---- LayerNorm, one wave per row ----------------------------------------------------------------
@@ -814,6 +826,7 @@ extern "C" int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, vo
         else if (forced == 4) forced = 3;                   // index of the 256x64 configuration
         live = getenv("PCLIP_GEMM_CFG_LIVE") != nullptr;   // tools/ab_cfg.py: re-read the overrides on every call
         nosplit = getenv("PCLIP_GEMM_NOSPLIT") != nullptr;
+        g_m16 = !(getenv("PCLIP_GEMM_M16") != nullptr && getenv("PCLIP_GEMM_M16")[0] == '0');
     }
     return gemm_dispatch((const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, cus, forced, !nosplit, (hipStream_t)stream);
 }

@@ -115,7 +115,11 @@ __device__ __forceinline__ void stage_first(const half_t* __restrict__ A, int ld
 // in flight across the first barrier (epilogue stores of the previous tile, bias loads): the first wait is
 // vmcnt(YOUNGER) instead of a full drain.
 // `stage_a(t, dst)` stages K-tile t of the tile's A operand (BM rows x 64 halves, swizzled as stage_tile does) into dst.
-template <class C, int YOUNGER = 0, bool ZERO_ACC = true, class StageA>
+// M16: the 32x32 accumulator tile is computed as 2x2 v_mfma_f32_16x16x32_f16 (K = 32 per instruction) instead of one
+// v_mfma_f32_32x32x16_f16: same FLOPs per cycle and the same LDS traffic, a quarter of the accumulator-register traffic per
+// FLOP.  Element e of acc.v[i][j] is then sub-tile (a, b) = (e >> 3, (e >> 2) & 1), row a*16 + (lane & 15), columns
+// b*16 + 4*(lane >> 4) + (e & 3).
+template <class C, int YOUNGER = 0, bool ZERO_ACC = true, bool M16 = false, class StageA>
 __device__ __forceinline__ void mainloop_g(const StageA& stage_a, const half_t* __restrict__ B, int ldb, int N, int nt, int n0,
                                            char* smem, Acc<C>& acc, int& p, bool counted_first = false) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -147,6 +151,38 @@ __device__ __forceinline__ void mainloop_g(const StageA& stage_a, const half_t* 
             }
         };
         if (!late) stage_next();
+        if (M16) {
+#pragma unroll
+            for (int ks = 0; ks < BK / 32; ++ks) {
+                if (ks == BK / 64 && late) stage_next();
+                const int kc = ks * 4 + (lane >> 4);                          // 16-byte chunk: k = ks*32 + 8*(lane >> 4) ..
+                half8_t af[C::TM][2], bf[C::TN][2];
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) af[i][a] = lds_frag(la, wm * (C::BM / C::WM) + i * 32 + a * 16 + (lane & 15), kc);
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) bf[j][b] = lds_frag(lb, wn * (C::BN / C::WN) + j * 32 + b * 16 + (lane & 15), kc);
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) {
+                                float4_t c = {acc.v[i][j][(a * 2 + b) * 4], acc.v[i][j][(a * 2 + b) * 4 + 1], acc.v[i][j][(a * 2 + b) * 4 + 2],
+                                              acc.v[i][j][(a * 2 + b) * 4 + 3]};
+                                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][b], af[i][a], c, 0, 0, 0);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) acc.v[i][j][(a * 2 + b) * 4 + r] = c[r];
+                            }
+            }
+            p ^= 1;
+            continue;
+        }
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             if (ks == BK / 32 && late) stage_next();
@@ -166,12 +202,12 @@ __device__ __forceinline__ void mainloop_g(const StageA& stage_a, const half_t* 
     }
 }
 
-template <class C, int YOUNGER = 0, bool ZERO_ACC = true>
+template <class C, int YOUNGER = 0, bool ZERO_ACC = true, bool M16 = false>
 __device__ __forceinline__ void mainloop(const half_t* __restrict__ A, int lda, const half_t* __restrict__ B, int ldb,
                                          int M, int N, int K, int m0, int n0, char* smem, Acc<C>& acc, int& p,
                                          bool counted_first = false) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    mainloop_g<C, YOUNGER, ZERO_ACC>([&](int t, char* dst) { stage_tile<C::BM, C::NWAVES>(A, lda, m0, M, t * BK, dst, wave, lane); },
+    mainloop_g<C, YOUNGER, ZERO_ACC, M16>([&](int t, char* dst) { stage_tile<C::BM, C::NWAVES>(A, lda, m0, M, t * BK, dst, wave, lane); },
                                      B, ldb, N, K / BK, n0, smem, acc, p, counted_first);
 }
 
@@ -216,13 +252,13 @@ struct ConvGather {
 // ---- fp16 output through an LDS-staged, fully coalesced epilogue -----------------------------------------
 // The BM x BN tile leaves in NH slabs of HR = 128 rows.  For slab h:
 //  step 0 `slab(h)`: caller hook before the slab is staged;
-//  step 1 (MFMA layout, waves owning rows of the slab): `pre(i, j, g, v4)` turns four consecutive-column
-//          accumulators into fp16 values (bias / activation); they are written as 8-byte units into a
+//  step 1 (MFMA layout, waves owning rows of the slab): `pre(i, j, coff, v4)` turns four consecutive-column
+//          accumulators (columns coff .. coff+3 of the wave's 32-column tile j) into fp16 values (activation); they are written as 8-byte units into a
 //          [HR][BN] fp16 LDS image with unit' = unit ^ (row & 15)  (conflict-free ds_write_b64);
 //  step 2 (row-major, all waves): `post(row_in_tile, chunk, pass, half8)` receives 8 consecutive columns of a
 //          row (one ds_read_b128; the XOR may swap the two 8-byte halves) — a wave instruction covers whole
 //          512-byte / 256-byte row segments: 16-byte fully coalesced global stores.
-template <class C, class Slab, class Pre, class Post>
+template <class C, bool M16 = false, class Slab, class Pre, class Post>
 __device__ __forceinline__ void epilogue_f16(const Acc<C>& acc, char* stg, const Slab& slab, const Pre& pre, const Post& post) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / C::WN, wn = wave % C::WN, hi = lane >> 5;
@@ -236,14 +272,17 @@ __device__ __forceinline__ void epilogue_f16(const Acc<C>& acc, char* stg, const
         if ((wm * WROWS) / C::HR == h) {
 #pragma unroll
             for (int i = 0; i < C::TM; ++i) {
-                const int ml = (wm * WROWS) % C::HR + i * 32 + (lane & 31);
 #pragma unroll
                 for (int j = 0; j < C::TN; ++j)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const int nl = wn * (C::BN / C::WN) + j * 32 + 8 * g + 4 * hi;
+                        // (row, first of four columns) inside the wave's 32x32 tile (i, j) of accumulator elements 4g .. 4g+3
+                        const int rl = M16 ? (g >> 1) * 16 + (lane & 15) : (lane & 31);
+                        const int coff = M16 ? (g & 1) * 16 + 4 * (lane >> 4) : 8 * g + 4 * hi;
+                        const int ml = (wm * WROWS) % C::HR + i * 32 + rl;
+                        const int nl = wn * (C::BN / C::WN) + j * 32 + coff;
                         float4_t v = {acc.v[i][j][4 * g], acc.v[i][j][4 * g + 1], acc.v[i][j][4 * g + 2], acc.v[i][j][4 * g + 3]};
-                        const half4_t hv = pre(i, j, g, v);
+                        const half4_t hv = pre(i, j, coff, v);
                         const int unit = (nl >> 2) ^ (ml & SWZ);
                         *reinterpret_cast<half4_t*>(stg + ml * RB + unit * 8) = hv;
                     }

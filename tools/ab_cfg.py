@@ -13,16 +13,16 @@ for m, n, k in shapes:
     if os.environ.get("DATA") == "small": a.mul_(1e-3); w.mul_(1e-3)
     bias = torch.randn(n, device="cuda").half(); out = torch.empty(m, n, device="cuda", dtype=torch.float16)
     for name, f in {"plain": lambda: ops.gemm(a, w, None, 0, None, out), "bias": lambda: ops.gemm(a, w, bias, 0, None, out), "bias+gelu": lambda: ops.gemm(a, w, bias, 1, None, out)}.items():
-        os.environ["PCLIP_GEMM_CFG"] = "1"; ref = f().clone()
+        os.environ["PCLIP_GEMM_CFG"] = "1"; os.environ["PCLIP_GEMM_M16"] = "0"; ref = f().clone()
         res = {c: [] for c in cfgs}
         for c in cfgs:
-            os.environ["PCLIP_GEMM_CFG"] = c
+            os.environ["PCLIP_GEMM_CFG"] = c.rstrip("m"); os.environ["PCLIP_GEMM_M16"] = "1" if c.endswith("m") else "0"
             out.zero_(); got = f(); torch.cuda.synchronize()
             bad = (got != ref).sum().item()
             if bad: print(f"  cfg {c} {name} {m}x{n}x{k}: {bad} mismatching elements, max diff {(got.float()-ref.float()).abs().max().item():.4g}")
         for r in range(5):
             for c in cfgs:
-                os.environ["PCLIP_GEMM_CFG"] = c
+                os.environ["PCLIP_GEMM_CFG"] = c.rstrip("m"); os.environ["PCLIP_GEMM_M16"] = "1" if c.endswith("m") else "0"
                 res[c].append(timeit(f, iters=12, warm=2) * 1e6)
         line = f"{m}x{n}x{k} {name:9s}"
         for c in cfgs:
