@@ -3,7 +3,8 @@
 // (utils.py:230-233) and activations x nn.Linear weights (clip/model.py:176-178)).
 //
 // Tile configurations (template Cfg): BM x BN x 64 per workgroup of WM x WN waves, each wave owning a
-// (BM/WM) x (BN/WN) block as TM x TN accumulators of v_mfma_f32_32x32x16_f16.
+// (BM/WM) x (BN/WN) block as TM x TN 32x32 accumulator tiles, each computed by 2x2 v_mfma_f32_16x16x32_f16 (default, M16)
+// or one v_mfma_f32_32x32x16_f16.
 //   Cfg<256,256,2,4>  512 threads, 128 acc VGPRs/lane, 128 KiB LDS, 1 workgroup/CU — large GEMMs
 //   Cfg<256,128,4,2>  512 threads,  64 acc VGPRs/lane,  96 KiB LDS, 1 workgroup/CU — N = 768-wide layers
 //   Cfg<128,128,2,2>  256 threads,  64 acc VGPRs/lane,  64 KiB LDS, 2 workgroups/CU — small problems
