@@ -178,7 +178,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv3x3_fast_kernel(const half
     int tile = pgemm::xcd_remap(blockIdx.x, G);
     if (tile >= ntiles) return;
     const int K = 9 * Cin, ldb = K, nt = K / pgemm::BK;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave % C::WN, hi = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave % C::WN;
     pgemm::ConvGather<C> ga{x, zero, H, W, Cin, M, {}, {}};
     auto copy_affine = [&](int t, int par) {
         const int tn = t - (t / tiles_n) * tiles_n;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void linear_generic_kernel(const half_t* __
     const int swz = pgemm::xcd_remap(blockIdx.x, gridDim.x);
     const int tile_m = swz / tiles_n, tile_n = swz - tile_m * tiles_n;
     const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave % C::WN, hi = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave % C::WN;
     int p = 0;
     pgemm::stage_first<C>(A, lda, B, ldb, M, N, m0, n0, smem, p);
     pgemm::Acc<C> acc;
