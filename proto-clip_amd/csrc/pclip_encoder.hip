@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void linear_generic_kernel(const half_t* __
     const int swz = pgemm::xcd_remap(blockIdx.x, gridDim.x);
     const int tile_m = swz / tiles_n, tile_n = swz - tile_m * tiles_n;
     const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave % C::WN;
+    const int tid = threadIdx.x, wave = tid >> 6, wn = wave % C::WN;
     int p = 0;
     pgemm::stage_first<C>(A, lda, B, ldb, M, N, m0, n0, smem, p);
     pgemm::Acc<C> acc;
