@@ -375,6 +375,226 @@ __global__ __launch_bounds__(256) void hp_sweep_kernel(const float* __restrict__
         if (cnt[i]) atomicAdd(&correct[i], cnt[i]);
 }
 
+// ---- small class counts (N <= 32: EuroSAT's 10 classes): the whole of P in ONE launch --------------------------
+// The two-stage path above is four launches (two norm passes, the distance GEMM, the softmax pass) — at EuroSAT's size
+// (8.35 MB of traffic, 1.3 us of HBM time) that is all launch latency.  Here a wave owns 16 queries: both banks sit in
+// LDS (rows padded by 16 B so the 16 class rows of a fragment read land on different banks), the query rows go straight
+// from HBM into the MFMA operand layout (lane = row l&15, k-chunk l>>4: 16-byte loads, every byte used once; the first
+// 512 k of the wave's first group are requested BEFORE the banks are staged, so the two latencies overlap), the
+// contraction is v_mfma_f32_16x16x32_f16 with the classes as the first operand, so a lane ends up with 4 consecutive
+// classes (4*(l>>4)+e) of ONE query (l&15) per 16-class tile: the fp32 norms (accumulated from the very fragments the
+// MFMAs consume), the cdist epilogue, both softmaxes, the alpha fusion and argmax / top-k are finished in registers with
+// two xor-shuffles (16, 32) per reduction.  Workgroups are 2 waves when every group of 16 queries finds a free slot at
+// once (latency-bound sizes) and 8 waves sharing one LDS copy of the banks otherwise.
+// acc + sum of the squares of 8 halfs: v_dot2_f32_f16 (exact products, fp32 accumulate), 4 instructions
+__device__ __forceinline__ float sq8(half8_t f, float acc) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const half2_t h = {f[2 * j], f[2 * j + 1]};
+        acc = __builtin_amdgcn_fdot2(h, h, acc, false);
+    }
+    return acc;
+}
+
+template <int NT, bool TWO>
+__global__ __launch_bounds__(512) void classify_small_kernel(const half_t* __restrict__ q, const half_t* __restrict__ zi,
+                                                             const half_t* __restrict__ zt, int Q, int N, int D, float alpha,
+                                                             float oma, float beta, float* __restrict__ p,
+                                                             int32_t* __restrict__ argmax, float* __restrict__ topk_p,
+                                                             int32_t* __restrict__ topk_i, int k) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NB = TWO ? 2 : 1, ROWS = NB * NT * 16;
+    const int tid = threadIdx.x, nthreads = blockDim.x, nwaves = nthreads >> 6;
+    const int lane = tid & 63, wave = tid >> 6, qr = lane & 15, kg = lane >> 4;
+    const int units = D >> 3, row_bytes = D * 2 + 16, steps = D >> 5;
+    const int ngroups = (Q + 15) >> 4;
+    int g = blockIdx.x * nwaves + wave;
+    half8_t qf[16];
+    bool have = false;
+    if (g < ngroups) {
+        const int m = g * 16 + qr;
+        const half_t* qrow = q + (size_t)(m < Q ? m : Q - 1) * D + kg * 8;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            if (s < steps) qf[s] = ld_half8(qrow + s * 32);
+        have = true;
+    }
+    {   // banks -> LDS, eight 16-byte units per thread in flight; rows of classes >= N are zero
+        const int total = ROWS * units;
+        const float inv_units = 1.f / (float)units;
+        for (int i0 = tid; i0 < total; i0 += 8 * nthreads) {
+            half8_t v[8];
+            int off[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * nthreads;
+                int r = (int)(((float)i + 0.5f) * inv_units);                       // i / units (i < 2^20: exact after the fix-up)
+                if (r * units > i) --r;
+                if ((r + 1) * units <= i) ++r;
+                const int u = i - r * units, c = r & (NT * 16 - 1) , bk = r / (NT * 16);
+                static_assert((NT & (NT - 1)) == 0, "NT must be a power of two");
+                v[j] = half8_t{};
+                off[j] = i < total ? r * row_bytes + u * 16 : -1;
+                if (i < total && c < N) v[j] = ld_half8((bk ? zt : zi) + (size_t)c * D + u * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (off[j] >= 0) *reinterpret_cast<half8_t*>(smem + off[j]) = v[j];
+        }
+    }
+    __syncthreads();
+    const int cls0 = 4 * kg;                                                          // first class of this lane inside a tile
+    for (; g < ngroups; g += gridDim.x * nwaves) {
+        const int m = g * 16 + qr;
+        const bool mv = m < Q;
+        const half_t* qrow = q + (size_t)(mv ? m : Q - 1) * D + kg * 8;             // clamped: the load stays in bounds, the row is dropped
+        float4_t acc[NB][NT];
+        float zn[NB][NT];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { acc[b][t] = float4_t{0.f, 0.f, 0.f, 0.f}; zn[b][t] = 0.f; }
+        float qs = 0.f;
+        for (int s0 = 0; s0 < steps; s0 += 16) {                                    // 512 k per pass: 16 query loads in flight
+            if (!have) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    if (s0 + s < steps) qf[s] = ld_half8(qrow + (s0 + s) * 32);
+            }
+            have = false;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                if (s0 + s < steps) {
+                    qs = sq8(qf[s], qs);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const half8_t zf = *reinterpret_cast<const half8_t*>(
+                                smem + ((b * NT + t) * 16 + qr) * row_bytes + (s0 + s) * 64 + kg * 16);
+                            zn[b][t] = sq8(zf, zn[b][t]);
+                            acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zf, qf[s], acc[b][t], 0, 0, 0);
+                        }
+                }
+        }
+        qs += __shfl_xor(qs, 16, WAVE);
+        qs += __shfl_xor(qs, 32, WAVE);
+        // cdist epilogue + softmax over the classes of this query (utils.py:225-244), as in sqdist_kernel / fuse_probs_kernel
+        float pr[NT][4];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            float d2[NT][4], mn = __builtin_inff(), mx = -__builtin_inff();
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float zsq = zn[b][t];                                                 // ||z_c||^2 of class t*16 + qr ...
+                zsq += __shfl_xor(zsq, 16, WAVE);
+                zsq += __shfl_xor(zsq, 32, WAVE);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float zs = __shfl(zsq, cls0 + e, WAVE);                     // ... moved to the accumulator layout
+                    const float v = __fadd_rn(__fadd_rn(-2.f * acc[b][t][e], qs), zs);
+                    const float d = sqrtf(fmaxf(v, 0.f));
+                    d2[t][e] = __fmul_rn(d, d);
+                    if (t * 16 + cls0 + e < N) { mn = fminf(mn, d2[t][e]); mx = fmaxf(mx, d2[t][e]); }
+                }
+            }
+            mn = fminf(mn, __shfl_xor(mn, 16, WAVE)); mn = fminf(mn, __shfl_xor(mn, 32, WAVE));
+            mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE)); mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+            const float top = __fmul_rn(beta, beta >= 0.f ? -mn : -mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    d2[t][e] = (t * 16 + cls0 + e < N) ? expf(__fsub_rn(__fmul_rn(beta, -d2[t][e]), top)) : 0.f;
+                    sum += d2[t][e];
+                }
+            sum += __shfl_xor(sum, 16, WAVE);
+            sum += __shfl_xor(sum, 32, WAVE);
+            const float w = b ? oma : alpha;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float term = __fmul_rn(w, __fdiv_rn(d2[t][e], sum));
+                    pr[t][e] = b ? __fadd_rn(pr[t][e], term) : term;
+                }
+        }
+        float best = -1.f;
+        int besti = 0x7fffffff;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = t * 16 + cls0 + e;
+                if (c < N) {
+                    if (p && mv) p[(size_t)m * N + c] = pr[t][e];
+                    if (pr[t][e] > best) { best = pr[t][e]; besti = c; }             // ascending c: first max kept
+                } else {
+                    pr[t][e] = -1.f;
+                }
+            }
+        auto quad_argmax = [&](float& v, int& i) {
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                const float ov = __shfl_xor(v, off, WAVE);
+                const int oi = __shfl_xor(i, off, WAVE);
+                if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+            }
+        };
+        if (argmax) {
+            quad_argmax(best, besti);
+            if (kg == 0 && mv) argmax[m] = besti;
+        }
+        if (topk_p || topk_i) {
+            for (int r = 0; r < k; ++r) {
+                float bv = -2.f;
+                int bi = 0x7fffffff;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (pr[t][e] > bv) { bv = pr[t][e]; bi = t * 16 + cls0 + e; }
+                quad_argmax(bv, bi);
+                if (kg == 0 && mv) {
+                    if (topk_p) topk_p[(size_t)m * k + r] = bv;
+                    if (topk_i) topk_i[(size_t)m * k + r] = bi;
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (t * 16 + cls0 + e == bi) pr[t][e] = -2.f;                 // remove the winner
+            }
+        }
+    }
+}
+
+template <int NT, bool TWO>
+int launch_classify_small(const void* q, const void* zi, const void* zt, int Q, int N, int D, float alpha, float oma, float beta,
+                          float* p, int32_t* argmax, float* topk_p, int32_t* topk_i, int k, int cus, hipStream_t s) {
+    const size_t lds = (size_t)(TWO ? 2 : 1) * NT * 16 * (D * 2 + 16);
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)classify_small_kernel<NT, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            pclip_set_error("pclip_classify_f16: cannot raise the dynamic LDS limit");
+            return PCLIP_E_LAUNCH;
+        }
+        attr = true;
+    }
+    const int ngroups = ceil_div(Q, 16);
+    int wg_per_cu = (int)((size_t)160 * 1024 / lds);
+    if (wg_per_cu > 8) wg_per_cu = 8;
+    const bool spread = ngroups <= 2 * cus * wg_per_cu;          // 2-wave workgroups give every group its own slot at once
+    static int spread_waves = getenv("PCLIP_CLASSIFY_SMALL_WAVES") ? atoi(getenv("PCLIP_CLASSIFY_SMALL_WAVES")) : 4;
+    const int nwaves = spread ? spread_waves : 8;
+    int grid = ceil_div(ngroups, nwaves);
+    if (grid > cus * wg_per_cu) grid = cus * wg_per_cu;
+    classify_small_kernel<NT, TWO><<<grid, nwaves * 64, lds, s>>>((const half_t*)q, (const half_t*)zi, (const half_t*)zt, Q, N, D, alpha,
+                                                                 oma, beta, p, argmax, topk_p, topk_i, k);
+    return pclip_check_launch("classify (small N)");
+}
+
 inline int row_grid(int R, int cap) { int g = ceil_div(R, 4); return g < 1 ? 1 : (g > cap ? cap : g); }
 
 struct SqWs { float *q_sq, *zi_sq, *zt_sq; size_t bytes; };
@@ -498,6 +718,27 @@ extern "C" int pclip_classify_f16(const void* q, const void* zi, const void* zt,
     const size_t need = pclip_workspace_bytes(PCLIP_OP_CLASSIFY, Q, N, D);
     if (ws_bytes < need) { pclip_set_error("pclip_classify_f16: workspace %zu < %zu", ws_bytes, need); return PCLIP_E_WORKSPACE; }
     if (Q == 0) return PCLIP_OK;
+    {   // small class counts: one launch (env PCLIP_CLASSIFY_SMALL=0 switches it off)
+        static int mode = -1, cus = 0;
+        if (mode < 0) {
+            const char* e = getenv("PCLIP_CLASSIFY_SMALL");
+            mode = e ? atoi(e) : 1;
+            cus = pclip_device_cus();
+            if (cus <= 0) cus = 256;
+        }
+        const int nt = N <= 16 ? 1 : 2;
+        const size_t lds = (size_t)(zt ? 2 : 1) * nt * 16 * ((size_t)D * 2 + 16);
+        if (mode > 0 && N > 0 && N <= 32 && D > 0 && D % 32 == 0 && lds <= 150 * 1024 && q && zi && k >= 0 && k <= N && k <= 16 &&
+            ((!topk_p && !topk_i) || k > 0)) {
+            hipStream_t s = (hipStream_t)stream;
+#define PCLIP_SMALL(NT)                                                                                                                   \
+    return zt ? launch_classify_small<NT, true>(q, zi, zt, Q, N, D, alpha, one_minus_alpha, beta, p, argmax, topk_p, topk_i, k, cus, s) \
+              : launch_classify_small<NT, false>(q, zi, zt, Q, N, D, alpha, one_minus_alpha, beta, p, argmax, topk_p, topk_i, k, cus, s)
+            if (nt == 1) { PCLIP_SMALL(1); }
+            PCLIP_SMALL(2);
+#undef PCLIP_SMALL
+        }
+    }
     SqWs w = carve_sq(ws, Q, N);
     const int ldd = padded_ld(N);
     float* d2i = (float*)((char*)ws + w.bytes);

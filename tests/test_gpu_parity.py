@@ -157,6 +157,37 @@ def test_P_against_reference_fixture(ops, name):
     assert (ti.cpu() == ri).float().mean().item() > 0.999                 # ties between ~0 probabilities may reorder
 
 
+@pytest.mark.parametrize("Q,N,D", [(1, 1, 32), (15, 3, 64), (16, 10, 512), (8100, 10, 512), (333, 16, 512), (100, 17, 768),
+                                   (1000, 32, 1024), (77, 31, 96), (500, 37, 512), (260, 47, 512), (129, 64, 512), (50, 64, 1024)])
+@pytest.mark.parametrize("alpha,beta", [(0.5, 12.0), (1.0, 0.7), (0.0, 3.0), (0.3, -2.0)])
+def test_classify_single_launch_small_N(ops, Q, N, D, alpha, beta):
+    """N <= 64 takes the one-launch kernel (classify_small_kernel: banks in LDS, a wave per 16 queries) for N <= 32 by default and
+    for every N <= 64 with PCLIP_CLASSIFY_SMALL=2: same results as the two-stage path (distance rows + softmax pass) up to fp32
+    summation order, p within 1e-5 of the oracle, top-1 / top-k identical wherever the runner-up is not within 1e-6."""
+    q = po.l2norm_rows(torch.from_numpy(synth.normal((Q, D), 21, 0)).half())
+    zi = po.l2norm_rows(torch.from_numpy(synth.normal((N, D), 21, 1)).half() + 0.3 * q[:1])
+    zt = (po.l2norm_rows(torch.from_numpy(synth.normal((N, D), 21, 2)).half()).float() * 1.2).half()    # non-unit bank
+    k = min(3, N)
+    p, am, tp, ti = ops.classify(dev(q), dev(zi), dev(zt), alpha, beta, want_p=True, want_argmax=True, topk=k)
+    p_or = po.P(q, zi, zt, alpha, beta)
+    assert (p.cpu() - p_or).abs().max().item() <= 1e-5
+    top2 = p_or.topk(min(2, N), dim=1)[0]
+    clear = (top2[:, 0] - top2[:, -1] > 1e-6) if N > 1 else torch.ones(Q, dtype=torch.bool)
+    assert torch.equal(am.cpu().long()[clear], p_or.max(1)[1][clear])
+    assert torch.equal(p.cpu().max(1)[1], am.cpu().long())                        # argmax of the p it wrote: first index on ties
+    rv, ri = p_or.topk(k, dim=1)
+    torch.testing.assert_close(tp.cpu(), rv, rtol=0, atol=1e-5)
+    assert torch.equal(tp.cpu()[:, 0], p.cpu().max(1)[0])
+    assert (ti.cpu() == ri).float().mean().item() > 0.99
+    _, am_only, _, _ = ops.classify(dev(q), dev(zi), dev(zt), alpha, beta, want_p=False, want_argmax=True)
+    assert torch.equal(am_only, am)
+    if D % 64 == 0:                                                                # the two-stage entry points need D % 64 == 0
+        d2i, d2t, _ = ops.sqdist(dev(q), dev(zi), dev(zt))
+        p2, am2, _, _ = ops.fuse_probs(d2i, d2t, N, alpha, beta, want_p=True, want_argmax=True)
+        assert (p - p2).abs().max().item() <= 2e-6
+        assert (am != am2).sum().item() <= (~clear).sum().item()
+
+
 def test_fuse_probs_edge_cases(ops):
     Q, N = 70, 130
     d2i = torch.from_numpy(synth.uniform(Q * N, 12, 0).reshape(Q, N)).float() * 4

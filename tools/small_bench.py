@@ -5,7 +5,8 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from proto_clip_amd import ops
 from kernel_bench import timeit
-for name, N, K, D, Q in (("EuroSAT C2", 10, 16, 512, 8100), ("Caltech-101", 100, 16, 1024, 2465), ("FewSOL-198", 198, 16, 768, 666),
+for name, N, K, D, Q in (("EuroSAT C2", 10, 16, 512, 8100), ("OxfordPets", 37, 16, 512, 3669), ("DTD", 47, 16, 512, 1692), ("N=64", 64, 16, 512, 20000),
+                         ("N=24 D=1024", 24, 16, 1024, 20000), ("Caltech-101", 100, 16, 1024, 2465), ("FewSOL-198", 198, 16, 768, 666),
                          ("ImageNet", 1000, 16, 512, 50000)):
     mem = torch.nn.functional.normalize(torch.randn(N * K, D, device="cuda"), dim=-1).half()
     q = torch.nn.functional.normalize(torch.randn(Q, D, device="cuda"), dim=-1).half()
