@@ -13,24 +13,36 @@ struct RowRegs {
 };
 
 template <int NCH>
-__device__ __forceinline__ float load_row_sq(const half_t* xr, int D, int lane, RowRegs<NCH>& r) {
-    float ss = 0.f;
+__device__ __forceinline__ void load_row(const half_t* xr, int D, int lane, RowRegs<NCH>& r) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         int d = c * 512 + lane * 8;
         if (d < D) {
             r.v[c] = ld_half8(xr + d);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float f = (float)r.v[c][j];
-                ss += f * f;
-            }
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) r.v[c][j] = (half_t)0.f;
         }
     }
+}
+
+template <int NCH>
+__device__ __forceinline__ float row_sq(const RowRegs<NCH>& r) {
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = (float)r.v[c][j];
+            ss += f * f;
+        }
     return wave_sum(ss);
+}
+
+template <int NCH>
+__device__ __forceinline__ float load_row_sq(const half_t* xr, int D, int lane, RowRegs<NCH>& r) {
+    load_row<NCH>(xr, D, lane, r);
+    return row_sq<NCH>(r);
 }
 
 // ---- row normalise: y = r16(x / r16(||x||)) ----------------------------------------------------
@@ -135,20 +147,28 @@ __device__ __forceinline__ void class_sum(const half_t* __restrict__ mem, int lo
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[c][j] = 0.f;
-    for (int row = lo + wave; row < hi; row += 4) {
-        RowRegs<NCH> r;
-        float ss = load_row_sq<NCH>(mem + (size_t)row * D, D, lane, r);
-        if (per_shot_norm) {
-            float n = r16(sqrtf(ss));
+    constexpr int PF = NCH <= 2 ? 4 : 2;                 // rows of one wave in flight: the loop is a latency chain otherwise
+    for (int row0 = lo + wave; row0 < hi; row0 += 4 * PF) {
+        RowRegs<NCH> rr[PF];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c)
+        for (int u = 0; u < PF; ++u)
+            if (row0 + 4 * u < hi) load_row<NCH>(mem + (size_t)(row0 + 4 * u) * D, D, lane, rr[u]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[c][j] += r16((float)r.v[c][j] / n);
-        } else {
+        for (int u = 0; u < PF; ++u) {
+            if (row0 + 4 * u >= hi) break;
+            const RowRegs<NCH>& r = rr[u];
+            if (per_shot_norm) {
+                float n = r16(sqrtf(row_sq<NCH>(r)));
 #pragma unroll
-            for (int c = 0; c < NCH; ++c)
+                for (int c = 0; c < NCH; ++c)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[c][j] += (float)r.v[c][j];
+                    for (int j = 0; j < 8; ++j) acc[c][j] += r16((float)r.v[c][j] / n);
+            } else {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[c][j] += (float)r.v[c][j];
+            }
         }
     }
 #pragma unroll
