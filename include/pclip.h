@@ -141,6 +141,19 @@ int pclip_adapter_conv_f16(const void* x, int B, int D, int three_x, const void*
 int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                    const void* bias, int act, const void* residual, pclip_stream_t stream);
 
+/* The same linear for SMALL M (a serving request: M = 197 x batch rows; the class-token tail of the last block: M = batch),
+ * where pclip_gemm_f16 has a dozen tiles for 256 CUs and a K-loop of 12 - 48 dependent round trips: the K range is cut into
+ * up to 8 slices (a function of K only), one workgroup per (128 x 64 tile, slice) writing an fp32 slab into ws; a second launch
+ * adds the slabs in slice order (deterministic) and applies bias / act.  Same arithmetic as pclip_gemm_f16 up to fp32 summation
+ * order (no residual operand).
+ *   pclip_gemm_splitk_workspace: bytes of `ws` for this shape on the current device, or 0 when the shape gains nothing
+ *     (enough tiles, K < 512, N % 64 != 0) — then call pclip_gemm_f16.
+ * Replaces the same nn.Linear call sites as pclip_gemm_f16 (clip/model.py:176-190, 236-238) on the serving path
+ * (toolkit proto_clip_classifier.py:132-158). */
+size_t pclip_gemm_splitk_workspace(int M, int N, int K);
+int pclip_gemm_splitk_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                          const void* bias, int act, void* ws, size_t ws_bytes, pclip_stream_t stream);
+
 /* Convolution-as-GEMM with the eval-mode BatchNorm (+ReLU) that follows it in the ModifiedResNet tower (clip/model.py:43-52,
  * 138-142): C = relu?( r16( r16(A B^T) * scale[n] + shift[n] ) ), scale/shift fp32 [N] = the folded running statistics and
  * affine.  Same rounding points as conv (fp16 tensor) followed by pclip_bn_act_f16. */

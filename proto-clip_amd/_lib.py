@@ -43,6 +43,8 @@ _SIGS = {
                              c_size_t, _P],
     "pclip_adapter_conv_f16": [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P],
     "pclip_gemm_f16": [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P],
+    "pclip_gemm_splitk_workspace": [c_int, c_int, c_int],
+    "pclip_gemm_splitk_f16": [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_size_t, _P],
     "pclip_gemm_bn_f16": [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P],
     "pclip_conv3x3_bn_f16": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P],
     "pclip_layernorm_f16": [_P, c_int, _P, _P, c_float, _P, c_int, c_int, _P],
@@ -74,7 +76,7 @@ _SIGS = {
     "pclip_preprocess_u8": [_P, _P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, _P, c_int, _P, _P],
     "pclip_workspace_bytes": [c_int, c_int, c_int, c_int],
 }
-_RESTYPES = {"pclip_last_error": c_char_p, "pclip_workspace_bytes": c_size_t, "pclip_gemm_kernel_launches": c_long}
+_RESTYPES = {"pclip_last_error": c_char_p, "pclip_workspace_bytes": c_size_t, "pclip_gemm_splitk_workspace": c_size_t, "pclip_gemm_kernel_launches": c_long}
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
 

@@ -831,6 +831,131 @@ extern "C" int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, vo
     return gemm_dispatch((const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, cus, forced, !nosplit, (hipStream_t)stream);
 }
 
+namespace {
+// ---- split-K for small M (serving: M = 197 x batch rows, the class-token tail: M = batch) ------------------------------------
+// A request of a few images gives every encoder linear 12 - 48 output tiles for 256 CUs and a K-loop of 12 - 48 dependent
+// LDS-DMA round trips (c_proj at M = 197: 12 workgroups x 48 K-tiles = 50 us).  Here the K range is cut into S slices, one
+// workgroup per (128 x 64 tile, slice), each writing its fp32 accumulators (valid rows only) as a [S][M][N] slab; a second,
+// fully parallel launch adds the S slabs in slice order (deterministic), applies bias / QuickGELU and stores fp16.  The slabs
+// are 32 KB per (tile, slice) — far beyond what a last-arriver reduction inside the first launch handles well (a first
+// version with device-scope fences + a tile counter measured 3x SLOWER than the unsplit kernel: every workgroup's release
+// writes back its XCD's L2) — so the combine sits at the launch boundary (guide §5: "combine in the next kernel").
+using CfgSplit = pgemm::Cfg<128, 64, 2, 2>;
+
+__global__ __launch_bounds__(CfgSplit::NTHREADS, 2) void linear_splitk_kernel(const half_t* __restrict__ A, int lda,
+                                                                            const half_t* __restrict__ B, int ldb, int M, int N,
+                                                                            int K, int tiles_n, int S, int steps_per,
+                                                                            float* __restrict__ ws) {
+    using C = CfgSplit;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tile = blockIdx.x / S, ks = blockIdx.x - tile * S;
+    const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+    const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
+    const int k0 = ks * steps_per * pgemm::BK;
+    const int klen = (K - k0 < steps_per * pgemm::BK) ? K - k0 : steps_per * pgemm::BK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave / C::WN, wn = wave % C::WN;
+    pgemm::Acc<C> acc;
+    int p = 0;
+    pgemm::stage_first<C>(A + k0, lda, B + k0, ldb, M, N, m0, n0, smem, p);
+    pgemm::mainloop<C, 0, true, true>(A + k0, lda, B + k0, ldb, M, N, klen, m0, n0, smem, acc, p);
+    // 16x16x32 accumulator layout: element group (i, j, g) of a lane = row wm*64 + i*32 + (g>>1)*16 + (lane&15),
+    // columns wn*32 + j*32 + (g&1)*16 + 4*(lane>>4) .. +3
+    float* slab = ws + (size_t)ks * M * N;
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int m = m0 + wm * (C::BM / C::WM) + i * 32 + (g >> 1) * 16 + (lane & 15);
+                const int n = n0 + wn * (C::BN / C::WN) + j * 32 + (g & 1) * 16 + 4 * (lane >> 4);
+                if (m < M)
+                    *reinterpret_cast<float4_t*>(slab + (size_t)m * N + n) =
+                        float4_t{acc.v[i][j][4 * g], acc.v[i][j][4 * g + 1], acc.v[i][j][4 * g + 2], acc.v[i][j][4 * g + 3]};
+            }
+}
+
+// out[m, n .. n+7] = act(sum_s slab[s][m][n ..] + bias[n ..]) — slices added in order, one thread per 8 columns
+template <int ACT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, int M, int N,
+                                                            const half_t* __restrict__ bias, half_t* __restrict__ Cout, int ldc) {
+    const int cpr = N >> 3;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)M * cpr) return;
+    const int m = (int)(idx / cpr), n = (int)(idx - (size_t)m * cpr) * 8;
+    const float* src = ws + (size_t)m * N + n;
+    const size_t slab = (size_t)M * N;
+    float4_t lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+#pragma unroll 8
+    for (int s = 0; s < S; ++s) {
+        lo += *reinterpret_cast<const float4_t*>(src + s * slab);
+        hi += *reinterpret_cast<const float4_t*>(src + s * slab + 4);
+    }
+    if (bias) {
+        const half8_t b = ld_half8(bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo[e] += (float)b[e]; hi[e] += (float)b[e + 4]; }
+    }
+    half4_t h0, h1;
+    if (ACT == 1) { h0 = quick_gelu16x4(lo); h1 = quick_gelu16x4(hi); }
+    else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h0[e] = (half_t)lo[e]; h1[e] = (half_t)hi[e]; }
+    }
+    st_half8(Cout + (size_t)m * ldc + n, half8_t{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]});
+}
+
+struct SplitPlan { int tiles_m, tiles_n, S, steps_per; size_t bytes; };
+// The slicing depends on K ONLY (up to 8 slices of >= 2 K-tiles), so that a row's result does not depend on how many other rows
+// the call carries; M and N only decide whether the split is used at all: few tiles for the chip, a K-loop long enough to cut.
+inline SplitPlan splitk_plan(int M, int N, int K, int cus) {
+    SplitPlan pl{0, 0, 0, 0, 0};
+    if (M <= 0 || N <= 0 || K <= 0 || N % CfgSplit::BN || K % pgemm::BK) return pl;
+    pl.tiles_m = ceil_div(M, CfgSplit::BM);
+    pl.tiles_n = N / CfgSplit::BN;
+    const int tiles = pl.tiles_m * pl.tiles_n, steps = K / pgemm::BK;
+    if (steps < 8) return pl;
+    pl.steps_per = steps / 8 > 2 ? steps / 8 : 2;
+    pl.S = ceil_div(steps, pl.steps_per);
+    pl.bytes = (size_t)pl.S * M * N * sizeof(float);
+    // measured model (tools/splitk_bench.py, us): unsplit = 2 + 0.7 per K-tile (one round of tiles, a dependent LDS-DMA round trip
+    // each); split = 5 (two launches) + 0.7 per K-tile of a slice + the slabs written and read back at ~3 TB/s
+    const double t_unsplit = 2.0 + 0.7 * steps, t_split = 5.0 + 0.7 * pl.steps_per + 2.0 * (double)pl.bytes / 3.0e6;
+    if (tiles > cus || tiles * pl.S > 4 * cus || t_split + 1.0 > t_unsplit) { pl.S = 0; pl.bytes = 0; return pl; }
+    return pl;
+}
+
+}  // namespace
+
+extern "C" size_t pclip_gemm_splitk_workspace(int M, int N, int K) {
+    int cus = pclip_device_cus();
+    if (cus <= 0) cus = 256;
+    return splitk_plan(M, N, K, cus).bytes;
+}
+
+extern "C" int pclip_gemm_splitk_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                                     const void* bias, int act, void* ws, size_t ws_bytes, pclip_stream_t stream) {
+    PCLIP_REQUIRE(A && B && C && ws, "pclip_gemm_splitk_f16: null pointer");
+    PCLIP_REQUIRE(act == 0 || act == 1, "pclip_gemm_splitk_f16: unknown activation %d", act);
+    PCLIP_REQUIRE(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0, "pclip_gemm_splitk_f16: bad leading dims");
+    PCLIP_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)C & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) &&
+                      ((uintptr_t)ws & 15) == 0, "pclip_gemm_splitk_f16: operands must be 16-byte aligned");
+    int cus = pclip_device_cus();
+    if (cus <= 0) cus = 256;
+    const SplitPlan pl = splitk_plan(M, N, K, cus);
+    PCLIP_REQUIRE(pl.S >= 2, "pclip_gemm_splitk_f16: shape M=%d N=%d K=%d is not a split-K shape (pclip_gemm_splitk_workspace == 0)", M, N, K);
+    if (ws_bytes < pl.bytes) { pclip_set_error("pclip_gemm_splitk_f16: workspace %zu < %zu", ws_bytes, pl.bytes); return PCLIP_E_WORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    linear_splitk_kernel<<<pl.tiles_m * pl.tiles_n * pl.S, CfgSplit::NTHREADS, CfgSplit::LDS_BYTES, s>>>(
+        (const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, pl.tiles_n, pl.S, pl.steps_per, (float*)ws);
+    const int rgrid = (int)(((size_t)M * (N / 8) + 255) / 256);
+    if (act == 1)
+        splitk_reduce_kernel<1><<<rgrid, 256, 0, s>>>((const float*)ws, pl.S, M, N, (const half_t*)bias, (half_t*)C, ldc);
+    else
+        splitk_reduce_kernel<0><<<rgrid, 256, 0, s>>>((const float*)ws, pl.S, M, N, (const half_t*)bias, (half_t*)C, ldc);
+    return pclip_check_launch("gemm_f16 (split-K)");
+}
+
 extern "C" int pclip_gemm_bn_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                                  const float* scale, const float* shift, int relu, pclip_stream_t stream) {
     PCLIP_REQUIRE(A && B && C && scale && shift, "pclip_gemm_bn_f16: null pointer");

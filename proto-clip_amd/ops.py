@@ -2,6 +2,7 @@
 and streams; every arithmetic step below is a libpclip kernel.  All functions require CUDA (ROCm)
 tensors and raise PclipError otherwise — there is deliberately no CPU path."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -247,9 +248,42 @@ def gemm(a, w, bias=None, act: int = 0, residual=None, out=None):
     N = w.shape[0]
     if out is None:
         out = torch.empty(M, N, dtype=torch.float16, device=a.device)
-    check(_lib.load().pclip_gemm_f16(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(out), out.stride(0), M, N, K,
-                                     ptr(bias), act, ptr(residual), stream()), "pclip_gemm_f16")
+    lib = _lib.load()
+    if residual is None and M <= _SPLITK_MAX_M and _SPLITK:
+        need = lib.pclip_gemm_splitk_workspace(M, N, K)
+        if need and a.stride(0) % 8 == 0 and w.stride(0) % 8 == 0 and out.stride(0) % 8 == 0 and \
+                not ((a.data_ptr() | w.data_ptr() | out.data_ptr()) & 15) and (bias is None or not (bias.data_ptr() & 15)):
+            ws = _workspace(need, a.device)
+            check(lib.pclip_gemm_splitk_f16(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(out), out.stride(0), M, N, K, ptr(bias), act,
+                                            ptr(ws), ws.numel(), stream()), "pclip_gemm_splitk_f16")
+            return out
+    check(lib.pclip_gemm_f16(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(out), out.stride(0), M, N, K,
+                             ptr(bias), act, ptr(residual), stream()), "pclip_gemm_f16")
     return out
+
+
+# split-K for small M (serving requests).  Opt-in (`with ops.low_latency():`, or PCLIP_GEMM_SPLITK=1): a split call sums K in
+# slices, so its last fp16 bit can differ from the unsplit kernel's — the batch paths keep one arithmetic for every batch size,
+# the serving entry takes the latency.
+_SPLITK = os.environ.get("PCLIP_GEMM_SPLITK", "0") == "1"
+_SPLITK_MAX_M = 4096
+
+
+class low_latency:
+    """Context manager: inside it, ops.gemm uses pclip_gemm_splitk_f16 for the shapes pclip_gemm_splitk_workspace accepts."""
+
+    def __init__(self, enabled: bool = True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        global _SPLITK
+        self.prev, _SPLITK = _SPLITK, self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        global _SPLITK
+        _SPLITK = self.prev
+        return False
 
 
 def gemm_bn(a, w, scale, shift, relu: bool = True, out=None):

@@ -50,8 +50,9 @@ def load_pretrained_mb_and_adapters(config=None, memory_bank_v_path=None, memory
 class ProtoClipClassifier:
     """classify(images [B,3,R,R]) -> (top-k probabilities [B,k] fp32, top-k class indices [B,k] int64)."""
 
-    def __init__(self, clip_model, embeddings_v, embeddings_t, adapter, shots, alpha, beta, top_k=5, class_names=None):
+    def __init__(self, clip_model, embeddings_v, embeddings_t, adapter, shots, alpha, beta, top_k=5, class_names=None, low_latency=True):
         self.clip_model, self.adapter = clip_model, adapter
+        self.low_latency = bool(low_latency)       # split-K linears for small requests (ops.low_latency)
         self.alpha, self.beta, self.top_k = float(alpha), float(beta), int(top_k)
         self.class_names = class_names
         NxK = embeddings_v.shape[0]
@@ -62,7 +63,7 @@ class ProtoClipClassifier:
         self._graphs = {}
 
     def _forward(self, images):
-        with torch.no_grad():
+        with torch.no_grad(), ops.low_latency(self.low_latency):
             f = self.clip_model.encode_image(images)                       # model_utils.py:75-77
             f = ops.l2norm_rows(f, out=f)
             a, a_sq = self.adapter_forward(f)                              # proto_clip_classifier.py:141-142

@@ -70,6 +70,56 @@ def test_gemm_row_split(ops, M, N, K):
         assert launches == 2                                # 2 full rounds of 256x256 tiles + the last 6912 rows
 
 
+@pytest.mark.parametrize("M,N,K,act", [(197, 768, 768, 0), (8, 2304, 768, 0), (1, 3072, 768, 1), (197, 768, 3072, 0), (1, 768, 3072, 0),
+                                        (32, 512, 768, 0), (788, 768, 3072, 0), (64, 768, 768, 1), (257, 1024, 4096, 0), (130, 64, 512, 1)])
+def test_gemm_splitk_small_M(ops, M, N, K, act):
+    """Serving shapes through pclip_gemm_splitk_f16 (K cut into slices, a second launch adds the slabs in slice order):
+    within 1 fp16 ulp of the fp32 reference like the unsplit kernel (3 with QuickGELU), deterministic (bit-identical runs),
+    rows beyond M untouched, the slicing independent of M (a row alone == the row in the batch),
+    and EXACT on integer-valued operands (any dropped / doubled slice or misplaced register group shows)."""
+    lib = ops._lib.load()
+    need = lib.pclip_gemm_splitk_workspace(M, N, K)
+    assert need > 0, "shape should be a split-K shape on this device"
+    a = (torch.from_numpy(synth.normal((M, K), 31, 0)).float() * 0.5).half().cuda()
+    w = (torch.from_numpy(synth.normal((N, K), 31, 1)).float() * K ** -0.5).half().cuda()
+    bias = (torch.from_numpy(synth.normal((N,), 31, 2)).float() * 0.1).half().cuda()
+    h = po.r16(a.float().cpu() @ w.float().cpu().t() + bias.float().cpu())
+    ref = po.r16(h * po.r16(torch.sigmoid(po.r16(1.702 * h)))) if act else h
+    out = torch.full((M + 3, N), 7.0, dtype=torch.float16, device="cuda")
+    with ops.low_latency():
+        y = ops.gemm(a, w, bias, act, None, out[:M])
+        assert ulp_diff(y.cpu(), ref.half()) <= (3 if act else 1)
+        assert (out[M:] == 7.0).all()
+        y2 = ops.gemm(a, w, bias, act)
+        assert torch.equal(y2, y)
+        r = M // 2
+        y1 = ops.gemm(a[r:r + 1].contiguous(), w, bias, act)
+        if lib.pclip_gemm_splitk_workspace(1, N, K):
+            assert torch.equal(y1[0], y[r])
+        ai = (torch.arange(M * K, device="cuda").reshape(M, K) % 5 - 2).half()
+        wi = (torch.arange(N * K, device="cuda").reshape(N, K) % 3 - 1).half()
+        assert torch.equal(ops.gemm(ai, wi).float(), (ai.float() @ wi.float().t()).half().float())
+    unsplit = ops.gemm(a, w, bias, act)                     # outside the context: the persistent kernel
+    assert ulp_diff(unsplit.cpu(), y.cpu()) <= (3 if act else 1)
+
+
+def test_gemm_splitk_refusals(ops):
+    lib = ops._lib.load()
+    assert lib.pclip_gemm_splitk_workspace(50432, 768, 768) == 0        # plenty of tiles: the persistent kernel's shape
+    assert lib.pclip_gemm_splitk_workspace(197, 768, 128) == 0          # K too short to cut
+    assert lib.pclip_gemm_splitk_workspace(197, 100, 768) == 0          # N % 64 != 0
+    assert lib.pclip_gemm_splitk_workspace(197, 3072, 768) == 0         # slab traffic would cost more than the K-loop it saves
+    a = torch.zeros(197, 768, dtype=torch.float16, device="cuda")
+    w = torch.zeros(768, 768, dtype=torch.float16, device="cuda")
+    out = torch.empty(197, 768, dtype=torch.float16, device="cuda")
+    ws = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    from proto_clip_amd._lib import ptr, stream
+    rc = lib.pclip_gemm_splitk_f16(ptr(a), 768, ptr(w), 768, ptr(out), 768, 197, 768, 768, None, 0, ptr(ws), ws.numel(), stream())
+    assert rc == -3 and b"workspace" in lib.pclip_last_error()
+    rc = lib.pclip_gemm_splitk_f16(ptr(a), 768, ptr(w), 768, ptr(out), 768, 50432, 768, 768, None, 0, ptr(ws), ws.numel(), stream())
+    assert rc == -1
+
+
 @pytest.mark.parametrize("R,D", [(7, 64), (500, 768), (197, 1024), (3, 512)])
 def test_layernorm(ops, R, D):
     x = (torch.from_numpy(synth.normal((R, D), 22, 0)).float() * 2 + 0.3).half()
@@ -246,7 +296,7 @@ def test_serving_entry_eager_and_graph(ops, tmp_path):
     tp, ti = clf.classify(imgs)
     assert tp.shape == (4, 3) and ti.shape == (4, 3) and ti.dtype == torch.int64
     # oracle on the GPU's own adapted features isolates the classification arithmetic
-    with torch.no_grad():
+    with torch.no_grad(), ops.low_latency():              # the serving entry runs its linears in low-latency (split-K) mode
         f = ops.l2norm_rows(model.encode_image(imgs))
         a = adapter(f, l2norm_out=True)
     p = po.P(a.cpu(), po.proto_build(emb_v, N, K), po.l2norm_rows(emb_t), 0.3, 7.0)
