@@ -761,9 +761,16 @@ inline int best_cfg(long M, int N, int cus, double* cost_out) {
     return pick;
 }
 
+// fewer 128x64 tiles than CUs: the latency-oriented ring kernel (defined below), bit-identical to the persistent kernels
+bool small_applies(int M, int N, int cus);
+int launch_small_one(const half_t* A, int lda, const half_t* B, int ldb, int M, int N, int K, const LinearEpi& epi, hipStream_t s);
+
 int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int N, int K, LinearEpi epi, int cus, int forced,
                   bool may_split, hipStream_t s) {
     const bool aligned = !epi.residual && epi.ldc % 8 == 0 && ((uintptr_t)epi.C & 15) == 0 && (!epi.bias || ((uintptr_t)epi.bias & 15) == 0);
+    static const bool small_on = !(getenv("PCLIP_GEMM_SMALL") && getenv("PCLIP_GEMM_SMALL")[0] == '0');
+    if (aligned && forced == -1 && small_on && epi.act <= 1 && small_applies(M, N, cus))
+        return launch_small_one(A, lda, B, ldb, M, N, K, epi, s);
     double cost = 1e30;
     int pick = aligned ? best_cfg(M, N, cus, &cost) : -1;
     if (forced == -2) { may_split = false; pick = -1; }        // generic kernel
@@ -840,12 +847,18 @@ namespace {
 // are 32 KB per (tile, slice) — far beyond what a last-arriver reduction inside the first launch handles well (a first
 // version with device-scope fences + a tile counter measured 3x SLOWER than the unsplit kernel: every workgroup's release
 // writes back its XCD's L2) — so the combine sits at the launch boundary (guide §5: "combine in the next kernel").
-using CfgSplit = pgemm::Cfg<128, 64, 2, 2>;
+using CfgSplit = pgemm::Cfg<128, 64, 4, 2>;       // 8 waves x 32x32: two waves per SIMD share the DMA set-up and the MFMAs of a K-tile
 
-__global__ __launch_bounds__(CfgSplit::NTHREADS, 2) void linear_splitk_kernel(const half_t* __restrict__ A, int lda,
-                                                                            const half_t* __restrict__ B, int ldb, int M, int N,
-                                                                            int K, int tiles_n, int S, int steps_per,
-                                                                            float* __restrict__ ws) {
+constexpr int kSmallStages = 4;                             // 6 slots measured no faster (7.5 vs 7.1 us at 12 K-tiles): not latency-limited any more
+constexpr int kSmallLds = kSmallStages * CfgSplit::STAGE_BYTES;        // the K-tile ring of pgemm::mainloop_ring (96 KiB)
+
+// S > 1: slice ks of the K range -> fp32 slab.  S == 1: the whole K range, bias / QuickGELU and the fp16 store right here.
+template <int ACT>
+__global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void linear_small_kernel(const half_t* __restrict__ A, int lda,
+                                                                           const half_t* __restrict__ B, int ldb, int M, int N,
+                                                                           int K, int tiles_n, int S, int steps_per,
+                                                                           float* __restrict__ ws, const half_t* __restrict__ bias,
+                                                                           half_t* __restrict__ Cout, int ldc) {
     using C = CfgSplit;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = blockIdx.x / S, ks = blockIdx.x - tile * S;
@@ -853,11 +866,37 @@ __global__ __launch_bounds__(CfgSplit::NTHREADS, 2) void linear_splitk_kernel(co
     const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
     const int k0 = ks * steps_per * pgemm::BK;
     const int klen = (K - k0 < steps_per * pgemm::BK) ? K - k0 : steps_per * pgemm::BK;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave / C::WN, wn = wave % C::WN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / C::WN, wn = wave % C::WN;
     pgemm::Acc<C> acc;
-    int p = 0;
-    pgemm::stage_first<C>(A + k0, lda, B + k0, ldb, M, N, m0, n0, smem, p);
-    pgemm::mainloop<C, 0, true, true>(A + k0, lda, B + k0, ldb, M, N, klen, m0, n0, smem, acc, p);
+    // S == 1: the bias is the accumulators' initial value exactly as in linear_fast_kernel -> the same bits as that kernel
+    pgemm::mainloop_ring<C, kSmallStages>(A + k0, lda, B + k0, ldb, M, N, klen / pgemm::BK, m0, n0, smem, acc, [&]() {
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                half4_t b = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+                if (S == 1 && bias) b = *reinterpret_cast<const half4_t*>(bias + n0 + wn * (C::BN / C::WN) + j * 32 + (g & 1) * 16 + 4 * (lane >> 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < C::TM; ++i) acc.v[i][j][4 * g + e] = (float)b[e];
+            }
+    });
+    if (S == 1) {
+        const int col = n0 + 8 * (tid % C::CPR);
+        auto pre = [&](int, int, int, float4_t v) {
+            if (ACT == 1) return quick_gelu16x4(v);
+            half4_t h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
+            return h;
+        };
+        // slot 0 of the ring is the staging buffer: the epilogue's first barrier comes after every wave's last K-tile
+        pgemm::epilogue_f16<C, true>(acc, smem, [](int) {}, pre, [&](int r, int, int, half8_t h) {
+            if (m0 + r < M) st_half8(Cout + (size_t)(m0 + r) * ldc + col, h);
+        });
+        return;
+    }
     // 16x16x32 accumulator layout: element group (i, j, g) of a lane = row wm*64 + i*32 + (g>>1)*16 + (lane&15),
     // columns wn*32 + j*32 + (g&1)*16 + 4*(lane>>4) .. +3
     float* slab = ws + (size_t)ks * M * N;
@@ -905,6 +944,34 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     st_half8(Cout + (size_t)m * ldc + n, half8_t{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]});
 }
 
+inline int small_attr() {
+    static bool done = false;
+    if (!done) {
+        if (hipFuncSetAttribute((const void*)linear_small_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmallLds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)linear_small_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmallLds) != hipSuccess) {
+            pclip_set_error("gemm_f16 (small M): cannot raise the dynamic LDS limit to %d", kSmallLds);
+            return PCLIP_E_LAUNCH;
+        }
+        done = true;
+    }
+    return PCLIP_OK;
+}
+
+bool small_applies(int M, int N, int cus) {
+    return M > 0 && N % CfgSplit::BN == 0 && (long)ceil_div(M, CfgSplit::BM) * (N / CfgSplit::BN) <= cus;
+}
+
+int launch_small_one(const half_t* A, int lda, const half_t* B, int ldb, int M, int N, int K, const LinearEpi& epi, hipStream_t s) {
+    if (int e = small_attr()) return e;
+    const int tiles_n = N / CfgSplit::BN, grid = ceil_div(M, CfgSplit::BM) * tiles_n, steps = K / pgemm::BK;
+    ++g_gemm_launches;
+    if (epi.act == 1)
+        linear_small_kernel<1><<<grid, CfgSplit::NTHREADS, kSmallLds, s>>>(A, lda, B, ldb, M, N, K, tiles_n, 1, steps, nullptr, epi.bias, epi.C, epi.ldc);
+    else
+        linear_small_kernel<0><<<grid, CfgSplit::NTHREADS, kSmallLds, s>>>(A, lda, B, ldb, M, N, K, tiles_n, 1, steps, nullptr, epi.bias, epi.C, epi.ldc);
+    return pclip_check_launch("gemm_f16 (small M)");
+}
+
 struct SplitPlan { int tiles_m, tiles_n, S, steps_per; size_t bytes; };
 // The slicing depends on K ONLY (up to 8 slices of >= 2 K-tiles), so that a row's result does not depend on how many other rows
 // the call carries; M and N only decide whether the split is used at all: few tiles for the chip, a K-loop long enough to cut.
@@ -918,10 +985,11 @@ inline SplitPlan splitk_plan(int M, int N, int K, int cus) {
     pl.steps_per = steps / 8 > 2 ? steps / 8 : 2;
     pl.S = ceil_div(steps, pl.steps_per);
     pl.bytes = (size_t)pl.S * M * N * sizeof(float);
-    // measured model (tools/splitk_bench.py, us): unsplit = 2 + 0.7 per K-tile (one round of tiles, a dependent LDS-DMA round trip
-    // each); split = 5 (two launches) + 0.7 per K-tile of a slice + the slabs written and read back at ~3 TB/s
-    const double t_unsplit = 2.0 + 0.7 * steps, t_split = 5.0 + 0.7 * pl.steps_per + 2.0 * (double)pl.bytes / 3.0e6;
-    if (tiles > cus || tiles * pl.S > 4 * cus || t_split + 1.0 > t_unsplit) { pl.S = 0; pl.bytes = 0; return pl; }
+    // measured model (tools/splitk_bench.py, us): one launch of the ring kernel = 3 + 0.34 per K-tile; split = 4.5 (two launches)
+    // + 0.34 per K-tile of a slice + the slabs written and read back at ~3 TB/s
+    static const int always = getenv("PCLIP_SPLITK_ALWAYS") ? atoi(getenv("PCLIP_SPLITK_ALWAYS")) : 0;
+    const double t_one = 3.0 + 0.34 * steps, t_split = 4.5 + 0.34 * pl.steps_per + 2.0 * (double)pl.bytes / 3.0e6;
+    if (tiles > cus || tiles * pl.S > 4 * cus || (!always && t_split + 0.5 > t_one)) { pl.S = 0; pl.bytes = 0; return pl; }
     return pl;
 }
 
@@ -946,8 +1014,9 @@ extern "C" int pclip_gemm_splitk_f16(const void* A, int lda, const void* B, int 
     PCLIP_REQUIRE(pl.S >= 2, "pclip_gemm_splitk_f16: shape M=%d N=%d K=%d is not a split-K shape (pclip_gemm_splitk_workspace == 0)", M, N, K);
     if (ws_bytes < pl.bytes) { pclip_set_error("pclip_gemm_splitk_f16: workspace %zu < %zu", ws_bytes, pl.bytes); return PCLIP_E_WORKSPACE; }
     hipStream_t s = (hipStream_t)stream;
-    linear_splitk_kernel<<<pl.tiles_m * pl.tiles_n * pl.S, CfgSplit::NTHREADS, CfgSplit::LDS_BYTES, s>>>(
-        (const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, pl.tiles_n, pl.S, pl.steps_per, (float*)ws);
+    if (int e = small_attr()) return e;
+    linear_small_kernel<0><<<pl.tiles_m * pl.tiles_n * pl.S, CfgSplit::NTHREADS, kSmallLds, s>>>(
+        (const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, pl.tiles_n, pl.S, pl.steps_per, (float*)ws, nullptr, nullptr, 0);
     const int rgrid = (int)(((size_t)M * (N / 8) + 255) / 256);
     if (act == 1)
         splitk_reduce_kernel<1><<<rgrid, 256, 0, s>>>((const float*)ws, pl.S, M, N, (const half_t*)bias, (half_t*)C, ldc);

@@ -250,6 +250,71 @@ struct ConvGather {
     }
 };
 
+// ---- latency-oriented K-loop: an NS-slot ring of K-tiles, NS-1 LDS-DMA stages in flight -------------------------------
+// For launches with fewer tiles than CUs (a serving request) the double-buffered loop above is a chain of dependent round
+// trips (~0.7 us per K-tile).  Here K-tiles t+1 .. t+NS-1 are in flight while tile t is multiplied (Little: a K-tile every
+// latency / (NS-1)); every wave issues the same number of LDS-DMA instructions per stage (PER), so the wait before tile t
+// is a counted vmcnt(stages still allowed in flight x PER).  16x16x32 MFMAs, same fragment order as mainloop_g's M16 branch
+// (bit-identical accumulation).  `init()` runs after the first NS-1 stages are on their way and sets the accumulators (zero,
+// or the bias as in linear_fast_kernel: its loads overlap the stages' latency).
+template <class C, int NS, class Init>
+__device__ __forceinline__ void mainloop_ring(const half_t* __restrict__ A, int lda, const half_t* __restrict__ B, int ldb, int M,
+                                              int N, int nt, int m0, int n0, char* smem, Acc<C>& acc, const Init& init) {
+    constexpr int PER = (C::BM + C::BN) / (8 * C::NWAVES);          // LDS-DMA instructions per wave per stage
+    static_assert(NS >= 3 && NS <= 6 && (NS - 2) * PER < 64, "ring depth / vmcnt range");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    auto stage = [&](int t, int slot) {
+        char* a = smem + slot * C::STAGE_BYTES;
+        stage_tile<C::BM, C::NWAVES>(A, lda, m0, M, t * BK, a, wave, lane);
+        stage_tile<C::BN, C::NWAVES>(B, ldb, n0, N, t * BK, a + C::A_BYTES, wave, lane);
+    };
+    for (int t = 0; t < NS - 1 && t < nt; ++t) stage(t, t);
+    init();
+    int slot = 0, fill = NS - 1;                                    // slot of tile t; slot of tile t + NS - 1
+    for (int t = 0; t < nt; ++t) {
+        const int ahead = nt - 1 - t;                               // younger stages already issued: min(ahead, NS - 2)
+        if (NS >= 6 && ahead >= 4) wait_vm<4 * PER>();
+        else if (NS >= 5 && ahead >= 3) wait_vm<3 * PER>();
+        else if (NS >= 4 && ahead >= 2) wait_vm<2 * PER>();
+        else if (ahead >= 1) wait_vm<PER>();
+        else wait_vm<0>();
+        lds_barrier();                                              // tile t visible; the slot of tile t-1 is free (everyone is past it)
+        if (t + NS - 1 < nt) stage(t + NS - 1, fill);
+        fill = slot;                                                // next iteration refills the slot being consumed now
+        const char* la = smem + slot * C::STAGE_BYTES;
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        const char* lb = la + C::A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            const int kc = ks * 4 + (lane >> 4);
+            half8_t af[C::TM][2], bf[C::TN][2];
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) af[i][a] = lds_frag(la, wm * (C::BM / C::WM) + i * 32 + a * 16 + (lane & 15), kc);
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) bf[j][b] = lds_frag(lb, wn * (C::BN / C::WN) + j * 32 + b * 16 + (lane & 15), kc);
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            float4_t c = {acc.v[i][j][(a * 2 + b) * 4], acc.v[i][j][(a * 2 + b) * 4 + 1], acc.v[i][j][(a * 2 + b) * 4 + 2],
+                                          acc.v[i][j][(a * 2 + b) * 4 + 3]};
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][b], af[i][a], c, 0, 0, 0);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc.v[i][j][(a * 2 + b) * 4 + r] = c[r];
+                        }
+        }
+    }
+}
+
 // ---- fp16 output through an LDS-staged, fully coalesced epilogue -----------------------------------------
 // The BM x BN tile leaves in NH slabs of HR = 128 rows.  For slab h:
 //  step 0 `slab(h)`: caller hook before the slab is staged;

@@ -70,8 +70,8 @@ def test_gemm_row_split(ops, M, N, K):
         assert launches == 2                                # 2 full rounds of 256x256 tiles + the last 6912 rows
 
 
-@pytest.mark.parametrize("M,N,K,act", [(197, 768, 768, 0), (8, 2304, 768, 0), (1, 3072, 768, 1), (197, 768, 3072, 0), (1, 768, 3072, 0),
-                                        (32, 512, 768, 0), (788, 768, 3072, 0), (64, 768, 768, 1), (257, 1024, 4096, 0), (130, 64, 512, 1)])
+@pytest.mark.parametrize("M,N,K,act", [(197, 768, 3072, 0), (1, 768, 3072, 0), (8, 3072, 3072, 1), (32, 512, 3072, 1), (257, 1024, 4096, 0),
+                                        (130, 64, 2048, 1), (64, 1024, 4096, 0)])
 def test_gemm_splitk_small_M(ops, M, N, K, act):
     """Serving shapes through pclip_gemm_splitk_f16 (K cut into slices, a second launch adds the slabs in slice order):
     within 1 fp16 ulp of the fp32 reference like the unsplit kernel (3 with QuickGELU), deterministic (bit-identical runs),
@@ -107,6 +107,7 @@ def test_gemm_splitk_refusals(ops):
     lib = ops._lib.load()
     assert lib.pclip_gemm_splitk_workspace(50432, 768, 768) == 0        # plenty of tiles: the persistent kernel's shape
     assert lib.pclip_gemm_splitk_workspace(197, 768, 128) == 0          # K too short to cut
+    assert lib.pclip_gemm_splitk_workspace(197, 768, 768) == 0          # 12 K-tiles: the ring kernel's one launch is faster
     assert lib.pclip_gemm_splitk_workspace(197, 100, 768) == 0          # N % 64 != 0
     assert lib.pclip_gemm_splitk_workspace(197, 3072, 768) == 0         # slab traffic would cost more than the K-loop it saves
     a = torch.zeros(197, 768, dtype=torch.float16, device="cuda")
@@ -114,7 +115,9 @@ def test_gemm_splitk_refusals(ops):
     out = torch.empty(197, 768, dtype=torch.float16, device="cuda")
     ws = torch.empty(1024, dtype=torch.uint8, device="cuda")
     from proto_clip_amd._lib import ptr, stream
-    rc = lib.pclip_gemm_splitk_f16(ptr(a), 768, ptr(w), 768, ptr(out), 768, 197, 768, 768, None, 0, ptr(ws), ws.numel(), stream())
+    a = torch.zeros(197, 3072, dtype=torch.float16, device="cuda")
+    w = torch.zeros(768, 3072, dtype=torch.float16, device="cuda")
+    rc = lib.pclip_gemm_splitk_f16(ptr(a), 3072, ptr(w), 3072, ptr(out), 768, 197, 768, 3072, None, 0, ptr(ws), ws.numel(), stream())
     assert rc == -3 and b"workspace" in lib.pclip_last_error()
     rc = lib.pclip_gemm_splitk_f16(ptr(a), 768, ptr(w), 768, ptr(out), 768, 50432, 768, 768, None, 0, ptr(ws), ws.numel(), stream())
     assert rc == -1
