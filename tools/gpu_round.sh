@@ -22,3 +22,4 @@ for d in ("pmc_fetch","pmc_write","pmc_mfma"):
     try: agg(f"gpurun_out/{d}/b_counter_collection.csv", ["linear_fast", "attention", "sqdist", "layernorm"])
     except Exception as e: print(d, "failed", e)
 PY
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 > gpurun_out/bench_torchrun.json 2> gpurun_out/bench_torchrun.err; tail -c 600 gpurun_out/bench_torchrun.json

@@ -25,7 +25,7 @@ for k in sorted(f):
     if k not in w: continue
     hbm = (2.0 * f[k][0] + w[k][0]) * 1024.0
     out["kernels"][k] = {"launches": f[k][1], "fetch_kb_raw": f[k][0], "write_kb": w[k][0], "hbm_bytes_per_launch": hbm}
-    if "linear_fast_kernel" in k:
+    if "linear_fast_kernel" in k or "linear_small_kernel" in k:
         gb += hbm * f[k][1]; gn += f[k][1]
 out["linear_kernel_hbm_bytes_per_launch"] = gb / max(gn, 1)
 json.dump(out, open(os.path.join(root, "profiles/r01_pmc_traffic.json"), "w"), indent=1)
