@@ -285,18 +285,22 @@ __device__ __forceinline__ void mainloop_ring(const half_t* __restrict__ A, int 
         const char* la = smem + slot * C::STAGE_BYTES;
         slot = slot + 1 == NS ? 0 : slot + 1;
         const char* lb = la + C::A_BYTES;
+        // every fragment of the K-tile first (ONE exposed LDS latency per tile), then the MFMAs in mainloop_g's order
+        half8_t af[BK / 32][C::TM][2], bf[BK / 32][C::TN][2];
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             const int kc = ks * 4 + (lane >> 4);
-            half8_t af[C::TM][2], bf[C::TN][2];
 #pragma unroll
             for (int i = 0; i < C::TM; ++i)
 #pragma unroll
-                for (int a = 0; a < 2; ++a) af[i][a] = lds_frag(la, wm * (C::BM / C::WM) + i * 32 + a * 16 + (lane & 15), kc);
+                for (int a = 0; a < 2; ++a) af[ks][i][a] = lds_frag(la, wm * (C::BM / C::WM) + i * 32 + a * 16 + (lane & 15), kc);
 #pragma unroll
             for (int j = 0; j < C::TN; ++j)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) bf[j][b] = lds_frag(lb, wn * (C::BN / C::WN) + j * 32 + b * 16 + (lane & 15), kc);
+                for (int b = 0; b < 2; ++b) bf[ks][j][b] = lds_frag(lb, wn * (C::BN / C::WN) + j * 32 + b * 16 + (lane & 15), kc);
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks)
 #pragma unroll
             for (int i = 0; i < C::TM; ++i)
 #pragma unroll
@@ -307,11 +311,10 @@ __device__ __forceinline__ void mainloop_ring(const half_t* __restrict__ A, int 
                         for (int b = 0; b < 2; ++b) {
                             float4_t c = {acc.v[i][j][(a * 2 + b) * 4], acc.v[i][j][(a * 2 + b) * 4 + 1], acc.v[i][j][(a * 2 + b) * 4 + 2],
                                           acc.v[i][j][(a * 2 + b) * 4 + 3]};
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][b], af[i][a], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][j][b], af[ks][i][a], c, 0, 0, 0);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) acc.v[i][j][(a * 2 + b) * 4 + r] = c[r];
                         }
-        }
     }
 }
 
