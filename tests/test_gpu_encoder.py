@@ -460,6 +460,33 @@ def test_full_size_vit_b16_against_oracle():
     assert torch.equal(f1[0], f[2])
 
 
+def test_serving_low_latency_mode_full_size():
+    """A ViT-B/16 request through the serving entry with the split-K linears (default) and without: the split changes fp32
+    summation order only, so the top-5 probabilities agree within the north star's 1e-3 and the top-1 class is the same; the
+    hipGraph replay of the low-latency request reproduces its eager launches bit for bit."""
+    from proto_clip_amd.clip.model import BACKBONES
+    from proto_clip_amd.model import Adapter_FC
+    from proto_clip_amd.serving import ProtoClipClassifier
+    kw = BACKBONES["ViT-B/16"]
+    model = build_model(random_state_dict(seed=24, **kw)).cuda()
+    D, N, K = kw["embed_dim"], 198, 16
+    split = synth.make_split(N, K, D, 8, 8, seed=3, sigma=3.0)
+    ev = (split.visual_memory_keys.t().float() * 1.2).half().contiguous().cuda()
+    et = (split.textual_memory_bank.t().float() * 1.4).half().contiguous().cuda()
+    torch.manual_seed(7)
+    adapter = Adapter_FC(D, dtype=torch.half).cuda()
+    imgs = synth.make_images(3, 224, seed=12, n_class=N).cuda()
+    fast = ProtoClipClassifier(model, ev, et, adapter, shots=K, alpha=0.2, beta=12.0, top_k=5)
+    slow = ProtoClipClassifier(model, ev, et, adapter, shots=K, alpha=0.2, beta=12.0, top_k=5, low_latency=False)
+    tp, ti = fast.classify(imgs)
+    rp, ri = slow.classify(imgs)
+    torch.testing.assert_close(tp, rp, rtol=0, atol=1e-3)
+    assert torch.equal(ti[:, 0], ri[:, 0]) or (rp[:, 0] - rp[:, 1]).min().item() < 1e-3
+    fast.capture(3)
+    tg, ig = fast.classify(imgs)
+    assert torch.equal(tg, tp) and torch.equal(ig, ti)
+
+
 def test_full_size_rn50_against_oracle():
     """The real RN50 tower (3-4-6-3 bottlenecks, 224 px, attention pool with 32 heads) on 4 images against the oracle: fused
     conv+BN launches, implicit-GEMM 3x3 convolutions, narrow tiles and the one-query attention pool all in play."""
