@@ -103,6 +103,28 @@ def test_gemm_splitk_small_M(ops, M, N, K, act):
     assert ulp_diff(unsplit.cpu(), y.cpu()) <= (3 if act else 1)
 
 
+@pytest.mark.parametrize("K", [64, 128, 192, 256, 320, 384, 576, 1024])
+@pytest.mark.parametrize("M,N", [(1, 64), (127, 192), (128, 64), (129, 128), (300, 320), (1000, 64)])
+def test_gemm_ring_kernel_every_k_tile_count(ops, M, N, K):
+    """Calls with no more 128x64 tiles than CUs run the ring kernel (4 K-tile slots, 3 LDS-DMA stages in flight, counted waits):
+    every prologue / steady-state / tail combination of the ring (1 .. 16 K-tiles) and every row-tile edge, EXACT on
+    integer-valued operands (a tile consumed before it landed, or overwritten while still being read, cannot pass), and equal
+    to the fp32 reference with bias / QuickGELU within the usual fp16 rounding."""
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N + K)
+    a = torch.randint(-3, 4, (M, K), device="cuda", generator=g).half()
+    w = torch.randint(-2, 3, (N, K), device="cuda", generator=g).half()
+    bias = torch.randint(-4, 5, (N,), device="cuda", generator=g).half()
+    ref = a.float() @ w.float().t() + bias.float()
+    for _ in range(3):                                      # repeated: a race would not fail every time
+        assert torch.equal(ops.gemm(a, w, bias).float(), ref.half().float())
+    assert torch.equal(ops.gemm(a, w).float(), (a.float() @ w.float().t()).half().float())
+    af = (torch.randn(M, K, device="cuda", generator=g) * 0.5).half()
+    wf = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).half()
+    h = po.r16((af.float() @ wf.float().t() + bias.float()).cpu())
+    gelu = po.r16(h * po.r16(torch.sigmoid(po.r16(1.702 * h))))
+    assert ulp_diff(ops.gemm(af, wf, bias, act=1).cpu(), gelu.half()) <= 3
+
+
 def test_gemm_splitk_refusals(ops):
     lib = ops._lib.load()
     assert lib.pclip_gemm_splitk_workspace(50432, 768, 768) == 0        # plenty of tiles: the persistent kernel's shape
