@@ -137,7 +137,7 @@ int pclip_adapter_conv_f16(const void* x, int B, int D, int three_x, const void*
  *   bias (nullable, fp16 [N]) is added before rounding (nn.Linear, clip/model.py:176-178);
  *   act: 0 none, 1 QuickGELU x*sigmoid(1.702x) (clip/model.py:164-166) with per-op fp16 rounding;
  *   residual (nullable, fp16 [M,N], ldc): out = r16(residual + r16(...)) (clip/model.py:188-189).
- * lda/ldb/ldc in elements.  K % 32 == 0 required. */
+ * lda/ldb/ldc in elements.  K % 64 == 0 required.  Calls with no more 128x64 output tiles than the device has CUs (a serving request, the class-token tail) run a latency-oriented kernel with the same arithmetic (bit-identical results). */
 int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                    const void* bias, int act, const void* residual, pclip_stream_t stream);
 
