@@ -769,7 +769,7 @@ int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int
                   bool may_split, hipStream_t s) {
     const bool aligned = !epi.residual && epi.ldc % 8 == 0 && ((uintptr_t)epi.C & 15) == 0 && (!epi.bias || ((uintptr_t)epi.bias & 15) == 0);
     static const bool small_on = !(getenv("PCLIP_GEMM_SMALL") && getenv("PCLIP_GEMM_SMALL")[0] == '0');
-    if (aligned && forced == -1 && small_on && epi.act <= 1 && small_applies(M, N, cus))
+    if (aligned && forced == -1 && small_on && (epi.act <= 1 || (((uintptr_t)epi.scale | (uintptr_t)epi.shift) & 15) == 0) && small_applies(M, N, cus))
         return launch_small_one(A, lda, B, ldb, M, N, K, epi, s);
     double cost = 1e30;
     int pick = aligned ? best_cfg(M, N, cus, &cost) : -1;
@@ -858,7 +858,9 @@ __global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void linear_small_kernel(con
                                                                            const half_t* __restrict__ B, int ldb, int M, int N,
                                                                            int K, int tiles_n, int S, int steps_per,
                                                                            float* __restrict__ ws, const half_t* __restrict__ bias,
-                                                                           half_t* __restrict__ Cout, int ldc) {
+                                                                           half_t* __restrict__ Cout, int ldc,
+                                                                           const float* __restrict__ scale,
+                                                                           const float* __restrict__ shift) {
     using C = CfgSplit;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = blockIdx.x / S, ks = blockIdx.x - tile * S;
@@ -884,9 +886,20 @@ __global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void linear_small_kernel(con
     });
     if (S == 1) {
         const int col = n0 + 8 * (tid % C::CPR);
-        auto pre = [&](int, int, int, float4_t v) {
+        auto pre = [&](int, int j, int coff, float4_t v) {
             if (ACT == 1) return quick_gelu16x4(v);
             half4_t h;
+            if (ACT >= 2) {                                 // eval BatchNorm (+ReLU) as in linear_fast_kernel: same roundings
+                const int n = n0 + wn * (C::BN / C::WN) + j * 32 + coff;
+                const float4_t sc = *reinterpret_cast<const float4_t*>(scale + n), sh = *reinterpret_cast<const float4_t*>(shift + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float y = r16(r16(v[e]) * sc[e] + sh[e]);
+                    if (ACT == 3) y = fmaxf(y, 0.f);
+                    h[e] = (half_t)y;
+                }
+                return h;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
             return h;
@@ -912,6 +925,49 @@ __global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void linear_small_kernel(con
                     *reinterpret_cast<float4_t*>(slab + (size_t)m * N + n) =
                         float4_t{acc.v[i][j][4 * g], acc.v[i][j][4 * g + 1], acc.v[i][j][4 * g + 2], acc.v[i][j][4 * g + 3]};
             }
+}
+
+// The implicit-GEMM 3x3 convolution (conv3x3_fast_kernel) for launches with no more tiles than CUs: the same gather, the ring
+// K-loop, the same BatchNorm (+ReLU) epilogue — bit-identical to the persistent kernel.
+template <int ACT>
+__global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void conv3x3_small_kernel(const half_t* __restrict__ x, const half_t* __restrict__ zero,
+                                                                            const half_t* __restrict__ w, int H, int W, int Cin, int M,
+                                                                            int N, const float* __restrict__ scale,
+                                                                            const float* __restrict__ shift, half_t* __restrict__ Cout,
+                                                                            int tiles_n) {
+    using C = CfgSplit;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
+    const int K = 9 * Cin;
+    const int tid = threadIdx.x, wave = tid >> 6, wn = wave % C::WN;
+    pgemm::ConvGather<C> ga{x, zero, H, W, Cin, M, {}, {}};
+    ga.prepare(m0);
+    pgemm::Acc<C> acc;
+    pgemm::mainloop_ring_g<C, kSmallStages>([&](int t, char* dst) { ga.stage(t, dst); }, w, K, N, K / pgemm::BK, n0, smem, acc, [&]() {
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc.v[i][j][e] = 0.f;
+    });
+    const int col = n0 + 8 * (tid % C::CPR);
+    auto pre = [&](int, int j, int coff, float4_t v) {
+        const int n = n0 + wn * (C::BN / C::WN) + j * 32 + coff;
+        const float4_t sc = *reinterpret_cast<const float4_t*>(scale + n), sh = *reinterpret_cast<const float4_t*>(shift + n);
+        half4_t h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float y = r16(r16(v[e]) * sc[e] + sh[e]);
+            if (ACT == 3) y = fmaxf(y, 0.f);
+            h[e] = (half_t)y;
+        }
+        return h;
+    };
+    pgemm::epilogue_f16<C, true>(acc, smem, [](int) {}, pre, [&](int r, int, int, half8_t h) {
+        if (m0 + r < M) st_half8(Cout + (size_t)(m0 + r) * N + col, h);
+    });
 }
 
 // out[m, n .. n+7] = act(sum_s slab[s][m][n ..] + bias[n ..]) — slices added in order, one thread per 8 columns
@@ -947,11 +1003,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 inline int small_attr() {
     static bool done = false;
     if (!done) {
-        if (hipFuncSetAttribute((const void*)linear_small_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmallLds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)linear_small_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kSmallLds) != hipSuccess) {
-            pclip_set_error("gemm_f16 (small M): cannot raise the dynamic LDS limit to %d", kSmallLds);
-            return PCLIP_E_LAUNCH;
-        }
+        const void* fns[] = {(const void*)linear_small_kernel<0>, (const void*)linear_small_kernel<1>, (const void*)linear_small_kernel<2>,
+                             (const void*)linear_small_kernel<3>, (const void*)conv3x3_small_kernel<2>, (const void*)conv3x3_small_kernel<3>};
+        for (const void* f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kSmallLds) != hipSuccess) {
+                pclip_set_error("gemm_f16 (small M): cannot raise the dynamic LDS limit to %d", kSmallLds);
+                return PCLIP_E_LAUNCH;
+            }
         done = true;
     }
     return PCLIP_OK;
@@ -965,10 +1023,14 @@ int launch_small_one(const half_t* A, int lda, const half_t* B, int ldb, int M, 
     if (int e = small_attr()) return e;
     const int tiles_n = N / CfgSplit::BN, grid = ceil_div(M, CfgSplit::BM) * tiles_n, steps = K / pgemm::BK;
     ++g_gemm_launches;
-    if (epi.act == 1)
-        linear_small_kernel<1><<<grid, CfgSplit::NTHREADS, kSmallLds, s>>>(A, lda, B, ldb, M, N, K, tiles_n, 1, steps, nullptr, epi.bias, epi.C, epi.ldc);
-    else
-        linear_small_kernel<0><<<grid, CfgSplit::NTHREADS, kSmallLds, s>>>(A, lda, B, ldb, M, N, K, tiles_n, 1, steps, nullptr, epi.bias, epi.C, epi.ldc);
+#define PCLIP_SMALL_LAUNCH(ACT)                                                                                                          \
+    linear_small_kernel<ACT><<<grid, CfgSplit::NTHREADS, kSmallLds, s>>>(A, lda, B, ldb, M, N, K, tiles_n, 1, steps, nullptr, epi.bias, epi.C, \
+                                                                        epi.ldc, epi.scale, epi.shift)
+    if (epi.act == 1) PCLIP_SMALL_LAUNCH(1);
+    else if (epi.act == 2) PCLIP_SMALL_LAUNCH(2);
+    else if (epi.act == 3) PCLIP_SMALL_LAUNCH(3);
+    else PCLIP_SMALL_LAUNCH(0);
+#undef PCLIP_SMALL_LAUNCH
     return pclip_check_launch("gemm_f16 (small M)");
 }
 
@@ -1016,7 +1078,7 @@ extern "C" int pclip_gemm_splitk_f16(const void* A, int lda, const void* B, int 
     hipStream_t s = (hipStream_t)stream;
     if (int e = small_attr()) return e;
     linear_small_kernel<0><<<pl.tiles_m * pl.tiles_n * pl.S, CfgSplit::NTHREADS, kSmallLds, s>>>(
-        (const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, pl.tiles_n, pl.S, pl.steps_per, (float*)ws, nullptr, nullptr, 0);
+        (const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, pl.tiles_n, pl.S, pl.steps_per, (float*)ws, nullptr, nullptr, 0, nullptr, nullptr);
     const int rgrid = (int)(((size_t)M * (N / 8) + 255) / 256);
     if (act == 1)
         splitk_reduce_kernel<1><<<rgrid, 256, 0, s>>>((const float*)ws, pl.S, M, N, (const half_t*)bias, (half_t*)C, ldc);
@@ -1077,10 +1139,22 @@ extern "C" int pclip_conv3x3_bn_f16(const void* x, const void* w, const void* ze
     if (B == 0) return PCLIP_OK;
     int cus = pclip_device_cus();
     if (cus <= 0) cus = 256;
+    hipStream_t s = (hipStream_t)stream;
+    static const bool small_on = !(getenv("PCLIP_GEMM_SMALL") && getenv("PCLIP_GEMM_SMALL")[0] == '0');
+    if (small_on && small_applies(B * H * W, Cout, cus)) {                     // a request of a few images: the ring kernel
+        if (int e = small_attr()) return e;
+        const int tiles_n = Cout / CfgSplit::BN, grid = ceil_div(B * H * W, CfgSplit::BM) * tiles_n;
+        if (relu)
+            conv3x3_small_kernel<3><<<grid, CfgSplit::NTHREADS, kSmallLds, s>>>((const half_t*)x, (const half_t*)zero_line, (const half_t*)w, H, W, Cin,
+                                                                           B * H * W, Cout, scale, shift, (half_t*)y, tiles_n);
+        else
+            conv3x3_small_kernel<2><<<grid, CfgSplit::NTHREADS, kSmallLds, s>>>((const half_t*)x, (const half_t*)zero_line, (const half_t*)w, H, W, Cin,
+                                                                           B * H * W, Cout, scale, shift, (half_t*)y, tiles_n);
+        return pclip_check_launch("conv3x3_bn (small M)");
+    }
     double cost;
     int pick = best_cfg((long)B * H * W, Cout, cus, &cost);
     if (pick == 4 || pick < 0) pick = 3;                        // the 4-wave thin tile has no gather variant; Cout % 64 == 0 always fits 256x64
-    hipStream_t s = (hipStream_t)stream;
     if (pick == 2) return launch_conv<CfgBig>(x, zero_line, w, B, H, W, Cin, Cout, scale, shift, relu, y, cus, s);
     if (pick == 1) return launch_conv<CfgWide>(x, zero_line, w, B, H, W, Cin, Cout, scale, shift, relu, y, cus, s);
     if (pick == 0) return launch_conv<CfgSmall>(x, zero_line, w, B, H, W, Cin, Cout, scale, shift, relu, y, 2 * cus, s);

@@ -257,16 +257,17 @@ struct ConvGather {
 // is a counted vmcnt(stages still allowed in flight x PER).  16x16x32 MFMAs, same fragment order as mainloop_g's M16 branch
 // (bit-identical accumulation).  `init()` runs after the first NS-1 stages are on their way and sets the accumulators (zero,
 // or the bias as in linear_fast_kernel: its loads overlap the stages' latency).
-template <class C, int NS, class Init>
-__device__ __forceinline__ void mainloop_ring(const half_t* __restrict__ A, int lda, const half_t* __restrict__ B, int ldb, int M,
-                                              int N, int nt, int m0, int n0, char* smem, Acc<C>& acc, const Init& init) {
+// `stage_a(t, dst)` stages K-tile t of the A operand (stage_tile, or ConvGather::stage for the implicit convolution).
+template <class C, int NS, class StageA, class Init>
+__device__ __forceinline__ void mainloop_ring_g(const StageA& stage_a, const half_t* __restrict__ B, int ldb, int N, int nt, int n0,
+                                                char* smem, Acc<C>& acc, const Init& init) {
     constexpr int PER = (C::BM + C::BN) / (8 * C::NWAVES);          // LDS-DMA instructions per wave per stage
     static_assert(NS >= 3 && NS <= 6 && (NS - 2) * PER < 64, "ring depth / vmcnt range");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / C::WN, wn = wave % C::WN;
     auto stage = [&](int t, int slot) {
         char* a = smem + slot * C::STAGE_BYTES;
-        stage_tile<C::BM, C::NWAVES>(A, lda, m0, M, t * BK, a, wave, lane);
+        stage_a(t, a);
         stage_tile<C::BN, C::NWAVES>(B, ldb, n0, N, t * BK, a + C::A_BYTES, wave, lane);
     };
     for (int t = 0; t < NS - 1 && t < nt; ++t) stage(t, t);
@@ -316,6 +317,14 @@ __device__ __forceinline__ void mainloop_ring(const half_t* __restrict__ A, int 
                             for (int r = 0; r < 4; ++r) acc.v[i][j][(a * 2 + b) * 4 + r] = c[r];
                         }
     }
+}
+
+template <class C, int NS, class Init>
+__device__ __forceinline__ void mainloop_ring(const half_t* __restrict__ A, int lda, const half_t* __restrict__ B, int ldb, int M,
+                                              int N, int nt, int m0, int n0, char* smem, Acc<C>& acc, const Init& init) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    mainloop_ring_g<C, NS>([&](int t, char* dst) { stage_tile<C::BM, C::NWAVES>(A, lda, m0, M, t * BK, dst, wave, lane); }, B, ldb, N, nt,
+                           n0, smem, acc, init);
 }
 
 // ---- fp16 output through an LDS-staged, fully coalesced epilogue -----------------------------------------
