@@ -239,8 +239,10 @@ int pclip_cast_f16_f32(const void* x, float* y, size_t n, pclip_stream_t stream)
 int pclip_gemm_f32(const void* A, int a_f16, long rsa, long csa, const void* B, int b_f16, long rsb, long csb, float* C, int ldc,
                    int M, int N, int K, float alpha, float beta, pclip_stream_t stream);
 
-/* out[c] (+)= scale * sum_r x[r, c]  (fixed summation order; accumulate != 0 adds to out). */
-int pclip_colsum_f32(const float* x, int ldx, int R, int C, float scale, float* out, int accumulate, pclip_stream_t stream);
+/* out[c] (+)= scale * sum_r x[r, c]  (fixed summation order; accumulate != 0 adds to out).  ws (nullable, >= 64 * C * 4 bytes):
+ * with it, more than 512 rows are summed as up to 64 row blocks in parallel and the block sums added in block order. */
+int pclip_colsum_f32(const float* x, int ldx, int R, int C, float scale, float* out, int accumulate, void* ws, size_t ws_bytes,
+                     pclip_stream_t stream);
 
 /* C[r, :] += s * rowscale[r] * X[r, :]  (the 2*rowsum(G)*q and 2*colsum(G)*z terms of the cdist backward). */
 int pclip_addscaled_rows_f32(float* C, int ldc, const float* X, int ldx, const float* rowscale, float s, int R, int D,

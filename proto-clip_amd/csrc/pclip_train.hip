@@ -89,6 +89,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     }
 }
 
+// part[blockIdx.y][c] = sum of the rows [blockIdx.y * rows_per, ...) of column c (same wave-interleaved fixed order as colsum_kernel)
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ x, int ldx, int R, int C, int rows_per,
+                                                          float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * rows_per, r1 = r0 + rows_per < R ? r0 + rows_per : R;
+    float s = 0.f;
+    if (c < C)
+        for (int r = r0 + wave; r < r1; r += 4) s += x[(size_t)r * ldx + c];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < C) part[(size_t)blockIdx.y * C + c] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+
 // C[r, :] += s * rowscale[r] * X[r, :]
 __global__ __launch_bounds__(256) void addscaled_rows_kernel(float* __restrict__ C, int ldc, const float* __restrict__ X, int ldx,
                                                              const float* __restrict__ rowscale, float s, int R, int D) {
@@ -238,24 +253,29 @@ __global__ __launch_bounds__(256) void l2norm_rows_backward_f32_kernel(const flo
 // backward: g (fp32, wrt out) -> fp32 normalise -> r16 (.float()) -> /K (fp16) -> fp16 normalise of every shot.
 // The fp16 stages follow autograd's op sequence for  x / x.norm(dim=-1, keepdim=True)  with fp16 tensors:
 //   div:  dx1 = r16s(gk / n);  dn = r16s(sum_d r16s(-gk * r16s(r16s(x/n)/n)))      norm:  dx2 = r16s(x * r16s(dn / n))
+// gk — the gradient of the fp16 mean, already divided by K — does not depend on the shot: it is computed once per class into an
+// LDS row (with the shot norms), so the work per class is O(K D) instead of the O(K^2 D) of recomputing the mean per shot.
 __global__ __launch_bounds__(256) void proto_backward_kernel(const half_t* __restrict__ mem, const float* __restrict__ g, int N,
                                                              int K, int D, int per_shot, int final_norm,
                                                              half_t* __restrict__ dmem) {
+    extern __shared__ float pb_lds[];                      // per wave: [D] m then gk | [32] shot norms
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* gks = pb_lds + (size_t)wave * (D + 32);
+    float* nk = gks + D;
     for (int n = blockIdx.x * 4 + wave; n < N; n += gridDim.x * 4) {
         const half_t* rows = mem + (size_t)n * K * D;
         const float* gn = g + (size_t)n * D;
         half_t* drows = dmem + (size_t)n * K * D;
-        float dot = 0.f, nrm2 = 0.f;                       // m.g and |m|^2 of the fp32 normalise
-        // exact forward recomputation: shot norms first (one wave reduction per shot)
-        float nk[32];                                      // K <= 32 shot norms (fp16-rounded) kept per lane
-        for (int k = 0; k < K && k < 32; ++k) {
+        // exact forward recomputation: shot norms first (fp16-rounded, one wave reduction per shot)
+        for (int k = 0; k < K; ++k) {
             const half_t* v = rows + (size_t)k * D;
             float ss = 0.f;
             for (int d = lane; d < D; d += 64) { const float x = (float)v[d]; ss += x * x; }
-            nk[k] = r16s(sqrtf(wave_sum(ss)));
+            ss = wave_sum(ss);
+            if (lane == 0) nk[k] = r16s(sqrtf(ss));
         }
-        // mean over shots (fp32 accumulate, one rounding) and its fp32 norm
+        // mean over shots (fp32 accumulate, one rounding), its fp32 norm and m.g
+        float dot = 0.f, nrm2 = 0.f;
         for (int d = lane; d < D; d += 64) {
             float acc = 0.f;
             for (int k = 0; k < K; ++k) {
@@ -263,6 +283,7 @@ __global__ __launch_bounds__(256) void proto_backward_kernel(const half_t* __res
                 acc += per_shot ? r16s(x / nk[k]) : x;
             }
             const float m = r16s(acc / (float)K);
+            gks[d] = m;
             nrm2 += m * m;
             dot += m * gn[d];
         }
@@ -270,38 +291,27 @@ __global__ __launch_bounds__(256) void proto_backward_kernel(const half_t* __res
         dot = wave_sum(dot);
         const float nrm = sqrtf(nrm2);
         const float pg = dot / nrm;                        // p . g with p = m / nrm
+        for (int d = lane; d < D; d += 64) {               // every lane touches only its own d: no barrier needed
+            const float m = gks[d];
+            const float gm = final_norm ? (gn[d] - (m / nrm) * pg) / nrm : gn[d];
+            gks[d] = r16s(r16s(gm) / (float)K);
+        }
         for (int k = 0; k < K; ++k) {
             const half_t* v = rows + (size_t)k * D;
-            // dn of this shot: needs gk for every d -> recompute gk on the fly (cheap: D/64 elements per lane)
+            const float nkk = nk[k];
             float dn = 0.f;
             if (per_shot) {
                 for (int d = lane; d < D; d += 64) {
-                    float acc = 0.f;
-                    for (int kk = 0; kk < K; ++kk) {
-                        const float x = (float)rows[(size_t)kk * D + d];
-                        acc += per_shot ? r16s(x / nk[kk]) : x;
-                    }
-                    const float m = r16s(acc / (float)K);
-                    const float gm = final_norm ? (gn[d] - (m / nrm) * pg) / nrm : gn[d];
-                    const float gk = r16s(r16s(gm) / (float)K);
                     const float x = (float)v[d];
-                    dn += r16s(-gk * r16s(r16s(x / nk[k]) / nk[k]));
+                    dn += r16s(-gks[d] * r16s(r16s(x / nkk) / nkk));
                 }
                 dn = r16s(wave_sum(dn));
             }
             for (int d = lane; d < D; d += 64) {
-                float acc = 0.f;
-                for (int kk = 0; kk < K; ++kk) {
-                    const float x = (float)rows[(size_t)kk * D + d];
-                    acc += per_shot ? r16s(x / nk[kk]) : x;
-                }
-                const float m = r16s(acc / (float)K);
-                const float gm = final_norm ? (gn[d] - (m / nrm) * pg) / nrm : gn[d];
-                const float gk = r16s(r16s(gm) / (float)K);
-                float out = gk;
+                float out = gks[d];
                 if (per_shot) {
                     const float x = (float)v[d];
-                    out = r16s(r16s(gk / nk[k]) + r16s(x * r16s(dn / nk[k])));
+                    out = r16s(r16s(out / nkk) + r16s(x * r16s(dn / nkk)));
                 }
                 drows[(size_t)k * D + d] = (half_t)out;
             }
@@ -426,11 +436,22 @@ extern "C" int pclip_gemm_f32(const void* A, int a_f16, long rsa, long csa, cons
     return pclip_check_launch("gemm_f32");
 }
 
-extern "C" int pclip_colsum_f32(const float* x, int ldx, int R, int C, float scale, float* out, int accumulate,
-                                pclip_stream_t stream) {
+extern "C" int pclip_colsum_f32(const float* x, int ldx, int R, int C, float scale, float* out, int accumulate, void* ws,
+                                size_t ws_bytes, pclip_stream_t stream) {
     PCLIP_REQUIRE(x && out, "pclip_colsum_f32: null pointer");
     PCLIP_REQUIRE(R >= 0 && C > 0 && ldx >= C, "pclip_colsum_f32: bad shape R=%d C=%d ld=%d", R, C, ldx);
-    colsum_kernel<<<ceil_div(C, 64), 256, 0, (hipStream_t)stream>>>(x, ldx, R, C, scale, out, accumulate);
+    hipStream_t s = (hipStream_t)stream;
+    // many rows: row blocks in parallel -> partial sums [RB][C] in the workspace -> summed in block order (still deterministic);
+    // one workgroup per 64 columns alone leaves the chip idle (C = 1000: 16 workgroups, C = 1 — a loss mean — one)
+    int rb = R > 512 ? ceil_div(R, 128) : 1;
+    if (rb > 64) rb = 64;
+    if (rb > 1 && ws && ws_bytes >= (size_t)rb * C * sizeof(float)) {
+        const int rows_per = ceil_div(R, rb);
+        colsum_part_kernel<<<dim3(ceil_div(C, 64), rb), 256, 0, s>>>(x, ldx, R, C, rows_per, (float*)ws);
+        colsum_kernel<<<ceil_div(C, 64), 256, 0, s>>>((const float*)ws, C, rb, C, scale, out, accumulate);
+        return pclip_check_launch("colsum_f32 (two-pass)");
+    }
+    colsum_kernel<<<ceil_div(C, 64), 256, 0, s>>>(x, ldx, R, C, scale, out, accumulate);
     return pclip_check_launch("colsum_f32");
 }
 
@@ -492,9 +513,9 @@ extern "C" int pclip_l2norm_rows_backward_f32(const float* x, const float* gy, f
 extern "C" int pclip_proto_backward_f16(const void* mem, const float* g, int N, int K, int D, int per_shot_norm, int final_norm,
                                         void* dmem, pclip_stream_t stream) {
     PCLIP_REQUIRE(mem && g && dmem, "pclip_proto_backward_f16: null pointer");
-    PCLIP_REQUIRE(N >= 0 && K > 0 && K <= 32 && D > 0, "pclip_proto_backward_f16: bad N=%d K=%d (<=32) D=%d", N, K, D);
+    PCLIP_REQUIRE(N >= 0 && K > 0 && K <= 32 && D > 0 && D <= 3072, "pclip_proto_backward_f16: bad N=%d K=%d (<=32) D=%d (<=3072)", N, K, D);
     if (N == 0) return PCLIP_OK;
-    proto_backward_kernel<<<row_grid(N, 8192), 256, 0, (hipStream_t)stream>>>((const half_t*)mem, g, N, K, D, per_shot_norm,
+    proto_backward_kernel<<<row_grid(N, 8192), 256, 4 * (size_t)(D + 32) * sizeof(float), (hipStream_t)stream>>>((const half_t*)mem, g, N, K, D, per_shot_norm,
                                                                              final_norm, (half_t*)dmem);
     return pclip_check_launch("proto_backward");
 }

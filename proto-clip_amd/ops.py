@@ -493,7 +493,9 @@ def colsum_f32(x: torch.Tensor, rows: int = None, cols: int = None, scale: float
     acc = out is not None
     if out is None:
         out = torch.empty(C, dtype=torch.float32, device=x.device)
-    check(_lib.load().pclip_colsum_f32(ptr(x), x.stride(0), R, C, scale, ptr(out), int(acc), stream()), "pclip_colsum_f32")
+    ws = _workspace(64 * C * 4, x.device) if R > 512 else None
+    check(_lib.load().pclip_colsum_f32(ptr(x), x.stride(0), R, C, scale, ptr(out), int(acc), ptr(ws), ws.numel() if ws is not None else 0,
+                                       stream()), "pclip_colsum_f32")
     return out
 
 
