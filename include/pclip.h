@@ -237,10 +237,12 @@ int pclip_cast_f16_f32(const void* x, float* y, size_t n, pclip_stream_t stream)
  * matmul autograd issues in the training step: cdist backward (dq = -2 G Z, dz = -2 G^T q), InfoNCE logits and their
  * gradients, Linear weight / input gradients of Adapter_FC. */
 int pclip_gemm_f32(const void* A, int a_f16, long rsa, long csa, const void* B, int b_f16, long rsb, long csb, float* C, int ldc,
-                   int M, int N, int K, float alpha, float beta, pclip_stream_t stream);
+                   int M, int N, int K, float alpha, float beta, void* ws, size_t ws_bytes, pclip_stream_t stream);
+/* ws (nullable): with >= 32 * M * N * 4 bytes, a call with at most 128 output tiles and K >= 1024 is cut into K slices whose
+ * partial products are added in slice order (deterministic; differs from the unsplit sum in fp32 order only). */
 
 /* out[c] (+)= scale * sum_r x[r, c]  (fixed summation order; accumulate != 0 adds to out).  ws (nullable, >= 64 * C * 4 bytes):
- * with it, more than 512 rows are summed as up to 64 row blocks in parallel and the block sums added in block order. */
+ * with it, more than 128 rows are summed as up to 64 row blocks in parallel and the block sums added in block order. */
 int pclip_colsum_f32(const float* x, int ldx, int R, int C, float scale, float* out, int accumulate, void* ws, size_t ws_bytes,
                      pclip_stream_t stream);
 

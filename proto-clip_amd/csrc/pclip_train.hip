@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void cast_f16_f32_kernel(const half_t* __restr
 template <typename TA, typename TB>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const TA* __restrict__ A, long rsa, long csa, const TB* __restrict__ B,
                                                        long rsb, long csb, float* __restrict__ C, int ldc, int M, int N,
-                                                       int K, float alpha, float beta) {
+                                                       int K, float alpha, float beta, int kper, float* __restrict__ slabs) {
     __shared__ float As[64][33], Bs[64][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
@@ -46,6 +46,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const TA* __restrict__ A,
     const bool a_k_fast = csa == 1, b_k_fast = rsb == 1;
     // register double buffering: the global loads of K-slab k0+32 fly while slab k0 is multiplied (the staging used to be a
     // load -> LDS -> barrier chain per slab: ~2 us of exposed latency each)
+    // split-K (slabs != nullptr): blockIdx.z owns k in [z*kper, (z+1)*kper) and writes its raw sums to slabs[z][M][N]
+    const int kbeg = slabs ? blockIdx.z * kper : 0;
+    const int kend = slabs ? (kbeg + kper < K ? kbeg + kper : K) : K;
     float ra[8], rb[8];
     auto fetch = [&](int k0) {
 #pragma unroll
@@ -53,13 +56,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const TA* __restrict__ A,
             const int i = tid + u * 256;
             int r, c;
             if (a_k_fast) { r = i >> 5; c = i & 31; } else { r = i & 63; c = i >> 6; }
-            ra[u] = (m0 + r < M && k0 + c < K) ? (float)A[(long)(m0 + r) * rsa + (long)(k0 + c) * csa] : 0.f;
+            ra[u] = (m0 + r < M && k0 + c < kend) ? (float)A[(long)(m0 + r) * rsa + (long)(k0 + c) * csa] : 0.f;
             if (b_k_fast) { r = i >> 5; c = i & 31; } else { r = i & 63; c = i >> 6; }
-            rb[u] = (n0 + r < N && k0 + c < K) ? (float)B[(long)(k0 + c) * rsb + (long)(n0 + r) * csb] : 0.f;
+            rb[u] = (n0 + r < N && k0 + c < kend) ? (float)B[(long)(k0 + c) * rsb + (long)(n0 + r) * csb] : 0.f;
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < K; k0 += 32) {
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const TA* __restrict__ A,
             Bs[r][c] = rb[u];
         }
         __syncthreads();
-        if (k0 + 32 < K) fetch(k0 + 32);
+        if (k0 + 32 < kend) fetch(k0 + 32);
 #pragma unroll
         for (int kk = 0; kk < 32; kk += 2) {
             const float b = Bs[wc * 32 + l31][kk + hi], a = As[wr * 32 + l31][kk + hi];
@@ -84,9 +87,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const TA* __restrict__ A,
     for (int e = 0; e < 16; ++e) {
         const int n = n0 + wc * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
         if (n < N) {
+            if (slabs) { slabs[((size_t)blockIdx.z * M + m) * N + n] = acc[e]; continue; }
             float* c = C + (size_t)m * ldc + n;
             *c = beta == 0.f ? alpha * acc[e] : fmaf(beta, *c, alpha * acc[e]);
         }
+    }
+}
+
+// C = alpha * sum_z slabs[z] + beta * C  (slices added in order: deterministic)
+__global__ __launch_bounds__(256) void gemm_f32_reduce_kernel(const float* __restrict__ slabs, int S, int M, int N, float* __restrict__ C,
+                                                              int ldc, float alpha, float beta) {
+    const size_t total = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        float acc = 0.f;
+        for (int z = 0; z < S; ++z) acc += slabs[(size_t)z * total + i];
+        const int m = (int)(i / N), n = (int)(i - (size_t)m * N);
+        float* c = C + (size_t)m * ldc + n;
+        *c = beta == 0.f ? alpha * acc : fmaf(beta, *c, alpha * acc);
     }
 }
 
@@ -441,16 +458,34 @@ extern "C" int pclip_cast_f16_f32(const void* x, float* y, size_t n, pclip_strea
 }
 
 extern "C" int pclip_gemm_f32(const void* A, int a_f16, long rsa, long csa, const void* B, int b_f16, long rsb, long csb, float* C,
-                              int ldc, int M, int N, int K, float alpha, float beta, pclip_stream_t stream) {
+                              int ldc, int M, int N, int K, float alpha, float beta, void* ws, size_t ws_bytes, pclip_stream_t stream) {
     PCLIP_REQUIRE(A && B && C, "pclip_gemm_f32: null pointer");
     PCLIP_REQUIRE(M >= 0 && N >= 0 && K > 0 && ldc >= N, "pclip_gemm_f32: bad shape M=%d N=%d K=%d ldc=%d", M, N, K, ldc);
     if (M == 0 || N == 0) return PCLIP_OK;
     dim3 grid(ceil_div(N, 64), ceil_div(M, 64));
     hipStream_t s = (hipStream_t)stream;
-    if (a_f16 && b_f16) gemm_f32_kernel<half_t, half_t><<<grid, 256, 0, s>>>((const half_t*)A, rsa, csa, (const half_t*)B, rsb, csb, C, ldc, M, N, K, alpha, beta);
-    else if (a_f16) gemm_f32_kernel<half_t, float><<<grid, 256, 0, s>>>((const half_t*)A, rsa, csa, (const float*)B, rsb, csb, C, ldc, M, N, K, alpha, beta);
-    else if (b_f16) gemm_f32_kernel<float, half_t><<<grid, 256, 0, s>>>((const float*)A, rsa, csa, (const half_t*)B, rsb, csb, C, ldc, M, N, K, alpha, beta);
-    else gemm_f32_kernel<float, float><<<grid, 256, 0, s>>>((const float*)A, rsa, csa, (const float*)B, rsb, csb, C, ldc, M, N, K, alpha, beta);
+    // few output tiles and a long K (weight gradients of the fc adapter: [D/4 x D] over thousands of query rows): K slices
+    // in parallel -> slabs in the workspace -> added in slice order
+    const int tiles = grid.x * grid.y;
+    int S = 1, kper = K;
+    if (ws && tiles <= 128 && K >= 1024) {
+        S = 512 / tiles;
+        if (S > K / 256) S = K / 256;
+        if (S > 32) S = 32;
+        kper = ceil_div(ceil_div(K, S), 32) * 32;
+        S = ceil_div(K, kper);
+        if (S < 2 || ws_bytes < (size_t)S * M * N * sizeof(float)) { S = 1; kper = K; }
+    }
+    float* slabs = S > 1 ? (float*)ws : nullptr;
+    grid.z = S;
+    if (a_f16 && b_f16) gemm_f32_kernel<half_t, half_t><<<grid, 256, 0, s>>>((const half_t*)A, rsa, csa, (const half_t*)B, rsb, csb, C, ldc, M, N, K, alpha, beta, kper, slabs);
+    else if (a_f16) gemm_f32_kernel<half_t, float><<<grid, 256, 0, s>>>((const half_t*)A, rsa, csa, (const float*)B, rsb, csb, C, ldc, M, N, K, alpha, beta, kper, slabs);
+    else if (b_f16) gemm_f32_kernel<float, half_t><<<grid, 256, 0, s>>>((const float*)A, rsa, csa, (const half_t*)B, rsb, csb, C, ldc, M, N, K, alpha, beta, kper, slabs);
+    else gemm_f32_kernel<float, float><<<grid, 256, 0, s>>>((const float*)A, rsa, csa, (const float*)B, rsb, csb, C, ldc, M, N, K, alpha, beta, kper, slabs);
+    if (S > 1) {
+        const size_t total = (size_t)M * N;
+        gemm_f32_reduce_kernel<<<(int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256), 256, 0, s>>>(slabs, S, M, N, C, ldc, alpha, beta);
+    }
     return pclip_check_launch("gemm_f32");
 }
 
@@ -461,7 +496,7 @@ extern "C" int pclip_colsum_f32(const float* x, int ldx, int R, int C, float sca
     hipStream_t s = (hipStream_t)stream;
     // many rows: row blocks in parallel -> partial sums [RB][C] in the workspace -> summed in block order (still deterministic);
     // one workgroup per 64 columns alone leaves the chip idle (C = 1000: 16 workgroups, C = 1 — a loss mean — one)
-    int rb = R > 512 ? ceil_div(R, 128) : 1;
+    int rb = R > 128 ? ceil_div(R, 32) : 1;
     if (rb > 64) rb = 64;
     if (rb > 1 && ws && ws_bytes >= (size_t)rb * C * sizeof(float)) {
         const int rows_per = ceil_div(R, rb);

@@ -479,8 +479,10 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: b
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=a.device)
         beta = 0.0
+    ws = _workspace(32 * M * N * 4, a.device) if K >= 1024 and ((M + 63) // 64) * ((N + 63) // 64) <= 128 else None
     check(_lib.load().pclip_gemm_f32(ptr(a), int(a.dtype == torch.float16), rsa, csa, ptr(b), int(b.dtype == torch.float16),
-                                     rsb, csb, ptr(out), out.stride(0), M, N, K, alpha, beta, stream()), "pclip_gemm_f32")
+                                     rsb, csb, ptr(out), out.stride(0), M, N, K, alpha, beta, ptr(ws),
+                                     ws.numel() if ws is not None else 0, stream()), "pclip_gemm_f32")
     return out
 
 
@@ -493,7 +495,7 @@ def colsum_f32(x: torch.Tensor, rows: int = None, cols: int = None, scale: float
     acc = out is not None
     if out is None:
         out = torch.empty(C, dtype=torch.float32, device=x.device)
-    ws = _workspace(64 * C * 4, x.device) if R > 512 else None
+    ws = _workspace(64 * C * 4, x.device) if R > 128 else None
     check(_lib.load().pclip_colsum_f32(ptr(x), x.stride(0), R, C, scale, ptr(out), int(acc), ptr(ws), ws.numel() if ws is not None else 0,
                                        stream()), "pclip_colsum_f32")
     return out

@@ -39,9 +39,9 @@ def assert_grad_close(got, ref, what, tol=2e-3, ulps=4):
 
 @pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
 @pytest.mark.parametrize("half_a", [False, True])
-def test_gemm_f32(ops, ta, tb, half_a):
+@pytest.mark.parametrize("M,N,K", [(150, 97, 203), (130, 70, 3000)])      # the second: few tiles, long K -> K slices + ordered reduce
+def test_gemm_f32(ops, ta, tb, half_a, M, N, K):
     g = torch.Generator().manual_seed(5)
-    M, N, K = 150, 97, 203
     a = torch.randn((K, M) if ta else (M, K), generator=g)
     b = torch.randn((N, K) if tb else (K, N), generator=g)
     if half_a:
