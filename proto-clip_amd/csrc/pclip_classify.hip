@@ -195,14 +195,27 @@ __global__ __launch_bounds__(256) void sqdist_f32_kernel(const float* __restrict
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     float nrm = 0.f;                                   // threads 0..63: ||q_row||^2, 64..127: ||z_row||^2
+    // register double buffering: the loads of K-slab k0+32 fly while slab k0 is multiplied (same arithmetic, same order)
+    float ra[8], rb[8];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + u * 256, r = i >> 5, c = i & 31;
+            ra[u] = (m0 + r < Q && k0 + c < D) ? q[(size_t)(m0 + r) * D + k0 + c] : 0.f;
+            rb[u] = (n0 + r < N && k0 + c < D) ? z[(size_t)(n0 + r) * D + k0 + c] : 0.f;
+        }
+    };
+    fetch(0);
     for (int k0 = 0; k0 < D; k0 += 32) {
         __syncthreads();
-        for (int i = tid; i < 64 * 32; i += 256) {
-            const int r = i >> 5, c = i & 31;
-            As[r][c] = (m0 + r < Q && k0 + c < D) ? q[(size_t)(m0 + r) * D + k0 + c] : 0.f;
-            Bs[r][c] = (n0 + r < N && k0 + c < D) ? z[(size_t)(n0 + r) * D + k0 + c] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + u * 256, r = i >> 5, c = i & 31;
+            As[r][c] = ra[u];
+            Bs[r][c] = rb[u];
         }
         __syncthreads();
+        if (k0 + 32 < D) fetch(k0 + 32);
         if (tid < 128) {
             const float* row = tid < 64 ? As[tid] : Bs[tid - 64];
 #pragma unroll 8
