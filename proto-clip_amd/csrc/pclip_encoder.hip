@@ -493,6 +493,13 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const half_t* __rest
 constexpr int ATT_DH = 64;
 constexpr int ATT_MAX_L = 288;
 
+// ds_read_b64_tr_b16: 64 bits per lane, 16-bit elements transposed inside each 16-lane group (see attention_kernel)
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ half4_t tr_read4(const char* lds_addr) {
+    const fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(lds_addr));
+    return __builtin_bit_cast(half4_t, v);
+}
+
 // General operand form: queries q [B][Lq rows, row stride ldq] (the FIRST Lq tokens of each sequence), keys / values in
 // kv [B*L rows, row stride ldkv] at column offsets k_off / v_off; the fused-QKV case is q = kv = qkv, ldq = ldkv = 3W,
 // k_off = W, v_off = 2W, Lq = L.  Lq < L serves the last vision block, whose output is only read at the class token.
@@ -504,7 +511,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const half_t
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int LP = NT * 32;
     half_t* Ks = reinterpret_cast<half_t*>(smem);             // [LP][64], 16-byte chunks XOR-swizzled by swz_key(row)
-    half_t* Vt = Ks + LP * ATT_DH;                            // [64][LV]: V transposed, (LV/4) odd -> conflict-free b64 reads
+    half_t* Vs = Ks + LP * ATT_DH;                            // [LP][64]: V row-major, chunk-swizzled (see the staging loop)
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int W = H * ATT_DH;
     const half_t* kbase = kvp + (size_t)b * L * ldkv + h * ATT_DH + k_off;
@@ -520,28 +527,27 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const half_t
         __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(kbase + (size_t)rc * ldkv + c * 8),
                                          (pgemm::lds_ptr_t)(Ks + r0 * ATT_DH), 16, 0, 0);
     }
-    // V^T: each thread transposes a 4-key x 8-dim block: 4 x 16-byte loads -> 8 x ds_write_b64
-    for (int i = tid; i < (LP / 4) * 8; i += NW * 64) {
-        const int kg = i >> 3, c = i & 7;
-        half8_t v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int r = kg * 4 + u;
-            if (r < L) v[u] = ld_half8(vbase + (size_t)r * ldkv + c * 8);
-            else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[u][j] = (half_t)0.f;     // padded keys must contribute exact zeros
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            half4_t t = {v[0][j], v[1][j], v[2][j], v[3][j]};
-            *reinterpret_cast<half4_t*>(Vt + (c * 8 + j) * LV + kg * 4) = t;
-        }
+    // V: row-major like K, by LDS-DMA (no registers, no transposing ds_writes); the 16-byte chunks of key row r are XORed with
+    // 4 * ((r >> 1) & 1) so that the four keys of a transpose-read (ds_read_b64_tr_b16, below) land on 4 x 16 distinct banks.
+    // Rows >= L re-read row L-1: their probabilities are exact zeros (masked scores), so they contribute 0 * finite = 0.
+    for (int r0 = wave * 8; r0 < LP; r0 += NW * 8) {
+        const int r = r0 + (lane >> 3);
+        const int c = (lane & 7) ^ (((r >> 1) & 1) << 2);
+        const int rc = r < L ? r : L - 1;
+        __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(vbase + (size_t)rc * ldkv + c * 8),
+                                         (pgemm::lds_ptr_t)(Vs + r0 * ATT_DH), 16, 0, 0);
     }
     __syncthreads();
 
     const int hi = lane >> 5, ql = lane & 31;
+    // transpose-read addressing (probed on gfx950, tools/probe/tr_probe.hip): inside a 16-lane group, lane i supplies the address
+    // of 4 consecutive halfs and lane l receives element (l & 3) of the words addressed by lanes 4*jj + ((l & 15) >> 2), jj = 0..3.
+    // With lane i pointing at V[key0 + (i >> 2)][d0 + 4*(i & 3) ..], lane l therefore receives V[key0 + jj][d0 + (l & 15)]: four
+    // consecutive keys of ITS output dimension — the A-operand fragment of O^T = V^T P^T, without a transposed copy of V.
+    const int i16 = lane & 15, vrow = hi * 4 + (i16 >> 2), vd = ((lane >> 4) & 1) * 16 + 4 * (i16 & 3), vswz = ((vrow >> 1) & 1) << 2;
+    int voff[2];                                           // byte offset of this lane's word for the output halves j = 0, 1
+#pragma unroll
+    for (int j = 0; j < 2; ++j) voff[j] = vrow * (ATT_DH * 2) + ((((j * 4 + (vd >> 3)) ^ vswz)) << 4) + (vd & 7) * 2;
     const int NTq = (Lq + 31) >> 5;
     for (int qb = wave; qb < NTq; qb += NW) {
         const int q = qb * 32 + ql;                     // this lane's query row
@@ -618,10 +624,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const half_t
                     for (int e = 0; e < 8; ++e) pf[e] = (half_t)st[u][s * 8 + e];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        // V^T fragment: row d = j*32 + ql, keys t*32 + 16s + 4hi + {0..3} and the same + 8
-                        const half_t* vp = Vt + (j * 32 + ql) * LV + (t0 + u) * 32 + s * 16 + hi * 4;
-                        const half4_t v0 = *reinterpret_cast<const half4_t*>(vp);
-                        const half4_t v1 = *reinterpret_cast<const half4_t*>(vp + 8);
+                        // V^T fragment: row d = j*32 + ql, keys t*32 + 16s + 4hi + {0..3} and the same + 8: two transpose-reads
+                        const char* vb = reinterpret_cast<const char*>(Vs) + ((t0 + u) * 32 + s * 16) * (ATT_DH * 2) + voff[j];
+                        const half4_t v0 = tr_read4(vb);
+                        const half4_t v1 = tr_read4(vb + 8 * (ATT_DH * 2));
                         const half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                         o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[j], 0, 0, 0);
                     }
@@ -1218,8 +1224,8 @@ extern "C" int pclip_attention_q_f16(const void* q, int ldq, long q_batch_stride
                   "pclip_attention_q_f16: strides / offsets must be multiples of 8 halves");
     if (B == 0) return PCLIP_OK;
     const int NT = ceil_div(L, 32), LP = NT * 32;
-    const int LV = (LP / 4) % 2 ? LP : LP + 4;
-    const size_t lds = (size_t)LP * ATT_DH * 2 + (size_t)ATT_DH * LV * 2;
+    const int LV = 0;                                       // (unused: V is kept row-major now)
+    const size_t lds = 2 * (size_t)LP * ATT_DH * 2;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)attention_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
