@@ -197,6 +197,11 @@ int pclip_attention_q_f16(const void* q, int ldq, long q_batch_stride, const voi
 int pclip_im2col_patches_f16(const void* img, int B, int R, int P, void* cols, int ld, pclip_stream_t stream);
 int pclip_vit_assemble_tokens_f16(const void* patch_emb, const void* class_emb, const void* pos_emb, int B,
                                   int G2, int W, void* tokens, pclip_stream_t stream);
+/* The same assembly fused with ln_pre and the first block's ln_1 (clip/model.py:225-227, 188): x0 = ln_pre(tokens) (the residual
+ * stream entering the transformer) and h = ln_1(x0), one pass per token row, bit-identical to the three separate calls. */
+int pclip_vit_embed_ln_f16(const void* patch_emb, const void* class_emb, const void* pos_emb, int B, int G2, int W,
+                           const float* gamma_pre, const float* beta_pre, const float* gamma_1, const float* beta_1, float eps,
+                           void* x0, void* h, pclip_stream_t stream);
 
 /* Text stem (clip/model.py:342-344): x = token_embedding[text] + positional_embedding, fp16. */
 int pclip_text_embed_f16(const int64_t* tokens, const void* tok_emb, const void* pos_emb, int B, int L, int W,

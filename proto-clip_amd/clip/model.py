@@ -63,7 +63,7 @@ def _transformer(width, layers):
     return t
 
 
-def _run_blocks(x, blocks, B, L, heads, causal, select=None, first_token=False):
+def _run_blocks(x, blocks, B, L, heads, causal, select=None, first_token=False, h0=None):
     """ResidualAttentionBlock.forward (clip/model.py:187-190) per layer on x [B*L, W] fp16.
     Each residual add is fused into the LayerNorm that reads its result, so the stream of a block is
         h = LN1(x [+ d])   qkv = in_proj(h)   a = attention(qkv)   d = out_proj(a)
@@ -81,7 +81,7 @@ def _run_blocks(x, blocks, B, L, heads, causal, select=None, first_token=False):
     n = len(blocks)
     for i, blk in enumerate(blocks):
         if d is None:
-            h = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias)
+            h = h0 if (i == 0 and h0 is not None) else ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias)   # h0: ln_1 of block 0, already done
         else:
             h = ops.add_layernorm(x, d, blk.ln_1.weight, blk.ln_1.bias)
         if select is not None and i == n - 1 and first_token and not causal:
@@ -170,10 +170,16 @@ class VisionTransformer(nn.Module):
         projT = self._cache.get("projT", self.proj, lambda t: t.t().contiguous())
         cols = ops.im2col_patches(img, P)                                   # conv1 as GEMM (clip/model.py:222)
         patch = ops.gemm(cols, wconv)
-        x = ops.vit_assemble_tokens(patch, cls16, pos16, B, G * G, W)       # clip/model.py:225-226
-        x = ops.layernorm(x, self.ln_pre.weight, self.ln_pre.bias)          # 227
+        blocks = self.transformer.resblocks
+        h0 = None
+        if len(blocks) > 0:                                                 # tokens + ln_pre + the first block's ln_1 in one pass
+            x, h0 = ops.vit_embed_ln(patch, cls16, pos16, B, G * G, W, self.ln_pre.weight, self.ln_pre.bias, blocks[0].ln_1.weight,
+                                     blocks[0].ln_1.bias)                   # clip/model.py:225-227, 188
+        else:
+            x = ops.vit_assemble_tokens(patch, cls16, pos16, B, G * G, W)   # clip/model.py:225-226
+            x = ops.layernorm(x, self.ln_pre.weight, self.ln_pre.bias)      # 227
         pick_cls = lambda t: t.view(B, L, W)[:, 0, :].contiguous()          # x[:, 0, :], 233 (taken before the last block's tail)
-        x, d = _run_blocks(x, self.transformer.resblocks, B, L, self.heads, causal=False, select=pick_cls, first_token=True)   # 229-231
+        x, d = _run_blocks(x, blocks, B, L, self.heads, causal=False, select=pick_cls, first_token=True, h0=h0)   # 229-231
         if d is None:
             cls = ops.layernorm(x, self.ln_post.weight, self.ln_post.bias)
         else:                                                               # ln_post((x + d)[:, 0, :]), 233

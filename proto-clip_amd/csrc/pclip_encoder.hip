@@ -700,6 +700,92 @@ __global__ __launch_bounds__(256) void assemble_tokens_kernel(const half_t* __re
     }
 }
 
+// The ViT stem after the patch GEMM in ONE pass per token row: x0 = ln_pre(r16([class ; patch] + pos)) and h = ln_1 of the first
+// block (clip/model.py:225-227, 188), both written — the three kernels it replaces (assemble, ln_pre, ln_1) re-read the
+// residual stream twice.  Row arithmetic identical to assemble_tokens_kernel + layernorm_kernel<MODE 0> (same summation order).
+template <int NCH>
+__device__ __forceinline__ void ln_row_inplace(float (&v)[NCH][8], int D, int lane, const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+        if (c * 512 + lane * 8 < D) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[c][j];
+        }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+        if (c * 512 + lane * 8 < D) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float t = v[c][j] - mean; q += t * t; }
+        }
+    const float rstd = 1.f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int d = c * 512 + lane * 8;
+        if (d < D) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float o = (v[c][j] - mean) * rstd * (float)gamma[d + j] + (float)beta[d + j];
+                v[c][j] = r16(o);
+            }
+        }
+    }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void vit_embed_ln_kernel(const half_t* __restrict__ patch, const half_t* __restrict__ cls,
+                                                           const half_t* __restrict__ pos, int B, int G2, int W,
+                                                           const float* __restrict__ g0, const float* __restrict__ b0,
+                                                           const float* __restrict__ g1, const float* __restrict__ b1, float eps,
+                                                           half_t* __restrict__ x0, half_t* __restrict__ h) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int L = G2 + 1;
+    const size_t R = (size_t)B * L;
+    for (size_t row = (size_t)blockIdx.x * 4 + wave; row < R; row += (size_t)gridDim.x * 4) {
+        const int l = (int)(row % L);
+        const size_t bb = row / L;
+        const half_t* src = l == 0 ? cls : patch + (bb * G2 + (l - 1)) * W;
+        float v[NCH][8];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int d = c * 512 + lane * 8;
+            if (d < W) {
+                const half8_t a = ld_half8(src + d), p = ld_half8(pos + (size_t)l * W + d);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[c][j] = (float)(half_t)((float)a[j] + (float)p[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+            }
+        }
+        ln_row_inplace<NCH>(v, W, lane, g0, b0, eps);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int d = c * 512 + lane * 8;
+            if (d < W) {
+                half8_t o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (half_t)v[c][j];
+                st_half8(x0 + row * W + d, o);
+            }
+        }
+        ln_row_inplace<NCH>(v, W, lane, g1, b1, eps);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int d = c * 512 + lane * 8;
+            if (d < W) {
+                half8_t o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (half_t)v[c][j];
+                st_half8(h + row * W + d, o);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restrict__ tokens,
                                                          const half_t* __restrict__ emb,
                                                          const half_t* __restrict__ pos, int B, int L, int W, int vocab,
@@ -1277,6 +1363,24 @@ extern "C" int pclip_vit_assemble_tokens_f16(const void* patch_emb, const void* 
     assemble_tokens_kernel<<<flat_grid((size_t)B * (G2 + 1) * (W / 8)), 256, 0, (hipStream_t)stream>>>(
         (const half_t*)patch_emb, (const half_t*)class_emb, (const half_t*)pos_emb, B, G2, W, (half_t*)tokens);
     return pclip_check_launch("assemble_tokens");
+}
+
+extern "C" int pclip_vit_embed_ln_f16(const void* patch_emb, const void* class_emb, const void* pos_emb, int B, int G2, int W,
+                                      const float* gamma_pre, const float* beta_pre, const float* gamma_1, const float* beta_1, float eps,
+                                      void* x0, void* h, pclip_stream_t stream) {
+    PCLIP_REQUIRE(patch_emb && class_emb && pos_emb && gamma_pre && beta_pre && gamma_1 && beta_1 && x0 && h, "pclip_vit_embed_ln_f16: null pointer");
+    PCLIP_REQUIRE(B >= 0 && G2 > 0 && W > 0 && W % 8 == 0 && W <= 4096, "pclip_vit_embed_ln_f16: bad shape B=%d G2=%d W=%d", B, G2, W);
+    if (B == 0) return PCLIP_OK;
+    const size_t R = (size_t)B * (G2 + 1);
+    const int grid = (int)((R + 3) / 4 > 16384 ? 16384 : (R + 3) / 4);
+#define PCLIP_VEL(NCH) vit_embed_ln_kernel<NCH><<<grid, 256, 0, (hipStream_t)stream>>>((const half_t*)patch_emb, (const half_t*)class_emb, \
+        (const half_t*)pos_emb, B, G2, W, gamma_pre, beta_pre, gamma_1, beta_1, eps, (half_t*)x0, (half_t*)h)
+    if (W <= 512) PCLIP_VEL(1);
+    else if (W <= 1024) PCLIP_VEL(2);
+    else if (W <= 2048) PCLIP_VEL(4);
+    else PCLIP_VEL(8);
+#undef PCLIP_VEL
+    return pclip_check_launch("vit_embed_ln");
 }
 
 extern "C" int pclip_text_embed_f16(const int64_t* tokens, const void* tok_emb, const void* pos_emb, int B, int L, int W,

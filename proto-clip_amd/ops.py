@@ -395,6 +395,17 @@ def vit_assemble_tokens(patch_emb, class_emb, pos_emb, B: int, G2: int, W: int) 
     return tokens
 
 
+def vit_embed_ln(patch_emb, class_emb, pos_emb, B: int, G2: int, W: int, g_pre, b_pre, g_1, b_1, eps: float = 1e-5):
+    """(x0, h) = (ln_pre(tokens), ln_1(x0)) with tokens = [class ; patches] + pos, one pass (clip/model.py:225-227, 188)."""
+    x0 = torch.empty(B * (G2 + 1), W, dtype=torch.float16, device=patch_emb.device)
+    h = torch.empty_like(x0)
+    f = lambda t: t if t.dtype == torch.float32 else t.float()
+    g_pre, b_pre, g_1, b_1 = f(g_pre), f(b_pre), f(g_1), f(b_1)
+    check(_lib.load().pclip_vit_embed_ln_f16(ptr(patch_emb), ptr(class_emb), ptr(pos_emb), B, G2, W, ptr(g_pre), ptr(b_pre), ptr(g_1),
+                                             ptr(b_1), eps, ptr(x0), ptr(h), stream()), "pclip_vit_embed_ln_f16")
+    return x0, h
+
+
 def text_embed(tokens, tok_emb, pos_emb) -> torch.Tensor:
     require_cuda(tokens, tok_emb)
     B, L = tokens.shape

@@ -482,6 +482,23 @@ def test_full_size_vit_b16_against_oracle():
     assert torch.equal(f1[0], f[2])
 
 
+@pytest.mark.parametrize("B,G2,W", [(3, 49, 768), (2, 196, 768), (1, 256, 1024), (5, 4, 128), (2, 9, 64)])
+def test_vit_stem_fused_equals_separate(ops, B, G2, W):
+    """tokens + ln_pre + the first block's ln_1 in one pass (pclip_vit_embed_ln_f16) against the three separate kernels: the row
+    arithmetic is the same, so both outputs must agree bit for bit."""
+    g = torch.Generator(device="cuda").manual_seed(B * G2 + W)
+    patch = (torch.randn(B * G2, W, device="cuda", generator=g) * 0.8).half()
+    cls = torch.randn(W, device="cuda", generator=g).half()
+    pos = (torch.randn(G2 + 1, W, device="cuda", generator=g) * 0.1).half()
+    gp, bp = 1 + 0.2 * torch.randn(W, device="cuda", generator=g), 0.1 * torch.randn(W, device="cuda", generator=g)
+    g1, b1 = 1 + 0.2 * torch.randn(W, device="cuda", generator=g), 0.1 * torch.randn(W, device="cuda", generator=g)
+    x0, h = ops.vit_embed_ln(patch, cls, pos, B, G2, W, gp, bp, g1, b1)
+    t = ops.vit_assemble_tokens(patch, cls, pos, B, G2, W)
+    r0 = ops.layernorm(t, gp, bp)
+    assert torch.equal(x0, r0)
+    assert torch.equal(h, ops.layernorm(r0, g1, b1))
+
+
 def test_serving_low_latency_mode_full_size():
     """A ViT-B/16 request through the serving entry with the split-K linears (default) and without: the split changes fp32
     summation order only, so the top-5 probabilities agree within the north star's 1e-3 and the top-1 class is the same; the
