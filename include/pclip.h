@@ -195,6 +195,8 @@ int pclip_attention_q_f16(const void* q, int ldq, long q_batch_stride, const voi
  * [B*G*G, ld >= 3*P*P] rows, zero beyond 3*P*P (the GEMM against conv1.weight follows), and the token assembly
  * x = [class_emb ; patches] + pos -> fp16 [B, 1+G*G, W]. */
 int pclip_im2col_patches_f16(const void* img, int B, int R, int P, void* cols, int ld, pclip_stream_t stream);
+/* the same gather from fp32 images, fused with their cast to fp16 (`image.type(self.dtype)`, clip/model.py:339) */
+int pclip_im2col_patches_f32(const float* img, int B, int R, int P, void* cols, int ld, pclip_stream_t stream);
 int pclip_vit_assemble_tokens_f16(const void* patch_emb, const void* class_emb, const void* pos_emb, int B,
                                   int G2, int W, void* tokens, pclip_stream_t stream);
 /* The same assembly fused with ln_pre and the first block's ln_1 (clip/model.py:225-227, 188): x0 = ln_pre(tokens) (the residual

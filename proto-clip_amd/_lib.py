@@ -52,6 +52,7 @@ _SIGS = {
     "pclip_attention_f16": [_P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "pclip_attention_q_f16": [_P, c_int, c_long, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "pclip_im2col_patches_f16": [_P, c_int, c_int, c_int, _P, c_int, _P],
+    "pclip_im2col_patches_f32": [_P, c_int, c_int, c_int, _P, c_int, _P],
     "pclip_vit_assemble_tokens_f16": [_P, _P, _P, c_int, c_int, c_int, _P, _P],
     "pclip_vit_embed_ln_f16": [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P, _P, _P],
     "pclip_text_embed_f16": [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P],

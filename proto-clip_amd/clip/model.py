@@ -150,9 +150,7 @@ class VisionTransformer(nn.Module):
         B, P, W = img.shape[0], self.patch_size, self.width
         G = self.input_resolution // P
         L = G * G + 1
-        if img.dtype == torch.float32:
-            img = ops.cast_f16(img)                      # image.type(self.dtype), clip/model.py:339
-        elif img.dtype != torch.float16:
+        if img.dtype not in (torch.float32, torch.float16):   # fp32: image.type(self.dtype) (clip/model.py:339) rides on the im2col gather
             raise PclipError(f"unsupported image dtype {img.dtype}")
         img = img.contiguous()
         kp = 3 * P * P

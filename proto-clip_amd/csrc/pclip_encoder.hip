@@ -656,8 +656,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const half_t
 // ---- ViT / text stems ------------------------------------------------------------------------------
 // conv1 (kernel = stride = P, no bias) == GEMM of im2col rows [B*G*G, ld >= 3*P*P] against weight
 // [W, 3*P*P]; columns >= 3*P*P are zero (K padded to the GEMM's BK for ViT-L/14, 3*14*14 = 588 -> 640).
-template <bool VEC>
-__global__ __launch_bounds__(256) void im2col_kernel(const half_t* __restrict__ img, int B, int R, int P, int G,
+// IT = float: the image.type(self.dtype) cast of clip/model.py:339 happens on the way (one rounding per pixel, as the cast kernel's)
+template <bool VEC, typename IT = half_t>
+__global__ __launch_bounds__(256) void im2col_kernel(const IT* __restrict__ img, int B, int R, int P, int G,
                                                      int ld, half_t* __restrict__ cols) {
     const int KP = 3 * P * P;
     constexpr int V = VEC ? 8 : 1;
@@ -674,8 +675,19 @@ __global__ __launch_bounds__(256) void im2col_kernel(const half_t* __restrict__ 
         }
         const int gx = (int)(pr % G), gy = (int)((pr / G) % G), bb = (int)(pr / ((size_t)G * G));
         const int c = k / (P * P), py = (k / P) % P, px = k % P;
-        const half_t* src = img + (((size_t)bb * 3 + c) * R + gy * P + py) * R + gx * P + px;
-        if (VEC) st_half8(dst, ld_half8(src)); else *dst = *src;
+        const IT* src = img + (((size_t)bb * 3 + c) * R + gy * P + py) * R + gx * P + px;
+        if (VEC) {
+            half8_t o;
+            if constexpr (sizeof(IT) == 2) o = ld_half8(reinterpret_cast<const half_t*>(src));
+            else {
+                const float4_t a = *reinterpret_cast<const float4_t*>(src), b = *reinterpret_cast<const float4_t*>(src + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { o[j] = (half_t)a[j]; o[j + 4] = (half_t)b[j]; }
+            }
+            st_half8(dst, o);
+        } else {
+            *dst = (half_t)*src;
+        }
     }
 }
 
@@ -1353,6 +1365,19 @@ extern "C" int pclip_im2col_patches_f16(const void* img, int B, int R, int P, vo
     if (vec) im2col_kernel<true><<<flat_grid(total), 256, 0, (hipStream_t)stream>>>((const half_t*)img, B, R, P, G, ld, (half_t*)cols);
     else im2col_kernel<false><<<flat_grid(total), 256, 0, (hipStream_t)stream>>>((const half_t*)img, B, R, P, G, ld, (half_t*)cols);
     return pclip_check_launch("im2col");
+}
+
+extern "C" int pclip_im2col_patches_f32(const float* img, int B, int R, int P, void* cols, int ld, pclip_stream_t stream) {
+    PCLIP_REQUIRE(img && cols, "pclip_im2col_patches_f32: null pointer");
+    PCLIP_REQUIRE(B >= 0 && P > 0 && R > 0 && R % P == 0, "pclip_im2col_patches_f32: bad B=%d R=%d P=%d", B, R, P);
+    PCLIP_REQUIRE(ld >= 3 * P * P, "pclip_im2col_patches_f32: ld=%d < 3*P*P", ld);
+    if (B == 0) return PCLIP_OK;
+    const int G = R / P;
+    const bool vec = P % 8 == 0 && R % 8 == 0 && ld % 8 == 0 && ((uintptr_t)img & 15) == 0;
+    const size_t total = (size_t)B * G * G * (vec ? ld / 8 : ld);
+    if (vec) im2col_kernel<true, float><<<flat_grid(total), 256, 0, (hipStream_t)stream>>>(img, B, R, P, G, ld, (half_t*)cols);
+    else im2col_kernel<false, float><<<flat_grid(total), 256, 0, (hipStream_t)stream>>>(img, B, R, P, G, ld, (half_t*)cols);
+    return pclip_check_launch("im2col (fp32 images)");
 }
 
 extern "C" int pclip_vit_assemble_tokens_f16(const void* patch_emb, const void* class_emb, const void* pos_emb, int B,

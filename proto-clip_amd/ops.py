@@ -383,6 +383,9 @@ def im2col_patches(img: torch.Tensor, P: int) -> torch.Tensor:
     G = R // P
     ld = (3 * P * P + 63) // 64 * 64        # K padded to the GEMM's K-tile (ViT-L/14: 588 -> 640)
     cols = torch.empty(B * G * G, ld, dtype=torch.float16, device=img.device)
+    if img.dtype == torch.float32:             # fused with the cast to fp16 (clip/model.py:339)
+        check(_lib.load().pclip_im2col_patches_f32(ptr(img), B, R, P, ptr(cols), ld, stream()), "pclip_im2col_patches_f32")
+        return cols
     check(_lib.load().pclip_im2col_patches_f16(ptr(img), B, R, P, ptr(cols), ld, stream()),
           "pclip_im2col_patches_f16")
     return cols

@@ -208,6 +208,9 @@ def test_stems(ops):
     assert cols.shape[1] == 640 and torch.equal(cols[:, :588], ref) and cols[:, 588:].abs().max().item() == 0
     x32 = torch.from_numpy(synth.normal((1000,), 24, 2)).float()
     assert torch.equal(ops.cast_f16(x32.cuda()).cpu(), x32.half())
+    # fp32 images: the cast to fp16 rides on the gather (vector path P % 8 == 0 and the scalar path of P = 14)
+    for im, pp in ((torch.from_numpy(synth.normal((B, 3, R, R), 24, 5)).float() * 1.7, P), (torch.from_numpy(synth.normal((2, 3, 70, 70), 24, 6)).float(), 14)):
+        assert torch.equal(ops.im2col_patches(im.cuda(), pp), ops.im2col_patches(im.half().cuda(), pp))
     toks = torch.tensor([[5, 9, 2, 11, 0, 0], [5, 11, 0, 0, 0, 0]])
     emb = torch.from_numpy(synth.normal((12, 64), 24, 3)).half()
     pos = torch.from_numpy(synth.normal((6, 64), 24, 4)).half()
