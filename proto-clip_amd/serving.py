@@ -50,9 +50,11 @@ def load_pretrained_mb_and_adapters(config=None, memory_bank_v_path=None, memory
 class ProtoClipClassifier:
     """classify(images [B,3,R,R]) -> (top-k probabilities [B,k] fp32, top-k class indices [B,k] int64)."""
 
-    def __init__(self, clip_model, embeddings_v, embeddings_t, adapter, shots, alpha, beta, top_k=5, class_names=None, low_latency=True):
+    def __init__(self, clip_model, embeddings_v, embeddings_t, adapter, shots, alpha, beta, top_k=5, class_names=None, low_latency=True,
+                 auto_graph=False, max_graphs=8):
         self.clip_model, self.adapter = clip_model, adapter
         self.low_latency = bool(low_latency)       # split-K linears for small requests (ops.low_latency)
+        self.auto_graph, self.max_graphs = bool(auto_graph), int(max_graphs)   # capture a hipGraph per new batch size on first use
         self.alpha, self.beta, self.top_k = float(alpha), float(beta), int(top_k)
         self.class_names = class_names
         NxK = embeddings_v.shape[0]
@@ -101,6 +103,9 @@ class ProtoClipClassifier:
     def classify(self, images):
         B = images.shape[0]
         hit = self._graphs.get(B)
+        if hit is None and self.auto_graph and images.dtype == torch.float32 and len(self._graphs) < self.max_graphs and B > 0:
+            self.capture(B)                                # eager launches cannot keep up with a small request
+            hit = self._graphs.get(B)
         if hit is not None and images.dtype == torch.float32:
             g, static_in, tp, ti = hit
             static_in.copy_(images, non_blocking=True)

@@ -527,6 +527,11 @@ def test_serving_low_latency_mode_full_size():
     fast.capture(3)
     tg, ig = fast.classify(imgs)
     assert torch.equal(tg, tp) and torch.equal(ig, ti)
+    auto = ProtoClipClassifier(model, ev, et, adapter, shots=K, alpha=0.2, beta=12.0, top_k=5, auto_graph=True)
+    for n in (3, 1, 3):                                     # a graph per batch size, captured on first use
+        ta, ia = auto.classify(imgs[:n])
+        assert torch.equal(ta, tp[:n]) and torch.equal(ia, ti[:n])
+    assert sorted(auto._graphs) == [1, 3]
 
 
 def test_full_size_rn50_against_oracle():
