@@ -99,6 +99,13 @@ def cls_acc(output, target, topk=1):
     return 100 * acc / target.shape[0]
 
 
+def get_target_inds(info):
+    """Episode ground-truth labels [n_class, k_query, 1] int64 on the GPU from info = (n_class, k_support, k_query)
+    (reference utils.py:112-122; no caller in the reference — kept for API completeness)."""
+    n_class, _, k_query = info
+    return torch.arange(n_class, device="cuda").view(n_class, 1, 1).expand(n_class, k_query, 1).long()
+
+
 def clip_classifier(classnames, template, clip_model, tokenize=None):
     """Textual memory bank [D, N] fp16 (reference utils.py:256-273).  All N*T prompts go through the
     text tower in large batches (the reference issues N calls of T prompts) and the per-class
