@@ -129,12 +129,26 @@ def train_proto_clip(cfg, visual_memory_keys, textual_memory_bank, adapter, val_
     return dict(history=history, best_acc=best_acc, best_epoch=best_epoch, trainer=trainer)
 
 
+# per-dataset (search_scale, search_step) constants the reference writes into cfg before a run (main.py:74-103; Tip-Adapter
+# legacy, read by nothing on this path — kept so that a cfg dict leaves run_proto_clip with the same keys)
+_SEARCH = {"caltech101": ([12, 5], [200, 20]), "dtd": ([13, 13], [200, 20]), "eurosat": ([12, 10], [200, 20]),
+           "fgvc": ([30, 30], [200, 20]), "food101": ([10, 10], [200, 20]), "imagenet": ([7, 3], [200, 20]),
+           "oxford_flowers": ([50, 50], [200, 20]), "oxford_pets": ([7, 3], [200, 20]), "stanford_cars": ([20, 10], [200, 20]),
+           "sun397": ([12, 10], [200, 20]), "ucf101": ([7, 3], [200, 20]), "fewsol": ([13, 13], [200, 20])}
+
+
+def search_scale_step(cfg):
+    cfg["search_scale"], cfg["search_step"] = _SEARCH.get(cfg.get("dataset"), (None, None))
+    return cfg
+
+
 def run_proto_clip(cfg, visual_memory_keys, visual_memory_values, val_features, val_labels, test_features,
                    test_labels, textual_memory_bank, clip_model, text_prompts, train_loader_F=None, variant="main"):
     """Reference main.py:105-465.  Returns a dict of everything it computed."""
     ndim, NxK = visual_memory_keys.shape
     K = cfg["shots"]
     N = NxK // K
+    cfg = search_scale_step(cfg)                                        # main.py:111
     qt = variant == "qt"                                               # main.qt.py: queries from the image loader
     subdir = "best-alpha-beta" if qt else "alpha-beta"                 # main.qt.py:292, 327
     alpha_list, beta_list = hp_grid(rounded=not qt)
