@@ -270,7 +270,7 @@ class ModifiedResNet(nn.Module):
 
     def _conv3_bn_relu(self, key, x, strides, B, H, W, C, conv, bn, stride=1):
         sc, sh = self._bn_affine(key, bn)
-        if stride == 1 and C % 64 == 0 and conv.weight.shape[0] % 64 == 0 and strides == (H * W * C, W * C, C, 1):
+        if stride == 1 and (C % 64 == 0 or C in (8, 16, 32)) and conv.weight.shape[0] % 64 == 0 and strides == (H * W * C, W * C, C, 1):
             return ops.conv3x3_bn(x, self._w3x3(key, conv), sc, sh, B, H, W, C, relu=True)   # implicit GEMM: no im2col buffer
         cols = ops.im2col3x3(x, strides, B, H, W, C, stride)
         return ops.gemm_bn(cols, self._w3x3(key, conv), sc, sh, relu=True)                   # relu(bn(conv3x3(x))) in one launch

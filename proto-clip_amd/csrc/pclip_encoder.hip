@@ -177,7 +177,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv3x3_fast_kernel(const half
     const int G = gridDim.x;
     int tile = pgemm::xcd_remap(blockIdx.x, G);
     if (tile >= ntiles) return;
-    const int K = 9 * Cin, ldb = K, nt = K / pgemm::BK;
+    const int nt = (9 * Cin + pgemm::BK - 1) / pgemm::BK, ldb = nt * pgemm::BK;    // w rows are zero-padded to the K-tile (Cin < 64)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave % C::WN;
     pgemm::ConvGather<C> ga{x, zero, H, W, Cin, M, {}, {}};
     auto copy_affine = [&](int t, int par) {
@@ -1043,12 +1043,12 @@ __global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void conv3x3_small_kernel(co
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
     const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
-    const int K = 9 * Cin;
+    const int nt = (9 * Cin + pgemm::BK - 1) / pgemm::BK, K = nt * pgemm::BK;       // w rows are zero-padded to the K-tile (Cin < 64)
     const int tid = threadIdx.x, wave = tid >> 6, wn = wave % C::WN;
     pgemm::ConvGather<C> ga{x, zero, H, W, Cin, M, {}, {}};
     ga.prepare(m0);
     pgemm::Acc<C> acc;
-    pgemm::mainloop_ring_g<C, kSmallStages>([&](int t, char* dst) { ga.stage(t, dst); }, w, K, N, K / pgemm::BK, n0, smem, acc, [&]() {
+    pgemm::mainloop_ring_g<C, kSmallStages>([&](int t, char* dst) { ga.stage(t, dst); }, w, K, N, nt, n0, smem, acc, [&]() {
 #pragma unroll
         for (int i = 0; i < C::TM; ++i)
 #pragma unroll
@@ -1235,7 +1235,7 @@ extern "C" int pclip_conv3x3_bn_f16(const void* x, const void* w, const void* ze
                                     const float* scale, const float* shift, int relu, void* y, pclip_stream_t stream) {
     PCLIP_REQUIRE(x && w && zero_line && scale && shift && y, "pclip_conv3x3_bn_f16: null pointer");
     PCLIP_REQUIRE(B >= 0 && H > 0 && W > 0 && H < 32768 && W < 32768, "pclip_conv3x3_bn_f16: bad shape B=%d H=%d W=%d", B, H, W);
-    PCLIP_REQUIRE(Cin > 0 && Cin % 64 == 0, "pclip_conv3x3_bn_f16: Cin=%d must be a multiple of 64 (use im2col + pclip_gemm_bn_f16 otherwise)", Cin);
+    PCLIP_REQUIRE(Cin > 0 && (Cin % 64 == 0 || Cin == 8 || Cin == 16 || Cin == 32), "pclip_conv3x3_bn_f16: Cin=%d must be a multiple of 64, or 8 / 16 / 32 (use im2col + pclip_gemm_bn_f16 otherwise)", Cin);
     PCLIP_REQUIRE(Cout > 0 && Cout % 64 == 0, "pclip_conv3x3_bn_f16: Cout=%d must be a multiple of 64", Cout);
     PCLIP_REQUIRE((long)B * H * W < (1L << 31) / 1, "pclip_conv3x3_bn_f16: too many output pixels");
     PCLIP_REQUIRE(((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)x & 15) == 0,

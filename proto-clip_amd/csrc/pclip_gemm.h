@@ -214,7 +214,7 @@ __device__ __forceinline__ void mainloop(const half_t* __restrict__ A, int lda, 
 
 // ---- implicit-GEMM gather for a 3x3 / stride 1 / pad 1 convolution on NHWC fp16 activations ------------------------------
 // Row m of the GEMM is output pixel (b, y, x); K-tile t covers tap = (t*64) / Cin and input channels c0 = (t*64) % Cin
-// (Cin % 64 == 0), i.e. the 128 contiguous bytes x[b, y+dy-1, x+dx-1, c0 .. c0+63] — or 128 zero bytes outside the image,
+// (Cin % 64 == 0; Cin = 8 / 16 / 32 take the per-chunk path of stage()), i.e. the 128 contiguous bytes x[b, y+dy-1, x+dx-1, c0 .. c0+63] — or 128 zero bytes outside the image,
 // fetched from a caller-provided zero line, because an LDS-DMA cannot be predicated per lane without leaving stale LDS.
 // The im2col matrix (9x the activation) is never materialised.
 template <class C>
@@ -237,6 +237,21 @@ struct ConvGather {
     }
     __device__ __forceinline__ void stage(int t, char* dst) const {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (Cin < BK) {
+            // Cin = 8 / 16 / 32 (the ResNet stem): a K-tile spans 64 / Cin taps, so the tap belongs to the 16-byte chunk, not to the
+            // row; taps >= 9 (K padded to the K-tile, zero weights there) read the zero line
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int r = wave * (C::BM / C::NWAVES) + i * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ swz_key(r);
+                const int k = t * BK + c * 8, tap = k / Cin, ci = k - tap * Cin, dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+                const int y = (yx[i] >> 16) + dy, xx = (yx[i] & 0xffff) + dx;
+                const bool in = tap < 9 && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
+                const half_t* src = in ? x + ((size_t)(pix[i] + dy * W + dx) * Cin + ci) : zero + c * 8;
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dst + (wave * (C::BM / C::NWAVES) + i * 8) * ROW_BYTES), 16, 0, 0);
+            }
+            return;
+        }
         const int k0 = t * BK, tap = k0 / Cin, c0 = k0 - tap * Cin, dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
 #pragma unroll
         for (int i = 0; i < NR; ++i) {

@@ -305,11 +305,12 @@ _zero_line = {}
 
 def conv3x3_bn(x, w, scale, shift, B: int, H: int, W: int, Cin: int, relu: bool = True):
     """relu?(bn(conv3x3(x))) (stride 1, pad 1) on NHWC rows x [B*H*W, Cin] with w [Cout, 9*Cin] in (ky, kx, Cin) order:
-    implicit GEMM, no im2col buffer.  Cin, Cout multiples of 64."""
+    implicit GEMM, no im2col buffer.  Cin a multiple of 64 — or 8 / 16 / 32 with the rows of w zero-padded to a multiple of 64 —
+    and Cout a multiple of 64."""
     require_cuda(x, w, scale, shift)
     x, w = _f16c(x), _f16c(w)
     Cout = w.shape[0]
-    if w.shape[1] != 9 * Cin or x.numel() != B * H * W * Cin:
+    if w.shape[1] != (9 * Cin + 63) // 64 * 64 or x.numel() != B * H * W * Cin:
         raise _lib.PclipError("conv3x3_bn: shape mismatch")
     z = _zero_line.get(x.device)
     if z is None:

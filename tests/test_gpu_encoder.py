@@ -427,7 +427,8 @@ def test_gemm_bn_equals_gemm_then_bn_act(ops, M, N, K, relu):
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,relu", [(2, 56, 56, 64, 64, True), (3, 28, 28, 128, 128, True), (2, 14, 14, 256, 256, True),
                                                  (5, 7, 7, 512, 512, True), (1, 9, 7, 64, 128, False), (3, 13, 11, 64, 64, True),
-                                                 (64, 56, 56, 64, 64, True), (1, 1, 1, 64, 64, True)])
+                                                 (64, 56, 56, 64, 64, True), (1, 1, 1, 64, 64, True), (2, 28, 28, 32, 64, True),
+                                                 (16, 112, 112, 32, 64, True), (1, 9, 11, 16, 64, False), (3, 7, 5, 8, 128, True)])
 def test_conv3x3_implicit_gemm_equals_im2col_path(ops, B, H, W, Cin, Cout, relu):
     """The implicit-GEMM convolution (LDS-DMA gather of every tap, zero line outside the image) against the materialised
     im2col + fused GEMM/BN path: same MFMA k-order -> bit-identical; plus a torch conv2d reference on the small cases."""
@@ -435,7 +436,10 @@ def test_conv3x3_implicit_gemm_equals_im2col_path(ops, B, H, W, Cin, Cout, relu)
     x = (torch.randn(B * H * W, Cin, device="cuda", generator=g) * 0.7).half()
     w = (torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) * (9 * Cin) ** -0.5).half()
     ss = torch.stack([1 + 0.3 * torch.randn(Cout, device="cuda", generator=g), 0.2 * torch.randn(Cout, device="cuda", generator=g)]).contiguous()
-    w2 = w.reshape(Cout, 9 * Cin).contiguous()
+    w2 = w.reshape(Cout, 9 * Cin)
+    if (9 * Cin) % 64:                                       # Cin < 64: rows zero-padded to the K-tile
+        w2 = torch.cat([w2, w2.new_zeros(Cout, (9 * Cin + 63) // 64 * 64 - 9 * Cin)], dim=1)
+    w2 = w2.contiguous()
     cols = ops.im2col3x3(x, (H * W * Cin, W * Cin, Cin, 1), B, H, W, Cin, 1)
     ref = ops.gemm_bn(cols, w2, ss[0], ss[1], relu=relu)
     got = ops.conv3x3_bn(x, w2, ss[0], ss[1], B, H, W, Cin, relu=relu)
