@@ -164,7 +164,7 @@ int pclip_gemm_bn_f16(const void* A, int lda, const void* B, int ldb, void* C, i
  * GEMM: the im2col matrix is never materialised (each K-tile is gathered by LDS-DMA; taps outside the image read
  * `zero_line`, >= 128 zero bytes in device memory supplied by the caller).  w [Cout, 3, 3, Cin] fp16; y [B*H*W, Cout].
  * Cin % 64 == 0, or Cin = 8 / 16 / 32 (the stem, clip/model.py:138-142) with every row of w zero-padded to a multiple of 64
- * halves; Cout % 64 == 0.  Identical to pclip_im2col3x3_f16 + pclip_gemm_bn_f16 (clip/model.py:20-22, 45-46). */
+ * halves; Cout % 64 == 0, or Cout = 32.  Identical to pclip_im2col3x3_f16 + pclip_gemm_bn_f16 (clip/model.py:20-22, 45-46). */
 int pclip_conv3x3_bn_f16(const void* x, const void* w, const void* zero_line, int B, int H, int W, int Cin, int Cout,
                          const float* scale, const float* shift, int relu, void* y, pclip_stream_t stream);
 

@@ -11,7 +11,7 @@ Precision follows `convert_weights` (clip/model.py:373-394): Linear/conv/project
 LayerNorm and embedding parameters fp32, activations fp16 with fp32 accumulation.
 Both vision towers are built: VisionTransformer (ViT-B/32, ViT-B/16, ViT-L/14) and ModifiedResNet (RN50 /
 RN101: NHWC activations, 1x1 convs as GEMMs and 3x3 convs as implicit GEMMs with the eval BatchNorm (+ReLU) in their
-epilogue; im2col + GEMM only for the 3 / 32-channel stem)."""
+epilogue; im2col + GEMM only for the strided 3-channel first convolution of the stem)."""
 import os
 from collections import OrderedDict
 
@@ -270,7 +270,8 @@ class ModifiedResNet(nn.Module):
 
     def _conv3_bn_relu(self, key, x, strides, B, H, W, C, conv, bn, stride=1):
         sc, sh = self._bn_affine(key, bn)
-        if stride == 1 and (C % 64 == 0 or C in (8, 16, 32)) and conv.weight.shape[0] % 64 == 0 and strides == (H * W * C, W * C, C, 1):
+        if stride == 1 and (C % 64 == 0 or C in (8, 16, 32)) and (conv.weight.shape[0] % 64 == 0 or conv.weight.shape[0] == 32) \
+                and strides == (H * W * C, W * C, C, 1):
             return ops.conv3x3_bn(x, self._w3x3(key, conv), sc, sh, B, H, W, C, relu=True)   # implicit GEMM: no im2col buffer
         cols = ops.im2col3x3(x, strides, B, H, W, C, stride)
         return ops.gemm_bn(cols, self._w3x3(key, conv), sc, sh, relu=True)                   # relu(bn(conv3x3(x))) in one launch

@@ -1236,7 +1236,7 @@ extern "C" int pclip_conv3x3_bn_f16(const void* x, const void* w, const void* ze
     PCLIP_REQUIRE(x && w && zero_line && scale && shift && y, "pclip_conv3x3_bn_f16: null pointer");
     PCLIP_REQUIRE(B >= 0 && H > 0 && W > 0 && H < 32768 && W < 32768, "pclip_conv3x3_bn_f16: bad shape B=%d H=%d W=%d", B, H, W);
     PCLIP_REQUIRE(Cin > 0 && (Cin % 64 == 0 || Cin == 8 || Cin == 16 || Cin == 32), "pclip_conv3x3_bn_f16: Cin=%d must be a multiple of 64, or 8 / 16 / 32 (use im2col + pclip_gemm_bn_f16 otherwise)", Cin);
-    PCLIP_REQUIRE(Cout > 0 && Cout % 64 == 0, "pclip_conv3x3_bn_f16: Cout=%d must be a multiple of 64", Cout);
+    PCLIP_REQUIRE(Cout > 0 && (Cout % 64 == 0 || Cout == 32), "pclip_conv3x3_bn_f16: Cout=%d must be a multiple of 64, or 32", Cout);
     PCLIP_REQUIRE((long)B * H * W < (1L << 31) / 1, "pclip_conv3x3_bn_f16: too many output pixels");
     PCLIP_REQUIRE(((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)x & 15) == 0,
                   "pclip_conv3x3_bn_f16: pointers must be 16-byte aligned");
@@ -1244,6 +1244,8 @@ extern "C" int pclip_conv3x3_bn_f16(const void* x, const void* w, const void* ze
     int cus = pclip_device_cus();
     if (cus <= 0) cus = 256;
     hipStream_t s = (hipStream_t)stream;
+    if (Cout == 32)                                                             // the stem's 32 -> 32 convolution: 256 x 32 tiles
+        return launch_conv<CfgThin>(x, zero_line, w, B, H, W, Cin, Cout, scale, shift, relu, y, 2 * cus, s);
     static const bool small_on = !(getenv("PCLIP_GEMM_SMALL") && getenv("PCLIP_GEMM_SMALL")[0] == '0');
     if (small_on && small_applies(B * H * W, Cout, cus)) {                     // a request of a few images: the ring kernel
         if (int e = small_attr()) return e;

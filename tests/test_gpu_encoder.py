@@ -428,7 +428,8 @@ def test_gemm_bn_equals_gemm_then_bn_act(ops, M, N, K, relu):
 @pytest.mark.parametrize("B,H,W,Cin,Cout,relu", [(2, 56, 56, 64, 64, True), (3, 28, 28, 128, 128, True), (2, 14, 14, 256, 256, True),
                                                  (5, 7, 7, 512, 512, True), (1, 9, 7, 64, 128, False), (3, 13, 11, 64, 64, True),
                                                  (64, 56, 56, 64, 64, True), (1, 1, 1, 64, 64, True), (2, 28, 28, 32, 64, True),
-                                                 (16, 112, 112, 32, 64, True), (1, 9, 11, 16, 64, False), (3, 7, 5, 8, 128, True)])
+                                                 (16, 112, 112, 32, 64, True), (1, 9, 11, 16, 64, False), (3, 7, 5, 8, 128, True),
+                                                 (16, 112, 112, 32, 32, True), (2, 10, 6, 32, 32, False), (1, 5, 5, 64, 32, True)])
 def test_conv3x3_implicit_gemm_equals_im2col_path(ops, B, H, W, Cin, Cout, relu):
     """The implicit-GEMM convolution (LDS-DMA gather of every tap, zero line outside the image) against the materialised
     im2col + fused GEMM/BN path: same MFMA k-order -> bit-identical; plus a torch conv2d reference on the small cases."""
