@@ -160,6 +160,13 @@ int pclip_gemm_splitk_f16(const void* A, int lda, const void* B, int ldb, void* 
 int pclip_gemm_bn_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                       const float* scale, const float* shift, int relu, pclip_stream_t stream);
 
+/* conv3 + bn3 + `out += identity` + ReLU of a bottleneck (clip/model.py:49-52) in one launch:
+ * C = relu( r16( r16( r16(A B^T) * scale[n] + shift[n] ) + residual ) ), residual fp16 [M, N] with the row stride ldc of C.
+ * Identical to pclip_gemm_f16 followed by pclip_bn_act_f16(residual, relu).  N % 64 == 0, K % 64 == 0, 16-byte aligned operands
+ * (PCLIP_E_INVALID otherwise: use the two calls). */
+int pclip_gemm_bn_res_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                          const float* scale, const float* shift, const void* residual, pclip_stream_t stream);
+
 /* 3x3 convolution, stride 1, padding 1, on NHWC fp16 activations x [B, H, W, Cin] + eval BatchNorm (+ReLU), as an implicit
  * GEMM: the im2col matrix is never materialised (each K-tile is gathered by LDS-DMA; taps outside the image read
  * `zero_line`, >= 128 zero bytes in device memory supplied by the caller).  w [Cout, 3, 3, Cin] fp16; y [B*H*W, Cout].

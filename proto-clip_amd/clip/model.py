@@ -285,14 +285,13 @@ class ModifiedResNet(nn.Module):
         if blk.stride > 1:
             out = ops.avgpool_nhwc(out, B, H, W, planes, blk.stride)                         # anti-aliased stride
             Ho, Wo = H // blk.stride, W // blk.stride
-        out = ops.gemm(out, self._w1x1(key + ".3", blk.conv3))
         identity = x
         if blk.downsample is not None:
             idn = ops.avgpool_nhwc(x, B, H, W, Cin, blk.stride) if blk.stride > 1 else x
             dsc, dsh = self._bn_affine(key + ".d", blk.downsample["1"])
             identity = ops.gemm_bn(idn, self._w1x1(key + ".d", blk.downsample["0"]), dsc, dsh, relu=False)
         sc, sh = self._bn_affine(key + ".3", blk.bn3)
-        out = ops.bn_act(out, sc, sh, residual=identity, relu=True, out=out)                  # relu(bn3(conv3) + identity)
+        out = ops.gemm_bn_res_relu(out, self._w1x1(key + ".3", blk.conv3), sc, sh, identity)  # relu(bn3(conv3(out)) + identity), one launch
         return out, Ho, Wo, planes * 4
 
     def forward(self, x):

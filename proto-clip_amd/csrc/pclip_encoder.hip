@@ -62,7 +62,9 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
                                                                      const float* __restrict__ scale,
                                                                      const float* __restrict__ shift,
                                                                      half_t* __restrict__ Cout, int ldc, int tiles_n,
-                                                                     int ntiles) {
+                                                                     int ntiles, const half_t* __restrict__ residual = nullptr) {
+    // ACT 5: relu(r16(r16(r16(acc) * scale + shift) + residual)) — bn3 + `out += identity` + ReLU of a bottleneck (clip/model.py:49-52)
+    // in the epilogue of its conv3 GEMM; the residual rows are read row-major in the coalesced store pass
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* bias_lds = reinterpret_cast<half_t*>(smem + C::LDS_BYTES);       // [2][BN] fp16
     float* affine_lds = reinterpret_cast<float*>(smem + C::LDS_BYTES);       // ACT >= 2: [2][ scale BN | shift BN ] fp32
@@ -152,12 +154,21 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
             return h;
         };
+        auto add_res = [&](size_t o, half8_t h) {
+            const half8_t rr = ld_half8(residual + o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = (half_t)fmaxf(r16((float)h[j] + (float)rr[j]), 0.f);
+            return h;
+        };
         if (full)
-            pgemm::epilogue_f16<C, M16>(acc, stg, [](int) {}, pre,
-                                        [&](int r, int, int, half8_t h) { st_half8(Cout + (size_t)(m0 + r) * ldc + col, h); });
+            pgemm::epilogue_f16<C, M16>(acc, stg, [](int) {}, pre, [&](int r, int, int, half8_t h) {
+                const size_t o = (size_t)(m0 + r) * ldc + col;
+                st_half8(Cout + o, ACT == 5 ? add_res(o, h) : h);
+            });
         else
             pgemm::epilogue_f16<C, M16>(acc, stg, [](int) {}, pre, [&](int r, int, int, half8_t h) {
-                if (m0 + r < M) st_half8(Cout + (size_t)(m0 + r) * ldc + col, h);
+                const size_t o = (size_t)(m0 + r) * ldc + col;
+                if (m0 + r < M) st_half8(Cout + o, ACT == 5 ? add_res(o, h) : h);
             });
         prev_full = full;
     }
@@ -311,7 +322,7 @@ static int launch_fast2(const void* A, int lda, const void* B, int ldb, int M, i
     const int tiles_m = ceil_div(M, C::BM), tiles_n = N / C::BN, ntiles = tiles_m * tiles_n;
     const int grid = ntiles < slots ? ntiles : slots;
     linear_fast_kernel<C, HAS_BIAS, ACT, M16><<<grid, C::NTHREADS, LDS, s>>>(
-        (const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi.bias, epi.scale, epi.shift, epi.C, epi.ldc, tiles_n, ntiles);
+        (const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi.bias, epi.scale, epi.shift, epi.C, epi.ldc, tiles_n, ntiles, epi.residual);
     return pclip_check_launch("gemm_f16");
 }
 
@@ -322,6 +333,7 @@ static int launch_fast_m(const void* A, int lda, const void* B, int ldb, int M, 
                          int slots, hipStream_t s) {
     if (epi.act == 2) return launch_fast2<C, false, 2, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
     if (epi.act == 3) return launch_fast2<C, false, 3, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
+    if (epi.act == 5) return launch_fast2<C, false, 5, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
     if (epi.bias) {
         if (epi.act == 1) return launch_fast2<C, true, 1, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
         return launch_fast2<C, true, 0, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
@@ -871,13 +883,15 @@ int launch_small_one(const half_t* A, int lda, const half_t* B, int ldb, int M, 
 
 int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int N, int K, LinearEpi epi, int cus, int forced,
                   bool may_split, hipStream_t s) {
-    const bool aligned = !epi.residual && epi.ldc % 8 == 0 && ((uintptr_t)epi.C & 15) == 0 && (!epi.bias || ((uintptr_t)epi.bias & 15) == 0);
+    const bool aligned = (!epi.residual || (epi.act == 5 && ((uintptr_t)epi.residual & 15) == 0)) && epi.ldc % 8 == 0 && ((uintptr_t)epi.C & 15) == 0 &&
+                         (!epi.bias || ((uintptr_t)epi.bias & 15) == 0);
     static const bool small_on = !(getenv("PCLIP_GEMM_SMALL") && getenv("PCLIP_GEMM_SMALL")[0] == '0');
     if (aligned && forced == -1 && small_on && (epi.act <= 1 || (((uintptr_t)epi.scale | (uintptr_t)epi.shift) & 15) == 0) && small_applies(M, N, cus))
         return launch_small_one(A, lda, B, ldb, M, N, K, epi, s);
     double cost = 1e30;
     int pick = aligned ? best_cfg(M, N, cus, &cost) : -1;
     if (forced == -2) { may_split = false; pick = -1; }        // generic kernel
+    if (epi.act == 5 && pick < 0) { pclip_set_error("pclip_gemm_bn_res_f16: N=%d / alignment not supported by the fused epilogue", N); return PCLIP_E_INVALID; }
     if (forced >= 0) {
         may_split = false;
         if (aligned && forced < kNumCfgs && N % kTileCfgs[forced].bn == 0) pick = forced;
@@ -901,6 +915,7 @@ int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int
             if (rc != PCLIP_OK) return rc;
             LinearEpi tail = epi;
             tail.C = epi.C + (size_t)split_rows * epi.ldc;
+            if (epi.residual) tail.residual = epi.residual + (size_t)split_rows * epi.ldc;   // act 5: same row stride as C
             return gemm_dispatch(A + (size_t)split_rows * lda, lda, B, ldb, M - (int)split_rows, N, K, tail, cus, -1, true, s);
         }
     }
@@ -964,7 +979,8 @@ __global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void linear_small_kernel(con
                                                                            float* __restrict__ ws, const half_t* __restrict__ bias,
                                                                            half_t* __restrict__ Cout, int ldc,
                                                                            const float* __restrict__ scale,
-                                                                           const float* __restrict__ shift) {
+                                                                           const float* __restrict__ shift,
+                                                                           const half_t* __restrict__ residual = nullptr) {
     using C = CfgSplit;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = blockIdx.x / S, ks = blockIdx.x - tile * S;
@@ -1010,7 +1026,14 @@ __global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void linear_small_kernel(con
         };
         // slot 0 of the ring is the staging buffer: the epilogue's first barrier comes after every wave's last K-tile
         pgemm::epilogue_f16<C, true>(acc, smem, [](int) {}, pre, [&](int r, int, int, half8_t h) {
-            if (m0 + r < M) st_half8(Cout + (size_t)(m0 + r) * ldc + col, h);
+            if (m0 + r >= M) return;
+            const size_t o = (size_t)(m0 + r) * ldc + col;
+            if (ACT == 5) {
+                const half8_t rr = ld_half8(residual + o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) h[j] = (half_t)fmaxf(r16((float)h[j] + (float)rr[j]), 0.f);
+            }
+            st_half8(Cout + o, h);
         });
         return;
     }
@@ -1108,7 +1131,7 @@ inline int small_attr() {
     static bool done = false;
     if (!done) {
         const void* fns[] = {(const void*)linear_small_kernel<0>, (const void*)linear_small_kernel<1>, (const void*)linear_small_kernel<2>,
-                             (const void*)linear_small_kernel<3>, (const void*)conv3x3_small_kernel<2>, (const void*)conv3x3_small_kernel<3>};
+                             (const void*)linear_small_kernel<3>, (const void*)linear_small_kernel<5>, (const void*)conv3x3_small_kernel<2>, (const void*)conv3x3_small_kernel<3>};
         for (const void* f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kSmallLds) != hipSuccess) {
                 pclip_set_error("gemm_f16 (small M): cannot raise the dynamic LDS limit to %d", kSmallLds);
@@ -1129,8 +1152,9 @@ int launch_small_one(const half_t* A, int lda, const half_t* B, int ldb, int M, 
     ++g_gemm_launches;
 #define PCLIP_SMALL_LAUNCH(ACT)                                                                                                          \
     linear_small_kernel<ACT><<<grid, CfgSplit::NTHREADS, kSmallLds, s>>>(A, lda, B, ldb, M, N, K, tiles_n, 1, steps, nullptr, epi.bias, epi.C, \
-                                                                        epi.ldc, epi.scale, epi.shift)
-    if (epi.act == 1) PCLIP_SMALL_LAUNCH(1);
+                                                                        epi.ldc, epi.scale, epi.shift, epi.residual)
+    if (epi.act == 5) PCLIP_SMALL_LAUNCH(5);
+    else if (epi.act == 1) PCLIP_SMALL_LAUNCH(1);
     else if (epi.act == 2) PCLIP_SMALL_LAUNCH(2);
     else if (epi.act == 3) PCLIP_SMALL_LAUNCH(3);
     else PCLIP_SMALL_LAUNCH(0);
@@ -1189,6 +1213,20 @@ extern "C" int pclip_gemm_splitk_f16(const void* A, int lda, const void* B, int 
     else
         splitk_reduce_kernel<0><<<rgrid, 256, 0, s>>>((const float*)ws, pl.S, M, N, (const half_t*)bias, (half_t*)C, ldc);
     return pclip_check_launch("gemm_f16 (split-K)");
+}
+
+extern "C" int pclip_gemm_bn_res_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                                     const float* scale, const float* shift, const void* residual, pclip_stream_t stream) {
+    PCLIP_REQUIRE(A && B && C && scale && shift && residual, "pclip_gemm_bn_res_f16: null pointer");
+    PCLIP_REQUIRE(M >= 0 && N > 0 && K > 0, "pclip_gemm_bn_res_f16: bad shape M=%d N=%d K=%d", M, N, K);
+    PCLIP_REQUIRE(K % pgemm::BK == 0 && N % 64 == 0, "pclip_gemm_bn_res_f16: K=%d, N=%d must be multiples of 64", K, N);
+    PCLIP_REQUIRE(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0, "pclip_gemm_bn_res_f16: bad leading dims");
+    PCLIP_REQUIRE(((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0, "pclip_gemm_bn_res_f16: scale / shift must be 16-byte aligned");
+    if (M == 0) return PCLIP_OK;
+    LinearEpi epi{nullptr, (const half_t*)residual, (half_t*)C, ldc, 5, scale, shift};
+    int cus = pclip_device_cus();
+    if (cus <= 0) cus = 256;
+    return gemm_dispatch((const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, cus, -1, true, (hipStream_t)stream);
 }
 
 extern "C" int pclip_gemm_bn_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,

@@ -300,6 +300,23 @@ def gemm_bn(a, w, scale, shift, relu: bool = True, out=None):
     return out
 
 
+def gemm_bn_res_relu(a, w, scale, shift, residual, out=None):
+    """relu(bn(a @ w.T) + residual): conv3 + bn3 + identity add + ReLU of a bottleneck in one launch where the fused epilogue
+    applies (N % 64 == 0, aligned operands), otherwise GEMM followed by bn_act — the same values either way."""
+    require_cuda(a, w, scale, shift, residual)
+    a, w, residual = _f16c(a), _f16c(w), _f16c(residual)
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float16, device=a.device)
+    if N % 64 == 0 and K % 64 == 0 and not ((a.data_ptr() | w.data_ptr() | out.data_ptr() | residual.data_ptr() | scale.data_ptr() | shift.data_ptr()) & 15):
+        check(_lib.load().pclip_gemm_bn_res_f16(ptr(a), K, ptr(w), w.shape[1], ptr(out), N, M, N, K, ptr(scale), ptr(shift), ptr(residual),
+                                                stream()), "pclip_gemm_bn_res_f16")
+        return out
+    gemm(a, w, out=out)
+    return bn_act(out, scale, shift, residual=residual, relu=True, out=out)
+
+
 _zero_line = {}
 
 

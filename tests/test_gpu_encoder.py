@@ -425,6 +425,22 @@ def test_gemm_bn_equals_gemm_then_bn_act(ops, M, N, K, relu):
     assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("M,N,K", [(5000, 256, 64), (3136 * 8, 256, 64), (70000, 512, 128), (777, 2048, 512), (49, 2048, 512), (200, 64, 64),
+                                   (50432, 1024, 256)])
+def test_gemm_bn_residual_relu_equals_separate(ops, M, N, K):
+    """conv3 + bn3 + identity add + ReLU of a bottleneck in one launch (pclip_gemm_bn_res_f16: persistent kernels incl. the row
+    split, and the ring kernel for small M) against GEMM followed by pclip_bn_act_f16: bit for bit."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = (torch.randn(M, K, device="cuda", generator=g) * 0.5).half()
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).half()
+    res = torch.randn(M, N, device="cuda", generator=g).half()
+    ss = torch.stack([1 + 0.3 * torch.randn(N, device="cuda", generator=g), 0.2 * torch.randn(N, device="cuda", generator=g)]).contiguous()
+    ref = ops.bn_act(ops.gemm(a, w), ss[0], ss[1], residual=res, relu=True)
+    got = ops.gemm_bn_res_relu(a, w, ss[0], ss[1], res)
+    assert torch.equal(got, ref)
+    assert (got >= 0).all()
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,relu", [(2, 56, 56, 64, 64, True), (3, 28, 28, 128, 128, True), (2, 14, 14, 256, 256, True),
                                                  (5, 7, 7, 512, 512, True), (1, 9, 7, 64, 128, False), (3, 13, 11, 64, 64, True),
                                                  (64, 56, 56, 64, 64, True), (1, 1, 1, 64, 64, True), (2, 28, 28, 32, 64, True),
