@@ -391,16 +391,28 @@ __global__ __launch_bounds__(256) void adapter_conv_backward_kernel(
         }
         __syncthreads();
         // ------------ conv2 weight gradient: dW2[co,ci,tap] = sum_p dt2[co,p] * a1[ci, p + tap] ------------
-        for (int o = tid; o < CW * CW * 9; o += 256) {
-            const int tap = o % 9, ci = (o / 9) % CW, co = o / (9 * CW);
+        // A work item is (co pair, ci pair, tap): per pixel ONE 4-byte read of each operand feeds four fmaf chains (the
+        // one-output-per-thread version read two halfs per multiply-add: 2304 x 529 of them per row, most of this kernel's time).
+        // Every output keeps its (py, px)-ordered fp32 chain.
+        for (int it = tid; it < 8 * 8 * 9; it += 256) {
+            const int tap = it % 9, cip = (it / 9) & 7, cop = it / 72;
             const int dy = tap / 3, dx = tap - dy * 3;
-            const half_t* dsrc = reinterpret_cast<const half_t*>(d2p + (co >> 1) * hp) + (co & 1);
-            const half_t* asrc = reinterpret_cast<const half_t*>(a1p + (ci >> 1) * hp) + (ci & 1);
-            float acc = 0.f;
+            const half2_t* dsrc = d2p + cop * hp;
+            const half2_t* asrc = a1p + cip * hp;
+            float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;       // [co parity][ci parity]
             for (int py = 0; py < s; ++py)
-                for (int px = 0; px < s; ++px)
-                    acc = fmaf((float)dsrc[2 * ((py + 1) * sp + px + 1)], (float)asrc[2 * ((py + dy) * sp + px + dx)], acc);
-            pw2[row * (CW * CW * 9) + o] = acc;
+                for (int px = 0; px < s; ++px) {
+                    const half2_t dv = dsrc[(py + 1) * sp + px + 1], av = asrc[(py + dy) * sp + px + dx];
+                    a00 = fmaf((float)dv[0], (float)av[0], a00);
+                    a01 = fmaf((float)dv[0], (float)av[1], a01);
+                    a10 = fmaf((float)dv[1], (float)av[0], a10);
+                    a11 = fmaf((float)dv[1], (float)av[1], a11);
+                }
+            float* dst = pw2 + row * (CW * CW * 9);
+            dst[((2 * cop) * CW + 2 * cip) * 9 + tap] = a00;
+            dst[((2 * cop) * CW + 2 * cip + 1) * 9 + tap] = a01;
+            dst[((2 * cop + 1) * CW + 2 * cip) * 9 + tap] = a10;
+            dst[((2 * cop + 1) * CW + 2 * cip + 1) * 9 + tap] = a11;
         }
         // ------------ conv2 input gradient (transposed conv): da1[ci,p] = r16(sum_co,tap dt2[co, p - tap + 1] w2[co,ci,tap]) ----
         __syncthreads();                                            // t2 is overwritten with da1 below: all readers are done
