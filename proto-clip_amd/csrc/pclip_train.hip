@@ -290,17 +290,26 @@ __global__ __launch_bounds__(256) void l2norm_rows_backward_f32_kernel(const flo
 //   div:  dx1 = r16s(gk / n);  dn = r16s(sum_d r16s(-gk * r16s(r16s(x/n)/n)))      norm:  dx2 = r16s(x * r16s(dn / n))
 // gk — the gradient of the fp16 mean, already divided by K — does not depend on the shot: it is computed once per class into an
 // LDS row (with the shot norms), so the work per class is O(K D) instead of the O(K^2 D) of recomputing the mean per shot.
+// LDSROWS: the K shot rows of the class are copied to LDS in one batch of loads first (K > 1: the three passes below are
+// otherwise ~3 K dependent round trips per wave, with one wave per SIMD at N = 1000 classes nothing hides them).
+template <bool LDSROWS>
 __global__ __launch_bounds__(256) void proto_backward_kernel(const half_t* __restrict__ mem, const float* __restrict__ g, int N,
                                                              int K, int D, int per_shot, int final_norm,
                                                              half_t* __restrict__ dmem) {
-    extern __shared__ float pb_lds[];                      // per wave: [D] m then gk | [32] shot norms
+    extern __shared__ __attribute__((aligned(16))) float pb_lds[];   // per wave: [D] m then gk | [32] shot norms | (LDSROWS) [K*D] halfs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* gks = pb_lds + (size_t)wave * (D + 32);
+    const int per_wave = D + 32 + (LDSROWS ? (K * D + 1) / 2 : 0);  // floats
+    float* gks = pb_lds + (size_t)wave * per_wave;
     float* nk = gks + D;
+    half_t* rl = reinterpret_cast<half_t*>(nk + 32);
     for (int n = blockIdx.x * 4 + wave; n < N; n += gridDim.x * 4) {
-        const half_t* rows = mem + (size_t)n * K * D;
+        const half_t* grows = mem + (size_t)n * K * D;
         const float* gn = g + (size_t)n * D;
         half_t* drows = dmem + (size_t)n * K * D;
+        if (LDSROWS) {                                       // D % 8 == 0 on this path (checked by the launcher)
+            for (int i = lane; i < K * D / 8; i += 64) *reinterpret_cast<half8_t*>(rl + i * 8) = ld_half8(grows + (size_t)i * 8);
+        }
+        const half_t* rows = LDSROWS ? rl : grows;
         // exact forward recomputation: shot norms first (fp16-rounded, one wave reduction per shot)
         for (int k = 0; k < K; ++k) {
             const half_t* v = rows + (size_t)k * D;
@@ -568,8 +577,22 @@ extern "C" int pclip_proto_backward_f16(const void* mem, const float* g, int N, 
     PCLIP_REQUIRE(mem && g && dmem, "pclip_proto_backward_f16: null pointer");
     PCLIP_REQUIRE(N >= 0 && K > 0 && K <= 32 && D > 0 && D <= 3072, "pclip_proto_backward_f16: bad N=%d K=%d (<=32) D=%d (<=3072)", N, K, D);
     if (N == 0) return PCLIP_OK;
-    proto_backward_kernel<<<row_grid(N, 8192), 256, 4 * (size_t)(D + 32) * sizeof(float), (hipStream_t)stream>>>((const half_t*)mem, g, N, K, D, per_shot_norm,
-                                                                             final_norm, (half_t*)dmem);
+    const size_t base = 4 * (size_t)(D + 32) * sizeof(float), with_rows = 4 * ((size_t)(D + 32) + ((size_t)K * D + 1) / 2) * sizeof(float);
+    if (K > 1 && D % 8 == 0 && with_rows <= 150 * 1024) {
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute((const void*)proto_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+                pclip_set_error("pclip_proto_backward_f16: cannot raise the dynamic LDS limit");
+                return PCLIP_E_LAUNCH;
+            }
+            attr = true;
+        }
+        proto_backward_kernel<true><<<row_grid(N, 8192), 256, with_rows, (hipStream_t)stream>>>((const half_t*)mem, g, N, K, D, per_shot_norm,
+                                                                                           final_norm, (half_t*)dmem);
+    } else {
+        proto_backward_kernel<false><<<row_grid(N, 8192), 256, base, (hipStream_t)stream>>>((const half_t*)mem, g, N, K, D, per_shot_norm,
+                                                                                       final_norm, (half_t*)dmem);
+    }
     return pclip_check_launch("proto_backward");
 }
 
