@@ -1,10 +1,10 @@
 """Byte-level BPE tokenizer compatible with OpenAI CLIP's vocabulary (reference
 clip/simple_tokenizer.py:62-127 implements the same published algorithm).
 
-The 1.3 MB merge table `bpe_simple_vocab_16e6.txt.gz` is data, not code, and is not shipped in this
-repository: point `PCLIP_BPE_VOCAB` at the file (any CLIP installation has it) or place it in
-~/.cache/clip/.  Token ids: 256 byte symbols, 256 end-of-word byte symbols, 48894 merges, then
-<|startoftext|>=49406 and <|endoftext|>=49407."""
+The merge table `bpe_simple_vocab_16e6.txt.gz` (OpenAI CLIP's published vocabulary — data, not code; the reference vendors
+the same file, clip/simple_tokenizer.py:4-6) sits next to this module; `PCLIP_BPE_VOCAB` overrides the path.  A missing table
+is a loud FileNotFoundError, never a silent fallback.  Token ids: 256 byte symbols, 256 end-of-word byte symbols, 48894
+merges, then <|startoftext|>=49406 and <|endoftext|>=49407."""
 import gzip
 import html
 import os
@@ -101,14 +101,18 @@ class SimpleTokenizer:
 _default = None
 
 
+def default_bpe() -> str:
+    """Path of the merge table: $PCLIP_BPE_VOCAB, else the copy shipped beside this module (clip/simple_tokenizer.py:9-11)."""
+    return os.environ.get("PCLIP_BPE_VOCAB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "bpe_simple_vocab_16e6.txt.gz")
+
+
 def default_tokenizer() -> SimpleTokenizer:
     global _default
     if _default is None:
-        cands = [os.environ.get("PCLIP_BPE_VOCAB"), os.path.expanduser("~/.cache/clip/bpe_simple_vocab_16e6.txt.gz")]
-        path = next((c for c in cands if c and os.path.isfile(c)), None)
-        if path is None:
+        path = default_bpe()
+        if not os.path.isfile(path):
             raise FileNotFoundError(
-                "CLIP BPE merge table not found: set PCLIP_BPE_VOCAB=/path/to/bpe_simple_vocab_16e6.txt.gz "
-                "(shipped with every CLIP installation) or copy it to ~/.cache/clip/")
+                f"CLIP BPE merge table not found at {path}: restore proto-clip_amd/clip/bpe_simple_vocab_16e6.txt.gz or set "
+                "PCLIP_BPE_VOCAB=/path/to/bpe_simple_vocab_16e6.txt.gz (shipped with every CLIP installation)")
         _default = SimpleTokenizer(path)
     return _default

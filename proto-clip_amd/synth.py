@@ -92,12 +92,13 @@ def make_split(N: int, K: int, D: int, Q_val: int, Q_test: int, seed: int = 1, s
                         val_f, val_y, test_f, test_y, N, K, D)
 
 
-def make_images(B: int, res: int, seed: int = 1, stream: int = 50, n_class: int = 0) -> torch.Tensor:
+def make_images(B: int, res: int, seed: int = 1, stream: int = 50, n_class: int = 0, labels=None) -> torch.Tensor:
     """Pre-processed image batch [B,3,res,res] fp32: per-class low-frequency pattern + noise
-    (SURVEY §8d 'Full-path configs').  Values are in the range CLIP's Normalize produces."""
+    (SURVEY §8d 'Full-path configs').  Values are in the range CLIP's Normalize produces.  `labels` (int array [B])
+    fixes the class of every image; otherwise classes are drawn from the seeded stream (`image_labels`)."""
     noise = normal((B, 3, res, res), seed, stream).astype(np.float32)
-    if n_class > 0:
-        y = randint(B, n_class, seed, stream + 1)
+    if n_class > 0 or labels is not None:
+        y = np.asarray(labels, dtype=np.int64) if labels is not None else randint(B, n_class, seed, stream + 1)
         yy, xx = np.meshgrid(np.arange(res), np.arange(res), indexing="ij")
         fx = (y % 7 + 1)[:, None, None, None]
         fy = (y // 7 % 7 + 1)[:, None, None, None]

@@ -24,6 +24,41 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+# ---- observed-vs-bound ledger: every tolerance-graded assertion records what it actually measured; the summary is printed
+# at the end of the run (also under -q) and written to gpurun_out/observed_tolerances.json, from where it is committed as
+# profiles/rNN_observed_tolerances.json.  Bounds are kept at <= 2x the largest value observed on MI355X.
+_OBSERVED = {}
+
+
+def observe(key, value, bound):
+    value, bound = float(value), float(bound)
+    cur = _OBSERVED.get(key)
+    if cur is None or value > cur[0]:
+        _OBSERVED[key] = (value, bound, (cur[2] + 1) if cur else 1)
+    else:
+        _OBSERVED[key] = (cur[0], cur[1], cur[2] + 1)
+    return value
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if not _OBSERVED:
+        return
+    tr = terminalreporter
+    tr.write_line("")
+    tr.write_line("observed maxima of tolerance-graded checks (value / bound, #checks):")
+    for k in sorted(_OBSERVED):
+        v, b, n = _OBSERVED[k]
+        tr.write_line(f"  {k:<58s} {v:10.3e} / {b:9.3e}  ({v / b if b else 0:5.2f} of the bound, {n} checks)")
+    try:
+        import json
+        out = os.path.join(REPO, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "observed_tolerances.json"), "w") as f:
+            json.dump({k: dict(observed=v, bound=b, checks=n) for k, (v, b, n) in sorted(_OBSERVED.items())}, f, indent=1)
+    except OSError:
+        pass
+
+
 def golden(name):
     path = os.path.join(GOLDEN, name + ".npz")
     if not os.path.exists(path):
@@ -52,36 +87,48 @@ def ulp_diff(a16, b16):
     return ((a - b).abs() / (scale * F16_ULP)).max().item()
 
 
-def assert_adapter_close(y16, ref16):
+def assert_adapter_close(y16, ref16, tag="adapter"):
     """Adapter outputs pass two or three whole-tensor LayerNorms in fp16.  A single 1-ulp flip in an
     intermediate (fp32 mean/variance summation order — it happens for ~1e-4 of elements even between two
-    CPU formulas of the same LayerNorm) is amplified by the next normalisation: conv-2x, whose conv3 output
-    has a tiny variance, shows up to 2.6 % of the row rms on one element and 4.5e-3 relative L2 on that row
-    between the reference and an exact restatement.  Tolerances: row relative L2 <= 1e-2 (mean <= 1e-3),
-    no element off by more than 5 % of the row rms.  (fp16 resolution itself is 1e-3 relative.)"""
+    CPU formulas of the same LayerNorm) is amplified by the next normalisation.  Bounds = 2x the largest value observed on
+    MI355X over every adapter test (profiles/r02_observed_tolerances.json), see ADAPTER_BOUNDS."""
     a, b = y16.float().cpu(), ref16.float().cpu()
     rel = (a - b).norm(dim=-1) / b.norm(dim=-1)
     rms = b.pow(2).mean(-1, keepdim=True).sqrt()
-    assert rel.max().item() <= 1e-2, rel.max().item()
-    assert rel.mean().item() <= 1e-3, rel.mean().item()
-    assert ((a - b).abs() / rms).max().item() < 0.05, ((a - b).abs() / rms).max().item()
+    b_max, b_mean, b_elem = ADAPTER_BOUNDS
+    v_max = observe(f"{tag}: row rel-L2 max", rel.max().item(), b_max)
+    v_mean = observe(f"{tag}: row rel-L2 mean", rel.mean().item(), b_mean)
+    v_elem = observe(f"{tag}: worst element / row rms", ((a - b).abs() / rms).max().item(), b_elem)
+    assert v_max <= b_max, v_max
+    assert v_mean <= b_mean, v_mean
+    assert v_elem < b_elem, v_elem
 
 
-def assert_grid_close(acc, ref_acc, n_queries, exact=False):
-    """(alpha, beta) accuracy grids.  Without an adapter in the path (exact=True) they must be identical to the reference up to
-    isolated 1e-7 ties.
-    Behind an adapter, the fp16 LayerNorm noise described above perturbs a few adapted queries, and a
-    near-tied query then flips at some grid points (the reference's own CPU/GPU builds would differ the same
-    way): allow at most 3 queries of difference anywhere and a mean absolute difference below half a query."""
+# (row relative L2 max, row relative L2 mean, worst element as a fraction of the row rms)
+ADAPTER_BOUNDS = (1e-2, 1e-3, 0.05)
+# post-adapter (alpha, beta) grids: (max queries of difference at any grid point, mean queries of difference)
+GRID_BOUNDS = (3.0, 0.5)
+# adapter-free grids: (max queries of difference at any grid point, fraction of grid points that differ at all)
+GRID_EXACT_BOUNDS = (1.0, 0.02)
+
+
+def assert_grid_close(acc, ref_acc, n_queries, exact=False, tag="grid"):
+    """(alpha, beta) accuracy grids against the reference's.  Without an adapter in the path (exact=True) the counts agree
+    except where a query's top-2 probabilities tie to ~1e-7 (fp32 summation order of the 512-long dot products differs between
+    the MFMA tile and the CPU BLAS).  Behind an adapter, the fp16 LayerNorm noise described above perturbs a few adapted
+    queries, and a near-tied query then flips at some grid points (the reference's own CPU/GPU builds would differ the same
+    way).  Every call records the observed differences (in queries)."""
     acc, ref_acc = np.asarray(acc, dtype=np.float64), np.asarray(ref_acc, dtype=np.float64)
-    if exact:
-        # No adapter in the path: counts agree except where a query's top-2 probabilities tie to ~1e-7 (fp32
-        # summation order of the 512-long dot products differs between the MFMA tile and the CPU BLAS; measured:
-        # 1 query of 16 000 at 4 of 319 pairs).  At most ONE query, at no more than 2 % of the pairs.
-        d = np.abs(acc - ref_acc) * n_queries
-        assert d.max() <= 1.0 + 1e-3, d.max()
-        assert (d > 1e-3).mean() <= 0.02, (d > 1e-3).mean()
-        return
     d = np.abs(acc - ref_acc) * n_queries
-    assert d.max() <= 3.0 + 1e-3, d.max()
-    assert d.mean() <= 0.5, d.mean()
+    if exact:
+        b_max, b_frac = GRID_EXACT_BOUNDS
+        v_max = observe(f"{tag} (no adapter): max queries differing at a grid point", d.max(), b_max)
+        v_frac = observe(f"{tag} (no adapter): fraction of grid points differing", (d > 1e-3).mean(), b_frac)
+        assert v_max <= b_max + 1e-3, v_max
+        assert v_frac <= b_frac, v_frac
+        return
+    b_max, b_mean = GRID_BOUNDS
+    v_max = observe(f"{tag} (behind adapter): max queries differing at a grid point", d.max(), b_max)
+    v_mean = observe(f"{tag} (behind adapter): mean queries differing", d.mean(), b_mean)
+    assert v_max <= b_max + 1e-3, v_max
+    assert v_mean <= b_mean, v_mean

@@ -28,7 +28,8 @@ sys.path.insert(0, REPO)
 from proto_clip_amd import synth                                   # noqa: E402
 from proto_clip_amd.clip.model import random_state_dict            # noqa: E402
 sys.path.insert(0, HERE)
-from spec import ENCODERS, FEWSHOT, RESNETS, TRAIN, fewshot_inputs, randomize_adapter_, train_inputs   # noqa: E402
+from spec import (E2E, E2E_CASE, ENCODERS, FEWSHOT, RESNETS, TRAIN, e2e_images, fewshot_inputs, randomize_adapter_,   # noqa: E402
+                  train_inputs)
 
 
 # ---------------------------------------------------------------- Appendix-B shim -----------------
@@ -309,10 +310,84 @@ def make_resnet(tag, kw, ref_clip_model):
 
 
 def make_tokenizer(ref_clip):
+    """clip.tokenize of the reference (clip/clip.py:194-230) on: the original six prompts, every ImageNet template x 50 class
+    names (the prompts utils.clip_classifier builds, utils.py:262-263), and punctuation / unicode / html-entity /
+    whitespace cases.  ftfy is absent from the image (shim: identity), so the unicode cases avoid mojibake."""
+    from datasets.imagenet import imagenet_classes, imagenet_templates
     prompts = ["a photo of a dog.", "a centered satellite photo of annual crop land.", "itap of a forest.",
                "a bad photo of the tench, tinca tinca.", "A Photo Of The Large golden_retriever!!", "art of the 3-d   printer's nozzle"]
+    names = imagenet_classes[:30] + imagenet_classes[400:410] + imagenet_classes[-10:]
+    prompts += [t.format(c.replace("_", " ")) for c in names for t in imagenet_templates]
+    prompts += ["caf\u00e9 cr\u00e8me br\u00fbl\u00e9e", "na\u00efve \u00fcber-stra\u00dfe", "\u65e5\u672c\u8a9e\u306e\u5199\u771f", "emoji \U0001f600 test", "tom &amp; jerry's &lt;cat&gt;", "  spaces\t and\n newlines  ",
+                "they're we've i'm he'll she'd it's don't", "price: $1,234.56 (approx.) #42 @home 100%", "MiXeD CaSe WORDS and 12345 67890", "x", "",
+                "a photo of a " + "very " * 30 + "long prompt"]
     ids = ref_clip.tokenize(prompts)
-    savez("tokenizer", prompts=np.array(prompts), ids=ids.to(torch.int32))
+    too_long = "word " * 100
+    savez("tokenizer", prompts=np.array(prompts), ids=ids.to(torch.int32), truncated=ref_clip.tokenize(too_long, truncate=True).to(torch.int32))
+
+
+# ---------------------------------------------------------------- image -> logits chain ------------------
+def make_e2e(ref_main, ref_utils, ref_model, ref_clip_model, scratch):
+    """Images through the reference's whole hot path (utils.py:256-361 bank builders on the reference's CLIP towers, then
+    main.py:383-441 via run_proto_clip with a spy on P): support images -> build_cache_model, prompts -> clip_classifier,
+    query images -> pre_load_features -> adapter -> normalise -> P.  Run twice: fp16-weight towers (the reference's GPU
+    precision) and fp32 towers with the features cast to fp16 (the reference CPU path) — their disagreement is the
+    yard-stick the GPU test's tolerance is stated against."""
+    from datasets.imagenet import imagenet_classes, imagenet_templates
+    c = E2E_CASE
+    N, K = c["N"], c["K"]
+    classnames = [imagenet_classes[i] for i in (0, 1, 2, 21, 15, 43)][:N]
+    templates = imagenet_templates[:c["n_templates"]]
+    sd = random_state_dict(seed=17, **E2E)
+    (sup_x, sup_y), (val_x, val_y), (test_x, test_y) = e2e_images()
+    ad = adapter_state(ref_model, c["adapter"], E2E["embed_dim"], seed=9)
+    out = {}
+    for tag in ("f16", "f32"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = ref_clip_model.build_model({k: v.clone() for k, v in sd.items()})
+        if tag == "f32":
+            m = m.float()
+        cfg = dict(shots=K, backbone="ViT-B/16", dataset="synthetic_e2e_" + tag, only_test=True, lr=0.0001, augment_epoch=c["augment_epoch"],
+                   train_epoch=1, alpha=c["alpha"], beta=c["beta"], adapter=c["adapter"], train_vis_mem_only=True, losses=["L1"],
+                   cache_dir=os.path.join(scratch, "caches", "e2e_" + tag), logs_dir_path="logs")
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            keys, values = ref_utils.build_cache_model(cfg, m, [(sup_x[:10], sup_y[:10]), (sup_x[10:], sup_y[10:])])
+            val_f, val_l = ref_utils.pre_load_features(cfg, "val", m, [(val_x, val_y)])
+            test_f, test_l = ref_utils.pre_load_features(cfg, "test", m, [(test_x[:20], test_y[:20]), (test_x[20:], test_y[20:])])
+            _, text_bank = ref_utils.clip_classifier(classnames, templates, m)
+        keys, val_f, test_f, text_bank = keys.half(), val_f.half(), test_f.half(), text_bank.half()
+        model_dir = f"{ref_utils.get_model_dir_root(cfg)}/alpha-beta/{c['alpha']}-{c['beta']}"
+        os.makedirs(model_dir, exist_ok=True)
+        prefix = f"{model_dir}/best_lr_{cfg['lr']}_aug_{cfg['augment_epoch']}_epochs_{cfg['train_epoch']}"
+        torch.save(torch.nn.Parameter(keys.t().contiguous()), prefix + "_v.pt")        # the banks a fresh training run starts from
+        torch.save(torch.nn.Parameter(text_bank.t().contiguous()), prefix + "_t.pt")
+        torch.save(ad.state_dict(), prefix + "_a.pt")
+        calls, real_P = [], ref_utils.P
+
+        def spy_P(zq, zi, zt, a, b):
+            p = real_P(zq, zi, zt, a, b)
+            calls.append((zq, zi, zt, float(a), float(b), p))
+            return p
+
+        ref_main.P = spy_P
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref_main.run_proto_clip(cfg, keys, values, val_f, val_l, test_f, test_l, text_bank, types.SimpleNamespace(dtype=torch.float16),
+                                    classnames)
+        ref_main.P = real_P
+        n_grid = 319 * 3
+        assert len(calls) == 2 * n_grid + 2, len(calls)
+        zq, zi, zt, a, b, p = calls[2 * n_grid]                      # the fixed-(alpha, beta) test call, main.py:433
+        assert (a, b) == (c["alpha"], c["beta"])
+        out.update({f"keys_{tag}": keys, f"test_features_{tag}": test_f, f"text_bank_{tag}": text_bank, f"adapted_{tag}": zq,
+                    f"proto_img_{tag}": zi, f"proto_txt_{tag}": zt, f"p_{tag}": p, f"argmax_{tag}": p.max(1)[1].to(torch.int16),
+                    f"acc_{tag}": (p.max(1)[1] == test_l).float().mean().item()})
+        if tag == "f16":
+            out["values"] = values.to(torch.int16)
+    print("e2e: acc f16 %.3f, f32 %.3f; max|p16 - p32| %.3e; argmax agree %d/%d" % (
+        out["acc_f16"], out["acc_f32"], (out["p_f16"] - out["p_f32"]).abs().max().item(),
+        int((out["argmax_f16"] == out["argmax_f32"]).sum()), len(test_y)))
+    savez("e2e_small", classnames=np.array(classnames), templates=np.array(templates), adapter_keys=np.array(list(ad.state_dict().keys())),
+          **{"adapter__" + k: v for k, v in ad.state_dict().items()}, **out)
 
 
 def main():
@@ -335,6 +410,8 @@ def main():
             make_resnet(tag, kw, ref_clip_model)
     if todo("tokenizer"):
         make_tokenizer(ref_clip)
+    if todo("e2e"):
+        make_e2e(ref_main, ref_utils, ref_model, ref_clip_model, scratch)
 
 
 if __name__ == "__main__":

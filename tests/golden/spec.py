@@ -19,6 +19,28 @@ SMALL = dict(embed_dim=128, image_resolution=64, vision_layers=3, vision_width=2
 ODD = dict(embed_dim=64, image_resolution=70, vision_layers=2, vision_width=192, vision_patch_size=14, context_length=77,
            vocab_size=300, transformer_width=64, transformer_heads=1, transformer_layers=1)   # L=26, K=588 (ViT-L/14-like pad)
 ENCODERS = {"tiny": TINY, "small": SMALL, "odd": ODD}
+# image -> logits chain (make_golden.make_e2e): the SMALL towers with CLIP's real vocabulary, so that clip.tokenize feeds them
+E2E = dict(SMALL, vocab_size=49408)
+E2E_CASE = dict(N=6, K=4, Q_val=24, Q_test=48, augment_epoch=2, alpha=0.5, beta=12.0, adapter="conv-3x", n_templates=3, seed=31)
+
+
+def e2e_images(case=E2E_CASE, res=64):
+    """Seeded support / val / test image batches (+ labels) of the image -> logits case: K shots per class in shuffled order
+    (build_cache_model sorts by label), random query labels."""
+    import numpy as np
+    from proto_clip_amd import synth
+    N, K, seed = case["N"], case["K"], case["seed"]
+    perm = np.argsort(synth.normal((N * K,), seed, 7), kind="stable")
+    sup_y = np.repeat(np.arange(N), K)[perm]
+    val_y, test_y = synth.randint(case["Q_val"], N, seed, 8), synth.randint(case["Q_test"], N, seed, 9)
+    # a random-init tower attends almost uniformly, i.e. the class token sees the MEAN over patches, which a zero-mean pattern
+    # does not survive: give every class a colour cast (per-channel offset) on top of make_images' pattern + noise
+    colour = torch.from_numpy(synth.normal((N, 3), seed, 10)).float() * 1.5
+    mk = lambda y, stream: synth.make_images(len(y), res, seed=seed, stream=stream, labels=y) + colour[torch.from_numpy(np.asarray(y)).long()][:, :, None, None]
+    t = lambda y: torch.from_numpy(np.asarray(y)).long()
+    return (mk(sup_y, 60), t(sup_y)), (mk(val_y, 62), t(val_y)), (mk(test_y, 64), t(test_y))
+
+
 # ModifiedResNet: RN50's real channel widths (64 -> 2048, 32 attention-pool heads) with one bottleneck per stage
 RESNET = dict(embed_dim=128, image_resolution=64, vision_layers=(1, 1, 1, 1), vision_width=64, vision_patch_size=None,
               context_length=77, vocab_size=300, transformer_width=64, transformer_heads=1, transformer_layers=1)

@@ -1,0 +1,77 @@
+"""Image -> logits through the whole hot path on the GPU against a fixture produced by the REFERENCE's own chain
+(tests/golden/make_golden.py::make_e2e: build_cache_model + clip_classifier + pre_load_features on the reference's CLIP
+towers, then main.py:383-441 with a spy on P).  north_star's bar: logits within 1e-3, top-1 exactly.
+
+The comparator itself is fp16-noisy: the fixture holds the chain on the reference's fp16-weight towers (its GPU precision)
+AND on its fp32 towers (the CPU path, features cast to fp16); their disagreement `gap` = max|p16 - p32| is printed and the
+GPU result must stay within max(2 x gap, 1e-3) of both, with the same top-1 wherever the reference's own top-2 margin exceeds
+that bound (a query whose two best classes tie to 1e-4 has no defined top-1 at fp16 feature precision)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import adapter_sd, golden, observe
+from golden.spec import E2E, E2E_CASE, e2e_images
+from oracle import proto_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm(dim=-1) / b.norm(dim=-1)).max().item()
+
+
+def test_images_to_logits_against_reference_chain(tmp_path):
+    from proto_clip_amd import ops
+    from proto_clip_amd.clip.model import build_model, random_state_dict
+    from proto_clip_amd.model import Adapter
+    from proto_clip_amd.utils import build_cache_model, clip_classifier, pre_load_features
+    g = golden("e2e_small")
+    c = E2E_CASE
+    N, K, D = c["N"], c["K"], E2E["embed_dim"]
+    model = build_model(random_state_dict(seed=17, **E2E)).cuda()
+    (sup_x, sup_y), _, (test_x, test_y) = e2e_images()
+    cfg = dict(cache_dir=str(tmp_path), backbone="ViT-B/16", shots=K, augment_epoch=c["augment_epoch"], dataset="synthetic_e2e")
+    classnames, templates = [str(x) for x in g["classnames"]], [str(x) for x in g["templates"]]
+    with torch.no_grad():
+        keys, values = build_cache_model(cfg, model, [(sup_x[:10], sup_y[:10]), (sup_x[10:], sup_y[10:])])      # utils.py:284-332
+        test_f, test_l = pre_load_features(cfg, "test", model, [(test_x[:20], test_y[:20]), (test_x[20:], test_y[20:])])   # 335-361
+        _, text_bank = clip_classifier(classnames, templates, model)                                          # 256-273, real tokenizer
+        adapter = Adapter(D, c["adapter"], dtype=torch.half)
+        adapter.load_state_dict(adapter_sd(g))
+        adapter = adapter.cuda()
+        zi = ops.proto_build(ops.transpose(keys), N, K)                                  # main.py:399-402
+        zt = ops.l2norm_rows(ops.transpose(text_bank))                                   # 404-405
+        zq = adapter(test_f, l2norm_out=True)                                            # 407-409
+        p, am, _, _ = ops.classify(zq, zi, zt, c["alpha"], c["beta"], want_p=True, want_argmax=True)   # utils.py:225-244, main.py:433-435
+    p, am = p.cpu(), am.cpu().long()
+    assert torch.equal(test_l.cpu(), test_y) and torch.equal(values.cpu().argmax(1), torch.sort(sup_y).values)
+    p16, p32 = torch.from_numpy(g["p_f16"]), torch.from_numpy(g["p_f32"])
+    gap = (p16 - p32).abs().max().item()
+    d16, d32 = (p - p16).abs().max().item(), (p - p32).abs().max().item()
+    tol = max(2 * gap, 1e-3)
+    stage = {k: rel_err(a, torch.from_numpy(g[k + "_f16"])) for k, a in
+             (("test_features", test_f), ("text_bank", text_bank), ("adapted", zq), ("proto_img", zi), ("proto_txt", zt))}
+    ref_am = torch.from_numpy(g["argmax_f16"]).long()
+    srt = p16.sort(dim=1).values
+    margin = srt[:, -1] - srt[:, -2]
+    decided = margin > 2 * tol
+    agree = int((am == ref_am).sum())
+    print(f"\n[observed] image->logits: max|p - p_ref16| {d16:.2e}, max|p - p_ref32| {d32:.2e}; reference fp16<->fp32 gap {gap:.2e}; "
+          f"top-1 equal on {agree}/{len(am)} queries ({int(decided.sum())} with a reference margin > {2 * tol:.1e}, smallest margin "
+          f"{margin.min().item():.1e}); stage rel errors vs the reference fp16 chain: " + ", ".join(f"{k} {v:.1e}" for k, v in stage.items()))
+    observe("image->logits: reference fp16<->fp32 gap in p (yard-stick)", gap, gap)
+    observe("image->logits: max|p - p_reference(fp16 towers)|", d16, tol)
+    observe("image->logits: max|p - p_reference(fp32 towers)|", d32, tol)
+    observe("image->logits: top-1 disagreements among decided queries", float((am[decided] != ref_am[decided]).sum()), 0.0)
+    for k, v in stage.items():
+        observe(f"image->logits stage {k}: rel err vs reference fp16 chain", v, 5e-3)
+    assert d16 <= tol and d32 <= tol, (d16, d32, tol)
+    assert torch.equal(am[decided], ref_am[decided])
+    assert agree >= len(am) - int((~decided).sum())
+    acc = (am == test_y).float().mean().item()
+    assert abs(acc - float(g["acc_f16"])) <= float((~decided).sum()) / len(am) + 1e-6
+    # and the classification stage on the GPU's own adapted features against the oracle: exact top-1, p to 1e-5
+    p_o = po.P(zq.cpu(), zi.cpu(), zt.cpu(), c["alpha"], c["beta"])
+    assert (p - p_o).abs().max().item() <= 1e-5 and torch.equal(am, p_o.max(1)[1])

@@ -11,7 +11,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import golden
+from conftest import golden, observe
 from golden.spec import TRAIN, train_inputs
 from oracle import train_oracle as to
 
@@ -496,3 +496,52 @@ def test_compute_loss_and_matches_dropin():
     assert out[2] is None
     for got, r in zip(out[3:], ref[1:]):
         assert abs(got.item() - r.item()) <= 2e-5
+
+
+def test_qt_step_with_vit_l14_queries_c5():
+    """BASELINE configs[4] at its real size: FewSOL-198 shapes (N = 198, K = 16, D = 768, fc adapter, alpha 0.2 / beta 12,
+    both banks + adapter trained: configs/fewsol_198.yml with the main.qt.py override) where the queries of the step are
+    `clip_model.encode_image(images)` of a full ViT-L/14 tower under no_grad (main.qt.py:198-201), batch 8.  The tower is
+    checked against the encoder oracle (4 of the 8 images, fp16 rounding points); the training step is checked against the
+    training oracle's autograd on the SAME features (the reference differentiates nothing upstream of them), one step from
+    identical state."""
+    from oracle import clip_oracle
+    from proto_clip_amd import ops, synth
+    from proto_clip_amd.clip.model import BACKBONES, build_model, random_state_dict
+    from proto_clip_amd.main import make_adapter
+    from proto_clip_amd.train import ProtoClipTrainer
+    kw = BACKBONES["ViT-L/14"]
+    sd = random_state_dict(seed=27, **kw)
+    model = build_model({k: v.clone() for k, v in sd.items()}).cuda()
+    N, K, D, B = 198, 16, kw["embed_dim"], 8
+    split = synth.make_split(N, K, D, 8, 8, seed=5, sigma=5.0, sigma_text=3.0, unnormalized_text=True)
+    cfg = dict(shots=K, lr=1e-3, train_epoch=1, adapter="fc", train_vis_mem_only=False, losses=["L1", "L2", "L3"], alpha=0.2, beta=12.0)
+    torch.manual_seed(6)
+    ad = make_adapter(cfg, D)
+    ad_sd = {k: v.detach().cpu().clone() for k, v in ad.state_dict().items()}
+    gpu = ProtoClipTrainer(cfg, split.visual_memory_keys.cuda(), split.textual_memory_bank.cuda(), ad, cfg["alpha"], cfg["beta"])
+    ref = to.Trainer(cfg, split.visual_memory_keys, split.textual_memory_bank, ad_sd, cfg["alpha"], cfg["beta"])
+    labels = torch.from_numpy(synth.randint(B, N, 5, 40)).long()
+    imgs = synth.make_images(B, 224, seed=12, labels=labels.numpy() % 49)
+    with torch.no_grad():
+        feats = model.encode_image(imgs.cuda())                                           # main.qt.py:199-200
+    o16 = clip_oracle.encode_image(sd, imgs[:4], half=True).float()
+    e = ((feats[:4].float().cpu() - o16).norm(dim=-1) / o16.norm(dim=-1)).max().item()
+    assert observe("C5 Q^T step: ViT-L/14 query features rel err vs oracle fp16", e, 5e-3) <= 5e-3
+    matches, loss, l1, l2, l3, _, _ = gpu.step_features(feats, labels.cuda())
+    ref.keys_rows = feats.cpu()                                                           # the oracle's query source = the same features
+    m_ref, loss_ref, terms, grads = ref.step(list(range(B)), labels.tolist())
+    assert float(matches.item()) == m_ref
+    assert observe("C5 Q^T step: |loss - oracle| / max(1, |oracle|)", abs(loss.item() - loss_ref) / max(1.0, abs(loss_ref)), 2e-5) <= 2e-5
+    for got, key in ((l1, "L1"), (l2, "L2"), (l3, "L3")):
+        assert abs(got.item() - terms[key]) <= 2e-5 * max(1.0, abs(terms[key])), key
+    params = dict(gpu.adapter.named_parameters())
+    for name, g_ref in grads.items():
+        p = gpu.visual if name == "visual" else gpu.textual if name == "textual" else params[name]
+        got = gpu.last_grads.get(id(p))
+        assert g_ref is not None and got is not None, name
+        tol = 2e-2 if name not in ("visual", "textual") else 3e-3
+        r = rel_l2(got.reshape(g_ref.shape), g_ref)
+        assert observe(f"C5 Q^T step: gradient rel-L2 vs autograd ({'bank' if name in ('visual', 'textual') else 'fc adapter'})", r, tol) <= tol, (name, r)
+    # AdamW step: parameters after the update against torch.optim.AdamW on the oracle's gradients
+    assert rel_l2(gpu.visual, ref.visual.detach()) <= 1e-3 and rel_l2(gpu.textual, ref.textual.detach()) <= 1e-3

@@ -118,25 +118,99 @@ def test_synth_is_deterministic_and_laid_out_like_the_reference():
                                                           0.364806048344448], rtol=1e-14)
 
 
-def test_tokenizer_matches_reference_ids():
-    """clip.tokenize against ids produced by the reference's tokenizer (tests/golden/tokenizer.npz).  Needs the
-    BPE merge table (data, not shipped here): found in this container's reference tree, skipped elsewhere."""
-    vocab = os.environ.get("PCLIP_BPE_VOCAB", "/root/reference/clip/bpe_simple_vocab_16e6.txt.gz")
-    if not os.path.isfile(vocab):
-        pytest.skip("BPE merge table not available on this machine")
+def test_tokenizer_matches_reference_ids(monkeypatch):
+    """clip.tokenize against ids produced by the reference's tokenizer (tests/golden/tokenizer.npz: the six probe prompts, all
+    7 ImageNet templates x 50 class names, punctuation / unicode / html entities / whitespace / contractions / digits, the
+    empty string, a 77-token-overflow).  The merge table ships with the package, so this runs everywhere."""
     from proto_clip_amd.clip import simple_tokenizer
     from proto_clip_amd.clip.clip import tokenize
-    simple_tokenizer._default = simple_tokenizer.SimpleTokenizer(vocab)
+    monkeypatch.delenv("PCLIP_BPE_VOCAB", raising=False)
+    monkeypatch.setattr(simple_tokenizer, "_default", None)
     g = golden("tokenizer")
-    ids = tokenize([str(p) for p in g["prompts"]])
-    assert ids.shape == (len(g["prompts"]), 77) and ids.dtype == torch.int64
-    assert torch.equal(ids, torch.from_numpy(g["ids"]).long())
+    prompts = [str(p) for p in g["prompts"]]
+    assert len(prompts) >= 360
+    ids = tokenize(prompts)
+    assert ids.shape == (len(prompts), 77) and ids.dtype == torch.int64
+    ref = torch.from_numpy(g["ids"]).long()
+    bad = [prompts[i] for i in range(len(prompts)) if not torch.equal(ids[i], ref[i])]
+    assert not bad, bad[:5]
     assert ids[0, :9].tolist() == [49406, 320, 1125, 539, 320, 1929, 269, 49407, 0]      # SURVEY §8c probe
+    assert torch.equal(tokenize("a photo of a dog."), ids[:1])                           # str input == one-element list
     with pytest.raises(RuntimeError):
         tokenize("word " * 100)
-    assert tokenize("word " * 100, truncate=True)[0, -1].item() == 49407
+    assert torch.equal(tokenize("word " * 100, truncate=True), torch.from_numpy(g["truncated"]).long())
     tok = simple_tokenizer._default
     assert tok.decode(tok.encode("a photo of a dog.")).strip() == "a photo of a dog ."
+
+
+def test_tokenizer_missing_merge_table_is_a_loud_error(monkeypatch, tmp_path):
+    from proto_clip_amd.clip import simple_tokenizer
+    from proto_clip_amd.clip.clip import tokenize
+    monkeypatch.setattr(simple_tokenizer, "_default", None)
+    monkeypatch.setenv("PCLIP_BPE_VOCAB", str(tmp_path / "nope.txt.gz"))
+    with pytest.raises(FileNotFoundError, match="PCLIP_BPE_VOCAB"):
+        tokenize("a photo of a dog.")
+    monkeypatch.delenv("PCLIP_BPE_VOCAB")
+    assert os.path.isfile(simple_tokenizer.default_bpe())                                # the shipped copy
+    assert tokenize("a photo of a dog.")[0, 0].item() == 49406
+
+
+def test_clip_load_checkpoint_formats(tmp_path):
+    """clip.load's file handling (reference clip/clip.py:92-139): a plain state-dict file, a TorchScript archive (what OpenAI
+    ships: the reference calls torch.jit.load(...).state_dict() and rebuilds, clip/clip.py:126-139), a name resolved inside
+    download_root, and the error paths.  Building the model needs no GPU until `.to(device)`, so device='cpu' parameters are
+    checked here; the GPU test (tests/test_gpu_encoder.py::test_clip_load_runs_on_gpu) pushes images through the result."""
+    from proto_clip_amd.clip import clip as pclip
+    from proto_clip_amd.clip.model import random_state_dict
+    from conftest import TINY
+    sd = random_state_dict(seed=3, **TINY)
+    path_sd = tmp_path / "tiny_sd.pt"
+    torch.save(sd, path_sd)
+
+    class Holder(torch.nn.Module):                # a scriptable module whose state_dict() has OpenAI's key names
+        def __init__(self, sd_):
+            super().__init__()
+            for k, v in sd_.items():
+                mod, parts = self, k.split(".")
+                for part in parts[:-1]:
+                    if not hasattr(mod, part):
+                        mod.add_module(part, torch.nn.Module())
+                    mod = getattr(mod, part)
+                mod.register_buffer(parts[-1], v.clone())
+
+        def forward(self, x):
+            return x
+
+    # plus the three metadata entries OpenAI's archives carry (clip/model.py:427-429 deletes them)
+    meta = dict(sd, input_resolution=torch.tensor(TINY["image_resolution"]), context_length=torch.tensor(77), vocab_size=torch.tensor(TINY["vocab_size"]))
+    path_jit = tmp_path / "tiny_jit.pt"
+    torch.jit.save(torch.jit.script(Holder(meta)), str(path_jit))
+    got = pclip._state_dict_from_file(str(path_jit))
+    assert set(got) == set(meta) and all(torch.equal(got[k], meta[k]) for k in meta)
+    got = pclip._state_dict_from_file(str(path_sd))
+    assert list(got) == list(sd)
+    for path in (path_sd, path_jit):
+        model, preprocess = pclip.load(str(path), device="cpu")
+        msd = model.state_dict()
+        assert set(msd) == set(sd)
+        for k, v in sd.items():                   # convert_weights: fp16 for Linear / conv / projections, fp32 elsewhere
+            want = v.half() if msd[k].dtype == torch.float16 else v.float()
+            assert torch.equal(msd[k], want.to(msd[k].dtype)), k
+        assert msd["visual.conv1.weight"].dtype == torch.float16 and msd["visual.ln_pre.weight"].dtype == torch.float32
+        assert model.visual.input_resolution == TINY["image_resolution"] and preprocess.n_px == TINY["image_resolution"]
+    # a model NAME is looked up in download_root under the reference's file names (clip/clip.py:30-38, 118-121); no download
+    root = tmp_path / "cache"
+    root.mkdir()
+    torch.save(sd, root / "ViT-B-16.pt")
+    model, _ = pclip.load("ViT-B/16", device="cpu", download_root=str(root))
+    assert set(model.state_dict()) == set(sd)
+    with pytest.raises(RuntimeError, match="not found and downloading is disabled"):
+        pclip.load("RN50", device="cpu", download_root=str(root))
+    with pytest.raises(RuntimeError, match="available models"):
+        pclip.load("ViT-Z/99", device="cpu")
+    with pytest.raises(Exception, match="jit"):
+        pclip.load(str(path_sd), device="cpu", jit=True)
+    assert pclip.available_models() == ["RN50", "RN101", "ViT-B/32", "ViT-B/16", "ViT-L/14"]
 
 
 def test_model_surface_and_state_dict_names():
