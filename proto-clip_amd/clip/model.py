@@ -64,27 +64,39 @@ def _transformer(width, layers):
 
 
 def _run_blocks(x, blocks, B, L, heads, causal, select=None, first_token=False, h0=None):
-    """ResidualAttentionBlock.forward (clip/model.py:187-190) per layer on x [B*L, W] fp16.
-    Each residual add is fused into the LayerNorm that reads its result, so the stream of a block is
-        h = LN1(x [+ d])   qkv = in_proj(h)   a = attention(qkv)   d = out_proj(a)
-        h = LN2(x += d)    f = QuickGELU(c_fc(h))                  d = c_proj(f)
-    Returns (x, d): the block stack's output is x + d, left for the caller's final LayerNorm to fuse.
+    """ResidualAttentionBlock.forward (clip/model.py:187-190) per layer on x [B*L, W] fp16 (updated IN PLACE).
+    Both residual adds ride in the epilogue of the GEMM that produces the addend (pclip_gemm_f16 with `residual`: the residual
+    rows are read in the coalesced store pass, r16(x + r16(acc + bias)) — the reference's two roundings), so a block is
+        h = LN1(x)   qkv = in_proj(h)   a = attention(qkv)   x += out_proj(a)
+        h = LN2(x)   f = QuickGELU(c_fc(h))                  x += c_proj(f)
+    and each LayerNorm is a plain read-x / write-h pass (the fused add + LayerNorm pass it replaces moved twice the bytes).
+    In low-latency mode (ops.low_latency: split-K linears of a serving request) the addend is produced by the split-K kernel
+    and the add stays in the LayerNorm pass (pclip_add_layernorm_f16) — the same values either way.
+    Returns (x, d): the stack's output is x (+ d when d is not None — low-latency mode leaves the last add to the caller's
+    final LayerNorm), [B, W] rows picked by `select` when given.
 
     `select(t)` picks, from a [B*L, W] tensor, the B rows the caller reads after the stack (the class token of the vision
     tower, clip/model.py:233; the EOT token of the text tower, :350).  The reference pushes every token through the last
     block and then discards all but that row; here the last block's out_proj, LN2 and MLP run on those B rows only — the
     same arithmetic for the rows that matter (a GEMM row does not depend on the other rows), 9/12 of one layer's linear
-    FLOPs saved (6 % of a 12-layer tower).  With `select`, x and d are returned as [B, W].  `first_token` (vision tower: the
+    FLOPs saved (6 % of a 12-layer tower).  `first_token` (vision tower: the
     selected row is token 0 of every sequence) additionally projects the last block's QUERIES for those B rows only and runs
     its attention for that one query per image (keys / values still come from every token)."""
-    d = None
     n = len(blocks)
+    d = None
+
+    def add_linear(x_, a_, lin, ln):
+        """x_ += lin(a_) ; returns (x_, LN(x_))."""
+        if ops.splitk_active(a_.shape[0]):
+            d = ops.gemm(a_, lin.weight, lin.bias)
+            return x_, ops.add_layernorm(x_, d, ln.weight, ln.bias)
+        ops.gemm(a_, lin.weight, lin.bias, residual=x_, out=x_)
+        return x_, (ops.layernorm(x_, ln.weight, ln.bias) if ln is not None else None)
+
+    h = h0 if (n > 0 and h0 is not None) else (ops.layernorm(x, blocks[0].ln_1.weight, blocks[0].ln_1.bias) if n > 0 else None)
     for i, blk in enumerate(blocks):
-        if d is None:
-            h = h0 if (i == 0 and h0 is not None) else ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias)   # h0: ln_1 of block 0, already done
-        else:
-            h = ops.add_layernorm(x, d, blk.ln_1.weight, blk.ln_1.bias)
-        if select is not None and i == n - 1 and first_token and not causal:
+        last = i == n - 1
+        if select is not None and last and first_token and not causal:
             W = h.shape[1]
             w, bias = blk.attn.in_proj_weight, blk.attn.in_proj_bias
             kv = ops.gemm(h, w[W:], bias[W:])                                     # keys | values of every token
@@ -93,12 +105,17 @@ def _run_blocks(x, blocks, B, L, heads, causal, select=None, first_token=False, 
         else:
             qkv = ops.gemm(h, blk.attn.in_proj_weight, blk.attn.in_proj_bias)
             a = ops.attention(qkv, B, L, heads, causal=causal)
-            if select is not None and i == n - 1:
-                a, x = select(a), select(x)              # x already holds the residual stream entering this block's out_proj add
-        d = ops.gemm(a, blk.attn.out_proj.weight, blk.attn.out_proj.bias)
-        h = ops.add_layernorm(x, d, blk.ln_2.weight, blk.ln_2.bias)
+            if select is not None and last:
+                a, x = select(a), select(x)              # x holds the residual stream entering this block's out_proj add
+        x, h = add_linear(x, a, blk.attn.out_proj, blk.ln_2)
         f = ops.gemm(h, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, act=1)
-        d = ops.gemm(f, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)
+        if last:
+            if ops.splitk_active(f.shape[0]):
+                d = ops.gemm(f, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)      # the caller's final LayerNorm adds it
+            else:
+                ops.gemm(f, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, residual=x, out=x)
+        else:
+            x, h = add_linear(x, f, blk.mlp.c_proj, blocks[i + 1].ln_1)
     if select is not None and n == 0:
         x = select(x)
     return x, d
@@ -178,9 +195,9 @@ class VisionTransformer(nn.Module):
             x = ops.layernorm(x, self.ln_pre.weight, self.ln_pre.bias)      # 227
         pick_cls = lambda t: t.view(B, L, W)[:, 0, :].contiguous()          # x[:, 0, :], 233 (taken before the last block's tail)
         x, d = _run_blocks(x, blocks, B, L, self.heads, causal=False, select=pick_cls, first_token=True, h0=h0)   # 229-231
-        if d is None:
+        if d is None:                                                       # ln_post(x[:, 0, :]), 233
             cls = ops.layernorm(x, self.ln_post.weight, self.ln_post.bias)
-        else:                                                               # ln_post((x + d)[:, 0, :]), 233
+        else:
             cls = ops.add_layernorm(x, d, self.ln_post.weight, self.ln_post.bias, update_x=False)
         return ops.gemm(cls, projT)                                         # x @ proj, 235-236
 

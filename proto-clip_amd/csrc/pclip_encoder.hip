@@ -61,19 +61,23 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
                                                                      int K, const half_t* __restrict__ bias,
                                                                      const float* __restrict__ scale,
                                                                      const float* __restrict__ shift,
-                                                                     half_t* __restrict__ Cout, int ldc, int tiles_n,
-                                                                     int ntiles, const half_t* __restrict__ residual = nullptr) {
+                                                                     half_t* Cout, int ldc, int tiles_n,
+                                                                     int ntiles, const half_t* residual = nullptr) {
     // ACT 5: relu(r16(r16(r16(acc) * scale + shift) + residual)) — bn3 + `out += identity` + ReLU of a bottleneck (clip/model.py:49-52)
-    // in the epilogue of its conv3 GEMM; the residual rows are read row-major in the coalesced store pass
+    // in the epilogue of its conv3 GEMM; the residual rows are read row-major in the coalesced store pass.
+    // ACT 6: r16(residual + r16(acc + bias)) — `x = x + attn(..)` / `x = x + mlp(..)` of a transformer block (clip/model.py:188-189)
+    // in the epilogue of out_proj / c_proj; Cout may BE residual (the residual stream is updated in place: every 16-byte chunk is
+    // read and then written by the same thread)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* bias_lds = reinterpret_cast<half_t*>(smem + C::LDS_BYTES);       // [2][BN] fp16
     float* affine_lds = reinterpret_cast<float*>(smem + C::LDS_BYTES);       // ACT >= 2: [2][ scale BN | shift BN ] fp32
-    constexpr bool AFFINE = ACT >= 2;
+    constexpr bool AFFINE = ACT == 2 || ACT == 3 || ACT == 5;
     const int G = gridDim.x;
     int tile = pgemm::xcd_remap(blockIdx.x, G);
     if (tile >= ntiles) return;
     int p = 0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave % C::WN, hi = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave % C::WN, hi = lane >> 5;
+    pgemm::TilePair<C> tp;                                       // M16: buffer-descriptor staging + pipelined K-loop (pgemm::mainloop_bl)
     // The bias enters as the INITIAL VALUE of the accumulators (fp32 copy of the fp16 bias: r16(bias + sum) instead of
     // r16(sum + bias), same value up to fp32 summation order), so the epilogue has no bias pass.  Its strip is copied one
     // tile ahead (double-buffered); every wave copies the same BN values: uniform vmcnt bookkeeping.
@@ -98,7 +102,11 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     }
     {
         const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-        pgemm::stage_first<C>(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, smem, p);
+        if (M16) {
+            tp.prepare(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, wave, lane);
+            tp.stage(0, smem + p * C::STAGE_BYTES, wave);
+        } else
+            pgemm::stage_first<C>(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, smem, p);
     }
     constexpr int YOUNGER = C::NH * C::NPASS + (AFFINE ? 2 : (HAS_BIAS ? 1 : 0));
     bool prev_full = false;
@@ -128,11 +136,16 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             copy_bias(tile + G < ntiles ? tile + G : tile, parity ^ 1);
         }
         if (AFFINE) copy_affine(tile + G < ntiles ? tile + G : tile, parity ^ 1);
-        pgemm::mainloop<C, YOUNGER, !HAS_BIAS, M16>(A, lda, B, ldb, M, N, K, m0, n0, smem, acc, p, prev_full);
+        if (M16) pgemm::mainloop_bl<C, YOUNGER, !HAS_BIAS>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane);
+        else pgemm::mainloop<C, YOUNGER, !HAS_BIAS, M16>(A, lda, B, ldb, M, N, K, m0, n0, smem, acc, p, prev_full);
         const int next = tile + G;
         if (next < ntiles) {                                  // buffer p is free: prefetch the next tile's K-tile 0
             const int tm = next / tiles_n, tn = next - tm * tiles_n;
-            pgemm::stage_first<C>(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, smem, p);
+            if (M16) {
+                tp.prepare(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, wave, lane);
+                tp.stage(0, smem + p * C::STAGE_BYTES, wave);
+            } else
+                pgemm::stage_first<C>(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, smem, p);
         }
         char* stg = smem + (p ^ 1) * C::STAGE_BYTES;          // buffer of the last K-tile, reused after a barrier
         const int col = n0 + 8 * (tid % C::CPR);
@@ -154,21 +167,38 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
             return h;
         };
-        auto add_res = [&](size_t o, half8_t h) {
-            const half8_t rr = ld_half8(residual + o);
+        // Residual operand: the NPASS 16-byte chunks a thread adds to in slab h are requested TOGETHER in the slab hook, before
+        // the slab is staged (they fly during the LDS write pass) — Cout may alias residual (in-place residual stream), so the
+        // compiler cannot hoist a later pass's load above an earlier pass's store by itself: load -> wait -> store per pass was
+        // 16 dependent round trips per tile.
+        constexpr bool RES = ACT == 5 || ACT == 6;
+        half8_t rr[RES ? C::NPASS : 1];
+        auto slab = [&](int h) {
+            if (!RES) return;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) h[j] = (half_t)fmaxf(r16((float)h[j] + (float)rr[j]), 0.f);
+            for (int ps = 0; ps < C::NPASS; ++ps) {
+                const int r = h * C::HR + tid / C::CPR + ps * C::ROWS_PER_PASS;
+                if (full || m0 + r < M) rr[ps] = ld_half8(residual + (size_t)(m0 + r) * ldc + col);
+            }
+        };
+        auto add_res = [&](int pass, half8_t h) {
+            const half8_t x = rr[RES ? pass % C::NPASS : 0];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float y = r16((float)x[j] + (float)h[j]);
+                h[j] = (half_t)(ACT == 5 ? fmaxf(y, 0.f) : y);
+            }
             return h;
         };
         if (full)
-            pgemm::epilogue_f16<C, M16>(acc, stg, [](int) {}, pre, [&](int r, int, int, half8_t h) {
+            pgemm::epilogue_f16<C, M16>(acc, stg, slab, pre, [&](int r, int, int pass, half8_t h) {
                 const size_t o = (size_t)(m0 + r) * ldc + col;
-                st_half8(Cout + o, ACT == 5 ? add_res(o, h) : h);
+                st_half8(Cout + o, RES ? add_res(pass, h) : h);
             });
         else
-            pgemm::epilogue_f16<C, M16>(acc, stg, [](int) {}, pre, [&](int r, int, int, half8_t h) {
+            pgemm::epilogue_f16<C, M16>(acc, stg, slab, pre, [&](int r, int, int pass, half8_t h) {
                 const size_t o = (size_t)(m0 + r) * ldc + col;
-                if (m0 + r < M) st_half8(Cout + o, ACT == 5 ? add_res(o, h) : h);
+                if (m0 + r < M) st_half8(Cout + o, RES ? add_res(pass, h) : h);
             });
         prev_full = full;
     }
@@ -310,7 +340,7 @@ template <class C, bool HAS_BIAS, int ACT, bool M16 = false>
 static int launch_fast2(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const LinearEpi& epi,
                         int slots, hipStream_t s) {
     static bool attr = false;
-    constexpr int LDS = C::LDS_BYTES + (ACT >= 2 ? 2 * 2 * C::BN * 4 : 2 * C::BN * 2);   // K-tile ring + double-buffered bias / affine strips
+    constexpr int LDS = C::LDS_BYTES + ((ACT == 2 || ACT == 3 || ACT == 5) ? 2 * 2 * C::BN * 4 : 2 * C::BN * 2);   // K-tile ring + double-buffered bias / affine strips
     if (!attr) {
         if (hipFuncSetAttribute((const void*)linear_fast_kernel<C, HAS_BIAS, ACT, M16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS) != hipSuccess) {
@@ -334,6 +364,7 @@ static int launch_fast_m(const void* A, int lda, const void* B, int ldb, int M, 
     if (epi.act == 2) return launch_fast2<C, false, 2, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
     if (epi.act == 3) return launch_fast2<C, false, 3, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
     if (epi.act == 5) return launch_fast2<C, false, 5, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
+    if (epi.act == 6) return launch_fast2<C, true, 6, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
     if (epi.bias) {
         if (epi.act == 1) return launch_fast2<C, true, 1, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
         return launch_fast2<C, true, 0, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
@@ -883,10 +914,10 @@ int launch_small_one(const half_t* A, int lda, const half_t* B, int ldb, int M, 
 
 int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int N, int K, LinearEpi epi, int cus, int forced,
                   bool may_split, hipStream_t s) {
-    const bool aligned = (!epi.residual || (epi.act == 5 && ((uintptr_t)epi.residual & 15) == 0)) && epi.ldc % 8 == 0 && ((uintptr_t)epi.C & 15) == 0 &&
+    const bool aligned = (!epi.residual || ((epi.act == 5 || epi.act == 6) && ((uintptr_t)epi.residual & 15) == 0)) && epi.ldc % 8 == 0 && ((uintptr_t)epi.C & 15) == 0 &&
                          (!epi.bias || ((uintptr_t)epi.bias & 15) == 0);
     static const bool small_on = !(getenv("PCLIP_GEMM_SMALL") && getenv("PCLIP_GEMM_SMALL")[0] == '0');
-    if (aligned && forced == -1 && small_on && (epi.act <= 1 || (((uintptr_t)epi.scale | (uintptr_t)epi.shift) & 15) == 0) && small_applies(M, N, cus))
+    if (aligned && forced == -1 && small_on && (epi.act <= 1 || epi.act == 6 || (((uintptr_t)epi.scale | (uintptr_t)epi.shift) & 15) == 0) && small_applies(M, N, cus))
         return launch_small_one(A, lda, B, ldb, M, N, K, epi, s);
     double cost = 1e30;
     int pick = aligned ? best_cfg(M, N, cus, &cost) : -1;
@@ -915,11 +946,12 @@ int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int
             if (rc != PCLIP_OK) return rc;
             LinearEpi tail = epi;
             tail.C = epi.C + (size_t)split_rows * epi.ldc;
-            if (epi.residual) tail.residual = epi.residual + (size_t)split_rows * epi.ldc;   // act 5: same row stride as C
+            if (epi.residual) tail.residual = epi.residual + (size_t)split_rows * epi.ldc;   // act 5 / 6: same row stride as C
             return gemm_dispatch(A + (size_t)split_rows * lda, lda, B, ldb, M - (int)split_rows, N, K, tail, cus, -1, true, s);
         }
     }
     ++g_gemm_launches;
+    if (pick < 0 && epi.act == 6) epi.act = 0;                  // generic kernel: bias + residual operands, same roundings
     if (pick == 2) return launch_fast<CfgBig>(A, lda, B, ldb, M, N, K, epi, cus, s);
     if (pick == 1) return launch_fast<CfgWide>(A, lda, B, ldb, M, N, K, epi, cus, s);
     if (pick == 0) return launch_fast<CfgSmall>(A, lda, B, ldb, M, N, K, epi, 2 * cus, s);
@@ -940,6 +972,7 @@ extern "C" int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, vo
     PCLIP_REQUIRE(act == 0 || act == 1, "pclip_gemm_f16: unknown activation %d", act);
     if (M == 0) return PCLIP_OK;
     LinearEpi epi{(const half_t*)bias, (const half_t*)residual, (half_t*)C, ldc, act, nullptr, nullptr};
+    if (residual && bias && act == 0) epi.act = 6;              // fused residual epilogue of the persistent / ring kernels
     static int cus = 0;
     static int forced = -1;
     static bool live = false, nosplit = false;
@@ -977,10 +1010,10 @@ __global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void linear_small_kernel(con
                                                                            const half_t* __restrict__ B, int ldb, int M, int N,
                                                                            int K, int tiles_n, int S, int steps_per,
                                                                            float* __restrict__ ws, const half_t* __restrict__ bias,
-                                                                           half_t* __restrict__ Cout, int ldc,
+                                                                           half_t* Cout, int ldc,
                                                                            const float* __restrict__ scale,
                                                                            const float* __restrict__ shift,
-                                                                           const half_t* __restrict__ residual = nullptr) {
+                                                                           const half_t* residual = nullptr) {
     using C = CfgSplit;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = blockIdx.x / S, ks = blockIdx.x - tile * S;
@@ -1009,7 +1042,7 @@ __global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void linear_small_kernel(con
         auto pre = [&](int, int j, int coff, float4_t v) {
             if (ACT == 1) return quick_gelu16x4(v);
             half4_t h;
-            if (ACT >= 2) {                                 // eval BatchNorm (+ReLU) as in linear_fast_kernel: same roundings
+            if (ACT == 2 || ACT == 3 || ACT == 5) {         // eval BatchNorm (+ReLU) as in linear_fast_kernel: same roundings
                 const int n = n0 + wn * (C::BN / C::WN) + j * 32 + coff;
                 const float4_t sc = *reinterpret_cast<const float4_t*>(scale + n), sh = *reinterpret_cast<const float4_t*>(shift + n);
 #pragma unroll
@@ -1028,10 +1061,13 @@ __global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void linear_small_kernel(con
         pgemm::epilogue_f16<C, true>(acc, smem, [](int) {}, pre, [&](int r, int, int, half8_t h) {
             if (m0 + r >= M) return;
             const size_t o = (size_t)(m0 + r) * ldc + col;
-            if (ACT == 5) {
+            if (ACT == 5 || ACT == 6) {
                 const half8_t rr = ld_half8(residual + o);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) h[j] = (half_t)fmaxf(r16((float)h[j] + (float)rr[j]), 0.f);
+                for (int j = 0; j < 8; ++j) {
+                    const float y = r16((float)rr[j] + (float)h[j]);
+                    h[j] = (half_t)(ACT == 5 ? fmaxf(y, 0.f) : y);
+                }
             }
             st_half8(Cout + o, h);
         });
@@ -1131,7 +1167,7 @@ inline int small_attr() {
     static bool done = false;
     if (!done) {
         const void* fns[] = {(const void*)linear_small_kernel<0>, (const void*)linear_small_kernel<1>, (const void*)linear_small_kernel<2>,
-                             (const void*)linear_small_kernel<3>, (const void*)linear_small_kernel<5>, (const void*)conv3x3_small_kernel<2>, (const void*)conv3x3_small_kernel<3>};
+                             (const void*)linear_small_kernel<3>, (const void*)linear_small_kernel<5>, (const void*)linear_small_kernel<6>, (const void*)conv3x3_small_kernel<2>, (const void*)conv3x3_small_kernel<3>};
         for (const void* f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kSmallLds) != hipSuccess) {
                 pclip_set_error("gemm_f16 (small M): cannot raise the dynamic LDS limit to %d", kSmallLds);
@@ -1154,6 +1190,7 @@ int launch_small_one(const half_t* A, int lda, const half_t* B, int ldb, int M, 
     linear_small_kernel<ACT><<<grid, CfgSplit::NTHREADS, kSmallLds, s>>>(A, lda, B, ldb, M, N, K, tiles_n, 1, steps, nullptr, epi.bias, epi.C, \
                                                                         epi.ldc, epi.scale, epi.shift, epi.residual)
     if (epi.act == 5) PCLIP_SMALL_LAUNCH(5);
+    else if (epi.act == 6) PCLIP_SMALL_LAUNCH(6);
     else if (epi.act == 1) PCLIP_SMALL_LAUNCH(1);
     else if (epi.act == 2) PCLIP_SMALL_LAUNCH(2);
     else if (epi.act == 3) PCLIP_SMALL_LAUNCH(3);

@@ -212,6 +212,145 @@ __device__ __forceinline__ void mainloop(const half_t* __restrict__ A, int lda, 
                                      B, ldb, N, K / BK, n0, smem, acc, p, counted_first);
 }
 
+// ---- buffer-descriptor staging + register-pipelined K-loop (the persistent linear kernels) ---------------------------------
+// The K-loop above leaves two things on the table (read off its ISA): (1) every LDS-DMA piece recomputes a 64-bit
+// per-lane global address (3 v_lshl_add_u64 + readfirstlane + s_mov m0 per piece, ~90 VGPRs of address state for the 16
+// pieces of a 256x256 tile), which is why the kernel sat at the 256-register cap with scratch spills; (2) hipcc reads two
+// fragments, waits lgkmcnt(0), issues 8 MFMAs, reads the next two ... — the LDS latency is exposed eight times per K-tile.
+// Here a tile operand is ONE buffer descriptor (SGPRs, base = first row of the tile) + one 32-bit byte offset per piece and
+// lane, fixed for the whole tile; the K-tile advances through the instruction's SCALAR offset (no VALU work per piece:
+// s_mov m0 + buffer_load ... lds).  The fragments are software-pipelined in GROUPS of (half of the wave's A rows) x (all
+// of its B columns) x one 32-wide k-step: while the 2*TM*TN MFMAs of a group issue, the next group's fragments are already
+// on their way from LDS (A next half; B of the next k-step during the second half).  Only the first group of a K-tile waits
+// for LDS with nothing to cover it.  Same k-order per accumulator as mainloop_g's M16 branch: bit-identical results.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+#else
+struct rsrc_t { int w[4]; };                     // the host pass only parses the kernels; the descriptor type is device-only
+#endif
+
+template <int ROWS, int NWAVES>
+struct TileSrc {
+    static constexpr int RPW = ROWS / NWAVES, NL = RPW / 8;          // rows per wave, LDS-DMA pieces per wave and K-tile
+    rsrc_t rs;
+    int voff[NL];
+    // rows >= nrows are clamped to the last row (never stored); row0 <= nrows - 1
+    __device__ __forceinline__ void prepare(const half_t* __restrict__ g, int ld, int row0, int nrows, int wave, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // descriptor inputs through readfirstlane: hipcc must be able to PROVE the descriptor wave-uniform, otherwise every
+        // buffer op is wrapped in a waterfall loop (guide T20)
+        const uint64_t addr = (uint64_t)(g + (size_t)row0 * ld);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)addr), hi = __builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+#endif
+        const int last = nrows - 1 - row0;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int r = wave * RPW + i * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ swz_key(r);
+            voff[i] = ((r < last ? r : last) * ld + c * 8) * 2;
+        }
+    }
+    __device__ __forceinline__ void stage(int k_bytes, char* lds_tile, int wave) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(lds_tile + (wave * RPW + i * 8) * ROW_BYTES), 16, voff[i], k_bytes, 0, 0);
+#endif
+    }
+};
+
+template <class C>
+struct TilePair {
+    TileSrc<C::BM, C::NWAVES> a;
+    TileSrc<C::BN, C::NWAVES> b;
+    __device__ __forceinline__ void prepare(const half_t* __restrict__ A, int lda, const half_t* __restrict__ B, int ldb, int M, int N,
+                                            int m0, int n0, int wave, int lane) {
+        a.prepare(A, lda, m0, M, wave, lane);
+        b.prepare(B, ldb, n0, N, wave, lane);
+    }
+    __device__ __forceinline__ void stage(int t, char* stage_buf, int wave) const {
+        a.stage(t * (BK * 2), stage_buf, wave);
+        b.stage(t * (BK * 2), stage_buf + C::A_BYTES, wave);
+    }
+};
+
+// K-loop over a tile whose K-tile 0 is already on its way into buffer `p` (TilePair::stage(0, ..)); semantics of `p`, YOUNGER,
+// counted_first as mainloop_g.  `wave` must be wave-uniform (readfirstlane).
+template <class C, int YOUNGER = 0, bool ZERO_ACC = true>
+__device__ __forceinline__ void mainloop_bl(const TilePair<C>& tp, int nt, char* smem, Acc<C>& acc, int& p, bool counted_first, int wave,
+                                            int lane) {
+    static_assert(C::TM >= 2 && C::TM % 2 == 0, "group pipeline splits the wave's A rows in two halves");
+    constexpr int HM = C::TM / 2;                                    // 32-row blocks per half
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    if (ZERO_ACC) {
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc.v[i][j][e] = 0.f;
+    }
+    // fragment addressing: row = 32-aligned base + 16*x + (lane & 15) -> swz_key(row) = (lane & 15) >> 1 for every fragment;
+    // 16-byte chunk kc = 4*ks + (lane >> 4)  ->  byte offset in the row ((kc ^ key) << 4); ks = 1 is ks = 0 with bit 6 flipped
+    const int key = (lane & 15) >> 1, q = lane >> 4;
+    const int col0 = (q ^ key) << 4;
+    const int offa = (wm * (C::BM / C::WM) + (lane & 15)) * ROW_BYTES + col0;
+    const int offb = C::A_BYTES + (wn * (C::BN / C::WN) + (lane & 15)) * ROW_BYTES + col0;
+    const bool late = C::NWAVES == 8 && wave >= 4;
+
+    for (int t = 0; t < nt; ++t) {
+        if (t == 0 && counted_first) wait_vm<YOUNGER>(); else wait_vm<0>();
+        lds_barrier();
+        const char* base = smem + p * C::STAGE_BYTES;
+        auto fa = [&](int ks, int i, int a) { return *reinterpret_cast<const half8_t*>(base + (offa ^ (ks << 6)) + (i * 32 + a * 16) * ROW_BYTES); };
+        auto fb = [&](int ks, int j, int b) { return *reinterpret_cast<const half8_t*>(base + (offb ^ (ks << 6)) + (j * 32 + b * 16) * ROW_BYTES); };
+        auto stage_next = [&]() { if (t + 1 < nt) tp.stage(t + 1, smem + (p ^ 1) * C::STAGE_BYTES, wave); };
+        half8_t bcur[C::TN][2], acur[HM][2], anext[HM][2], bnext[C::TN][2];
+        auto load_a = [&](half8_t (&dst)[HM][2], int ks, int half) {
+#pragma unroll
+            for (int i = 0; i < HM; ++i)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) dst[i][a] = fa(ks, half * HM + i, a);
+        };
+        auto load_b = [&](half8_t (&dst)[C::TN][2], int ks) {
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) dst[j][b] = fb(ks, j, b);
+        };
+        auto group = [&](const half8_t (&af)[HM][2], const half8_t (&bf)[C::TN][2], int half) {
+#pragma unroll
+            for (int i = 0; i < HM; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            float16_t& dst = acc.v[half * HM + i][j];
+                            float4_t c = {dst[(a * 2 + b) * 4], dst[(a * 2 + b) * 4 + 1], dst[(a * 2 + b) * 4 + 2], dst[(a * 2 + b) * 4 + 3]};
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][b], af[i][a], c, 0, 0, 0);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) dst[(a * 2 + b) * 4 + r] = c[r];
+                        }
+        };
+        load_b(bcur, 0);
+        load_a(acur, 0, 0);
+        if (!late) stage_next();
+        load_a(anext, 0, 1);
+        group(acur, bcur, 0);                    // ks 0, rows half 0   (covers anext)
+        load_b(bnext, 1);
+        load_a(acur, 1, 0);
+        group(anext, bcur, 1);                   // ks 0, rows half 1   (covers bnext, acur)
+        if (late) stage_next();
+        load_a(anext, 1, 1);
+        group(acur, bnext, 0);                   // ks 1, rows half 0   (covers anext)
+        group(anext, bnext, 1);                  // ks 1, rows half 1
+        p ^= 1;
+    }
+}
+
 // ---- implicit-GEMM gather for a 3x3 / stride 1 / pad 1 convolution on NHWC fp16 activations ------------------------------
 // Row m of the GEMM is output pixel (b, y, x); K-tile t covers tap = (t*64) / Cin and input channels c0 = (t*64) % Cin
 // (Cin % 64 == 0; Cin = 8 / 16 / 32 take the per-chunk path of stage()), i.e. the 128 contiguous bytes x[b, y+dy-1, x+dx-1, c0 .. c0+63] — or 128 zero bytes outside the image,

@@ -269,6 +269,11 @@ _SPLITK = os.environ.get("PCLIP_GEMM_SPLITK", "0") == "1"
 _SPLITK_MAX_M = 4096
 
 
+def splitk_active(M: int) -> bool:
+    """True when ops.gemm would consider the split-K kernel for an M-row call (low-latency mode and a small M)."""
+    return _SPLITK and M <= _SPLITK_MAX_M
+
+
 class low_latency:
     """Context manager: inside it, ops.gemm uses pclip_gemm_splitk_f16 for the shapes pclip_gemm_splitk_workspace accepts."""
 

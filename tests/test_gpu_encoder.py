@@ -674,3 +674,28 @@ def test_clip_load_runs_on_gpu(tmp_path):
     assert model.encode_image(x[None]).shape == (1, TINY["embed_dim"])
     toks = pclip.tokenize(["a photo of a dog.", "itap of a tench."])        # ids beyond the tiny vocabulary are clamped by the embedding gather
     assert model.encode_text(toks.cuda()).shape == (2, TINY["embed_dim"])
+
+
+@pytest.mark.parametrize("M,N,K", [(50432, 768, 768), (197, 768, 3072), (8, 768, 768), (1024, 768, 3072), (3000, 512, 2048), (777, 1024, 64),
+                                   (20000, 1024, 256), (257, 100, 128)])
+def test_gemm_residual_epilogue_in_place(ops, M, N, K):
+    """`x += linear(a)` of a transformer block (clip/model.py:188-189) as the epilogue of the GEMM (persistent kernels incl. the row
+    split, the ring kernel for small M, the generic kernel for ragged N), with the output written over the residual operand:
+    bit-identical to the GEMM followed by a separate fp16 add, and to the fused add + LayerNorm pass it replaces."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = (torch.randn(M, K, device="cuda", generator=g) * 0.5).half()
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).half()
+    bias = (torch.randn(N, device="cuda", generator=g) * 0.1).half()
+    x = torch.randn(M, N, device="cuda", generator=g).half()
+    d = ops.gemm(a, w, bias)
+    ref = (x.float() + d.float()).half()
+    out = ops.gemm(a, w, bias, residual=x)                 # separate output
+    assert torch.equal(out, ref)
+    x2 = x.clone()
+    got = ops.gemm(a, w, bias, residual=x2, out=x2)        # in place
+    assert got.data_ptr() == x2.data_ptr() and torch.equal(x2, ref)
+    if N % 8 == 0:
+        gam, bet = 1 + 0.1 * torch.randn(N, device="cuda", generator=g), 0.1 * torch.randn(N, device="cuda", generator=g)
+        x3 = x.clone()
+        h_old = ops.add_layernorm(x3, d, gam, bet)         # the pass the fused epilogue replaces
+        assert torch.equal(x3, x2) and torch.equal(ops.layernorm(x2, gam, bet), h_old)
