@@ -7,6 +7,9 @@
 #include <type_traits>
 
 namespace {
+#ifndef PCLIP_PF
+#define PCLIP_PF false           // L2 prefetch two K-tiles ahead inside the persistent linear kernels: measured no gain, off
+#endif
 
 // ---- nn.Linear on MFMA ------------------------------------------------------------------------
 // Rounding points follow the reference's fp16 tensors: r16(acc + bias); QuickGELU as three fp16
@@ -46,6 +49,20 @@ __device__ __forceinline__ half4_t quick_gelu16x4(float4_t v) {
     return half4_t{y01[0], y01[1], y23[0], y23[1]};
 }
 
+// Output rows of the persistent linear kernels: non-temporal 16-byte stores (A/B switch PCLIP_NT_STORE) — a c_fc launch writes
+// 1.2 GB that nobody re-reads before it has left the 4 MiB L2 anyway; keeping it out leaves the L2 to the operand panels.
+#ifndef PCLIP_NT_STORE
+#define PCLIP_NT_STORE 1
+#endif
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_out(half_t* p, half8_t v) {
+#if PCLIP_NT_STORE
+    __builtin_nontemporal_store(__builtin_bit_cast(f32x4_t, v), reinterpret_cast<f32x4_t*>(p));
+#else
+    st_half8(p, v);
+#endif
+}
+
 // ---- fast kernel: N % BN == 0, 16-byte aligned C rows, no residual -----------------------------------------
 // Persistent: one launch = at most `slots` resident workgroups; each walks output tiles round by round
 // (round r covers tiles [r*G, (r+1)*G), XCD-remapped inside the round so that one XCD's L2 sees
@@ -72,6 +89,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     half_t* bias_lds = reinterpret_cast<half_t*>(smem + C::LDS_BYTES);       // [2][BN] fp16
     float* affine_lds = reinterpret_cast<float*>(smem + C::LDS_BYTES);       // ACT >= 2: [2][ scale BN | shift BN ] fp32
     constexpr bool AFFINE = ACT == 2 || ACT == 3 || ACT == 5;
+    constexpr int STRIP_BYTES = AFFINE ? 2 * 2 * C::BN * 4 : 2 * C::BN * 2;   // then 256 bytes of scrap for the L2 prefetch
     const int G = gridDim.x;
     int tile = pgemm::xcd_remap(blockIdx.x, G);
     if (tile >= ntiles) return;
@@ -136,7 +154,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             copy_bias(tile + G < ntiles ? tile + G : tile, parity ^ 1);
         }
         if (AFFINE) copy_affine(tile + G < ntiles ? tile + G : tile, parity ^ 1);
-        if (M16) pgemm::mainloop_bl<C, YOUNGER, !HAS_BIAS>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane);
+        if (M16) pgemm::mainloop_bl<C, YOUNGER, !HAS_BIAS, PCLIP_PF>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, smem + C::LDS_BYTES + STRIP_BYTES);
         else pgemm::mainloop<C, YOUNGER, !HAS_BIAS, M16>(A, lda, B, ldb, M, N, K, m0, n0, smem, acc, p, prev_full);
         const int next = tile + G;
         if (next < ntiles) {                                  // buffer p is free: prefetch the next tile's K-tile 0
@@ -190,15 +208,23 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             }
             return h;
         };
+#if (PCLIP_ABL & 4) && defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j) asm volatile("" ::"v"(acc.v[i][j]));
+        if (false)
+#else
         if (full)
+#endif
             pgemm::epilogue_f16<C, M16>(acc, stg, slab, pre, [&](int r, int, int pass, half8_t h) {
                 const size_t o = (size_t)(m0 + r) * ldc + col;
-                st_half8(Cout + o, RES ? add_res(pass, h) : h);
+                st_out(Cout + o, RES ? add_res(pass, h) : h);
             });
         else
             pgemm::epilogue_f16<C, M16>(acc, stg, slab, pre, [&](int r, int, int pass, half8_t h) {
                 const size_t o = (size_t)(m0 + r) * ldc + col;
-                if (m0 + r < M) st_half8(Cout + o, RES ? add_res(pass, h) : h);
+                if (m0 + r < M) st_out(Cout + o, RES ? add_res(pass, h) : h);
             });
         prev_full = full;
     }
@@ -340,7 +366,7 @@ template <class C, bool HAS_BIAS, int ACT, bool M16 = false>
 static int launch_fast2(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const LinearEpi& epi,
                         int slots, hipStream_t s) {
     static bool attr = false;
-    constexpr int LDS = C::LDS_BYTES + ((ACT == 2 || ACT == 3 || ACT == 5) ? 2 * 2 * C::BN * 4 : 2 * C::BN * 2);   // K-tile ring + double-buffered bias / affine strips
+    constexpr int LDS = C::LDS_BYTES + ((ACT == 2 || ACT == 3 || ACT == 5) ? 2 * 2 * C::BN * 4 : 2 * C::BN * 2) + 256;   // K-tile ring + double-buffered bias / affine strips + prefetch scrap
     if (!attr) {
         if (hipFuncSetAttribute((const void*)linear_fast_kernel<C, HAS_BIAS, ACT, M16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS) != hipSuccess) {

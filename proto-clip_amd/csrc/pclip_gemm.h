@@ -251,11 +251,13 @@ struct TileSrc {
             voff[i] = ((r < last ? r : last) * ld + c * 8) * 2;
         }
     }
+    // AUX: cache-policy bits of the buffer load (0 default, 2 = nt: streamed operand)
+    template <int AUX = 0>
     __device__ __forceinline__ void stage(int k_bytes, char* lds_tile, int wave) const {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
         for (int i = 0; i < NL; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(lds_tile + (wave * RPW + i * 8) * ROW_BYTES), 16, voff[i], k_bytes, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(lds_tile + (wave * RPW + i * 8) * ROW_BYTES), 16, voff[i], k_bytes, 0, AUX);
 #endif
     }
 };
@@ -264,22 +266,47 @@ template <class C>
 struct TilePair {
     TileSrc<C::BM, C::NWAVES> a;
     TileSrc<C::BN, C::NWAVES> b;
+    int pf_voff;                  // L2 prefetch (below): byte offset of this lane's row in the operand wave `wave` touches
+    bool pf_a;
     __device__ __forceinline__ void prepare(const half_t* __restrict__ A, int lda, const half_t* __restrict__ B, int ldb, int M, int N,
                                             int m0, int n0, int wave, int lane) {
         a.prepare(A, lda, m0, M, wave, lane);
         b.prepare(B, ldb, n0, N, wave, lane);
+        // wave u touches rows 64u .. 64u+63 of A, the waves after the A rows touch B's rows (leftover waves re-touch A)
+        constexpr int UA = C::BM / 64;
+        const int ub = wave - UA;
+        pf_a = !(ub >= 0 && ub * 64 < C::BN);
+        const int r = (pf_a ? (wave < UA ? wave : 0) : ub) * 64 + lane;
+        const int last = (pf_a ? M - 1 - m0 : N - 1 - n0);
+        pf_voff = (r < last ? r : last) * (pf_a ? lda : ldb) * 2;
+    }
+    // One 4-byte LDS-DMA per lane = one 128-byte line of K-tile t per row, dropped into a 256-byte LDS scrap area: its only purpose
+    // is to pull the lines of a LATER K-tile from HBM into L2 while the current one is multiplied, so that the real LDS-DMA of
+    // that K-tile (issued one K-tile ahead, all the LDS there is room for) finds them in L2.  Ablation (tools/ablate_gemm.py):
+    // the K-loop without MFMAs takes 80 % of the full kernel's time — every 64 KB batch contains activation rows nobody has
+    // touched before, and its slowest line is an HBM round trip.
+    __device__ __forceinline__ void prefetch(int t, char* scrap, int wave) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (pf_a) __builtin_amdgcn_raw_ptr_buffer_load_lds(a.rs, (lds_ptr_t)scrap, 4, pf_voff, t * (BK * 2), 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(b.rs, (lds_ptr_t)scrap, 4, pf_voff, t * (BK * 2), 0, 0);
+#endif
     }
     __device__ __forceinline__ void stage(int t, char* stage_buf, int wave) const {
-        a.stage(t * (BK * 2), stage_buf, wave);
-        b.stage(t * (BK * 2), stage_buf + C::A_BYTES, wave);
+#ifndef PCLIP_NT_A
+#define PCLIP_NT_A 0
+#endif
+        a.template stage<PCLIP_NT_A>(t * (BK * 2), stage_buf, wave);
+        b.template stage<0>(t * (BK * 2), stage_buf + C::A_BYTES, wave);
     }
 };
 
 // K-loop over a tile whose K-tile 0 is already on its way into buffer `p` (TilePair::stage(0, ..)); semantics of `p`, YOUNGER,
 // counted_first as mainloop_g.  `wave` must be wave-uniform (readfirstlane).
-template <class C, int YOUNGER = 0, bool ZERO_ACC = true>
+// PF: every iteration additionally issues TilePair::prefetch of K-tile t + 2 (clamped) into `scrap` right after the LDS-DMA of
+// K-tile t + 1; the wait at the top of the next iteration then leaves that one youngest operation in flight (vmcnt(1)).
+template <class C, int YOUNGER = 0, bool ZERO_ACC = true, bool PF = true>
 __device__ __forceinline__ void mainloop_bl(const TilePair<C>& tp, int nt, char* smem, Acc<C>& acc, int& p, bool counted_first, int wave,
-                                            int lane) {
+                                            int lane, char* scrap = nullptr) {
     static_assert(C::TM >= 2 && C::TM % 2 == 0, "group pipeline splits the wave's A rows in two halves");
     constexpr int HM = C::TM / 2;                                    // 32-row blocks per half
     const int wm = wave / C::WN, wn = wave % C::WN;
@@ -300,12 +327,22 @@ __device__ __forceinline__ void mainloop_bl(const TilePair<C>& tp, int nt, char*
     const bool late = C::NWAVES == 8 && wave >= 4;
 
     for (int t = 0; t < nt; ++t) {
-        if (t == 0 && counted_first) wait_vm<YOUNGER>(); else wait_vm<0>();
+        if (t == 0) { if (counted_first) wait_vm<YOUNGER>(); else wait_vm<0>(); }
+        else if (PF) wait_vm<1>();
+        else wait_vm<0>();
         lds_barrier();
         const char* base = smem + p * C::STAGE_BYTES;
         auto fa = [&](int ks, int i, int a) { return *reinterpret_cast<const half8_t*>(base + (offa ^ (ks << 6)) + (i * 32 + a * 16) * ROW_BYTES); };
         auto fb = [&](int ks, int j, int b) { return *reinterpret_cast<const half8_t*>(base + (offb ^ (ks << 6)) + (j * 32 + b * 16) * ROW_BYTES); };
-        auto stage_next = [&]() { if (t + 1 < nt) tp.stage(t + 1, smem + (p ^ 1) * C::STAGE_BYTES, wave); };
+#ifndef PCLIP_ABL
+#define PCLIP_ABL 0          // compile-time ablation builds (tools/gpu_ablate.sh): 1 no LDS-DMA in the K-loop, 2 no MFMAs, 4 no epilogue
+#endif
+        auto stage_next = [&]() {
+            if (t + 1 < nt && !(PCLIP_ABL & 1)) {
+                tp.stage(t + 1, smem + (p ^ 1) * C::STAGE_BYTES, wave);
+                if (PF) tp.prefetch(t + 2 < nt ? t + 2 : nt - 1, scrap, wave);
+            }
+        };
         half8_t bcur[C::TN][2], acur[HM][2], anext[HM][2], bnext[C::TN][2];
         auto load_a = [&](half8_t (&dst)[HM][2], int ks, int half) {
 #pragma unroll
@@ -320,6 +357,13 @@ __device__ __forceinline__ void mainloop_bl(const TilePair<C>& tp, int nt, char*
                 for (int b = 0; b < 2; ++b) dst[j][b] = fb(ks, j, b);
         };
         auto group = [&](const half8_t (&af)[HM][2], const half8_t (&bf)[C::TN][2], int half) {
+#if (PCLIP_ABL & 2) && defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (int i = 0; i < HM; ++i) { asm volatile("" ::"v"(af[i][0]), "v"(af[i][1])); }
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j) { asm volatile("" ::"v"(bf[j][0]), "v"(bf[j][1])); }
+            return;
+#endif
 #pragma unroll
             for (int i = 0; i < HM; ++i)
 #pragma unroll
