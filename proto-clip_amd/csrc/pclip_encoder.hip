@@ -7,6 +7,9 @@
 #include <type_traits>
 
 namespace {
+#ifndef PCLIP_SR
+#define PCLIP_SR 1               // K-loop with staggered refill of the buffer being consumed (pgemm::mainloop_sr); 0: mainloop_bl
+#endif
 #ifndef PCLIP_PF
 #define PCLIP_PF false           // L2 prefetch two K-tiles ahead inside the persistent linear kernels: measured no gain, off
 #endif
@@ -154,7 +157,11 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             copy_bias(tile + G < ntiles ? tile + G : tile, parity ^ 1);
         }
         if (AFFINE) copy_affine(tile + G < ntiles ? tile + G : tile, parity ^ 1);
+#if PCLIP_SR
+        if (M16) pgemm::mainloop_sr<C, YOUNGER, !HAS_BIAS>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane);
+#else
         if (M16) pgemm::mainloop_bl<C, YOUNGER, !HAS_BIAS, PCLIP_PF>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, smem + C::LDS_BYTES + STRIP_BYTES);
+#endif
         else pgemm::mainloop<C, YOUNGER, !HAS_BIAS, M16>(A, lda, B, ldb, M, N, K, m0, n0, smem, acc, p, prev_full);
         const int next = tile + G;
         if (next < ntiles) {                                  // buffer p is free: prefetch the next tile's K-tile 0

@@ -229,6 +229,9 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 struct rsrc_t { int w[4]; };                     // the host pass only parses the kernels; the descriptor type is device-only
 #endif
 
+#ifndef PCLIP_NT_A
+#define PCLIP_NT_A 0             // cache-policy bits of the A-operand LDS-DMA (2 = nt measured 7 % slower: every A line has 3 - 12 readers)
+#endif
 template <int ROWS, int NWAVES>
 struct TileSrc {
     static constexpr int RPW = ROWS / NWAVES, NL = RPW / 8;          // rows per wave, LDS-DMA pieces per wave and K-tile
@@ -292,9 +295,6 @@ struct TilePair {
 #endif
     }
     __device__ __forceinline__ void stage(int t, char* stage_buf, int wave) const {
-#ifndef PCLIP_NT_A
-#define PCLIP_NT_A 0
-#endif
         a.template stage<PCLIP_NT_A>(t * (BK * 2), stage_buf, wave);
         b.template stage<0>(t * (BK * 2), stage_buf + C::A_BYTES, wave);
     }
@@ -390,6 +390,99 @@ __device__ __forceinline__ void mainloop_bl(const TilePair<C>& tp, int nt, char*
         if (late) stage_next();
         load_a(anext, 1, 1);
         group(acur, bnext, 0);                   // ks 1, rows half 0   (covers anext)
+        group(anext, bnext, 1);                  // ks 1, rows half 1
+        p ^= 1;
+    }
+}
+
+// ---- staggered refill: the same K-loop with the LDS-DMA of K-tile t + 2 issued DURING iteration t --------------------------
+// tools/probe/dma_probe.hip: what bounds the operand delivery of a CU is the number of bytes it keeps in flight — a 64 KB
+// burst that is awaited before the next one is issued (mainloop_bl: buffer p ^ 1 is refilled at the top of iteration t) delivers
+// 1.2 - 1.4 us per K-tile at the bench's shapes, two 32 KB stages continuously in flight 0.9 - 1.2 us; touching the lines early
+// (L2 prefetch) does nothing.  There is no LDS for a third buffer, but the buffer being CONSUMED frees up in two steps: its B
+// half once every wave holds the k-step-1 B fragments in registers (before the third group of MFMAs), its A half once the last
+// A fragments are in (before the fourth).  Two extra LDS-only barriers mark those points and K-tile t + 2 is requested right
+// there — B first, then A — into the half that just became free, i.e. 1.3 - 1.6 iterations ahead of its use instead of 1.0, and
+// the requests of a K-tile are spread over the iteration instead of bursting at its top.  Per wave the iteration issues NB then
+// NA pieces, so the wait at the top of iteration t + 1 is the counted vmcnt(NA + NB): K-tile t + 1 (requested during t - 1) has
+// landed, K-tile t + 2 stays in flight.  Same fragment order as mainloop_bl: bit-identical results.
+template <class C, int YOUNGER = 0, bool ZERO_ACC = true>
+__device__ __forceinline__ void mainloop_sr(const TilePair<C>& tp, int nt, char* smem, Acc<C>& acc, int& p, bool counted_first, int wave,
+                                            int lane) {
+    static_assert(C::TM >= 2 && C::TM % 2 == 0, "group pipeline splits the wave's A rows in two halves");
+    constexpr int HM = C::TM / 2;
+    constexpr int NA = TileSrc<C::BM, C::NWAVES>::NL, NB = TileSrc<C::BN, C::NWAVES>::NL;
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    if (ZERO_ACC) {
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc.v[i][j][e] = 0.f;
+    }
+    const int key = (lane & 15) >> 1, q = lane >> 4;
+    const int col0 = (q ^ key) << 4;
+    const int offa = (wm * (C::BM / C::WM) + (lane & 15)) * ROW_BYTES + col0;
+    const int offb = C::A_BYTES + (wn * (C::BN / C::WN) + (lane & 15)) * ROW_BYTES + col0;
+
+    for (int t = 0; t < nt; ++t) {
+        if (t == 0) { if (counted_first) wait_vm<YOUNGER>(); else wait_vm<0>(); }
+        else if (t + 1 < nt) wait_vm<NA + NB>();
+        else wait_vm<0>();
+        lds_barrier();
+        char* cur = smem + p * C::STAGE_BYTES;
+        const char* base = cur;
+        auto fa = [&](int ks, int i, int a) { return *reinterpret_cast<const half8_t*>(base + (offa ^ (ks << 6)) + (i * 32 + a * 16) * ROW_BYTES); };
+        auto fb = [&](int ks, int j, int b) { return *reinterpret_cast<const half8_t*>(base + (offb ^ (ks << 6)) + (j * 32 + b * 16) * ROW_BYTES); };
+        half8_t bcur[C::TN][2], acur[HM][2], anext[HM][2], bnext[C::TN][2];
+        auto load_a = [&](half8_t (&dst)[HM][2], int ks, int half) {
+#pragma unroll
+            for (int i = 0; i < HM; ++i)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) dst[i][a] = fa(ks, half * HM + i, a);
+        };
+        auto load_b = [&](half8_t (&dst)[C::TN][2], int ks) {
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) dst[j][b] = fb(ks, j, b);
+        };
+        auto group = [&](const half8_t (&af)[HM][2], const half8_t (&bf)[C::TN][2], int half) {
+#pragma unroll
+            for (int i = 0; i < HM; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            float16_t& dst = acc.v[half * HM + i][j];
+                            float4_t c = {dst[(a * 2 + b) * 4], dst[(a * 2 + b) * 4 + 1], dst[(a * 2 + b) * 4 + 2], dst[(a * 2 + b) * 4 + 3]};
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][b], af[i][a], c, 0, 0, 0);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) dst[(a * 2 + b) * 4 + r] = c[r];
+                        }
+        };
+        const bool refill = t + 2 < nt;                               // workgroup-uniform
+        load_b(bcur, 0);
+        load_a(acur, 0, 0);
+        if (t == 0 && nt > 1) tp.stage(1, smem + (p ^ 1) * C::STAGE_BYTES, wave);   // the other buffer was the previous tile's epilogue staging area until the barrier above
+        load_a(anext, 0, 1);
+        group(acur, bcur, 0);                    // ks 0, rows half 0
+        load_b(bnext, 1);
+        load_a(acur, 1, 0);
+        group(anext, bcur, 1);                   // ks 0, rows half 1
+        if (refill) {
+            lds_barrier();                       // every wave holds its last B fragments of this K-tile: the B half of `cur` is free
+            tp.b.template stage<0>((t + 2) * (BK * 2), cur + C::A_BYTES, wave);
+        }
+        load_a(anext, 1, 1);
+        group(acur, bnext, 0);                   // ks 1, rows half 0
+        if (refill) {
+            lds_barrier();                       // ... and its last A fragments: the A half is free
+            tp.a.template stage<PCLIP_NT_A>((t + 2) * (BK * 2), cur, wave);
+        }
         group(anext, bnext, 1);                  // ks 1, rows half 1
         p ^= 1;
     }

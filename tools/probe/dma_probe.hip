@@ -19,6 +19,8 @@ __global__ __launch_bounds__(512, 2) void probe(const half_t* __restrict__ A, co
                                                 int ntiles, int* sink, int mode) {
 #if defined(__HIP_DEVICE_COMPILE__)      // device-only builtins: the host pass must see an empty body or it drops the stub
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const bool pf = mode & 8;
+    mode &= 7;
     constexpr int ROWB = BKS * 2, RPP = 1024 / ROWB, STAGE = 512 * ROWB, PER = 512 / RPP / 8;   // pieces per wave per stage
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int G = gridDim.x, nt = K / BKS;
@@ -61,16 +63,24 @@ __global__ __launch_bounds__(512, 2) void probe(const half_t* __restrict__ A, co
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(isb ? rs[1] : rs[0], (lds_ptr_t)(smem + slot * STAGE + (wave * PER + j) * 1024), 16, voff[j], t * ROWB, 0, 0);
             }
         };
+        // pf: each lane touches one 128-byte line (row = wave*64 + lane of the 512-row K-tile) of K-tile t + NS with a 4-byte LDS-DMA
+        const int prow = wave * 64 + lane;
+        const int pvoff = ((prow & 255) * K) * 2;
+        const bool pb = prow >= 256;
+        auto touch = [&](int t) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(pb ? rs[1] : rs[0], (lds_ptr_t)(smem + NS * STAGE), 4, pvoff, (t < nt ? t : nt - 1) * ROWB, 0, 0);
+        };
         for (int t = 0; t < NS - 1 && t < nt; ++t) stage(t, t);
         int slot = 0, fill = NS - 1;
         for (int t = 0; t < nt; ++t) {
             const int ahead = nt - 1 - t;
-            if (NS >= 5 && ahead >= 3) wait_vm<3 * PER>();
+            if (pf && NS == 2 && t > 0) wait_vm<1>();
+            else if (NS >= 5 && ahead >= 3) wait_vm<3 * PER>();
             else if (NS >= 4 && ahead >= 2) wait_vm<2 * PER>();
             else if (NS >= 3 && ahead >= 1) wait_vm<PER>();
             else wait_vm<0>();
             lds_barrier();
-            if (t + NS - 1 < nt) stage(t + NS - 1, fill);
+            if (t + NS - 1 < nt) { stage(t + NS - 1, fill); if (pf && NS == 2) touch(t + 2); }
             fill = slot;
             cnt += smem[slot * STAGE + threadIdx.x * 16];
             slot = slot + 1 == NS ? 0 : slot + 1;
@@ -84,7 +94,7 @@ __global__ __launch_bounds__(512, 2) void probe(const half_t* __restrict__ A, co
 template <int BKS, int NS>
 void run(const half_t* A, const half_t* B, int M, int N, int K, int* sink, const char* name, int mode) {
     const int tiles_m = (M + 255) / 256, tiles_n = N / 256, ntiles = tiles_m * tiles_n;
-    const int lds = NS * 512 * BKS * 2;
+    const int lds = NS * 512 * BKS * 2 + 256;
     hipFuncSetAttribute((const void*)probe<BKS, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -186,7 +196,9 @@ int main() {
     hipMalloc(&A, (size_t)M * KMAX * 2); hipMalloc(&B, (size_t)NMAX * KMAX * 2); hipMalloc(&sink, 4);
     hipMemset(A, 0, (size_t)M * KMAX * 2); hipMemset(B, 0, (size_t)NMAX * KMAX * 2);
     for (auto [n, k] : std::vector<std::pair<int, int>>{{3072, 768}, {768, 768}, {768, 3072}}) {
-        for (int mode = 1; mode < 3; ++mode) {
+        run<64, 2>(A, B, M, n, k, sink, "BK64 x 2 slots", 1);
+        run<64, 2>(A, B, M, n, k, sink, "BK64 x 2 + L2 touch", 9);
+        for (int mode = 1; mode < 1; ++mode) {
             run<64, 2>(A, B, M, n, k, sink, "BK64 x 2 slots", mode);
             run_rows<256, 2>(A, B, M, n, k, sink, mode);
             run_rows<256, 3>(A, B, M, n, k, sink, mode);
