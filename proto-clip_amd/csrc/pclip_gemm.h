@@ -406,6 +406,9 @@ __device__ __forceinline__ void mainloop_bl(const TilePair<C>& tp, int nt, char*
 // the requests of a K-tile are spread over the iteration instead of bursting at its top.  Per wave the iteration issues NB then
 // NA pieces, so the wait at the top of iteration t + 1 is the counted vmcnt(NA + NB): K-tile t + 1 (requested during t - 1) has
 // landed, K-tile t + 2 stays in flight.  Same fragment order as mainloop_bl: bit-identical results.
+// Measured alternatives (same-process A/B, tools/ab_lib.py): ONE mid-iteration barrier with both halves requested at 75 % is
+// 4 - 8 % slower (the spread of the requests matters more than the barrier); reading every fragment earlier so that the halves
+// free up at 25 % / 50 % spills (72 B of scratch) and is 1 - 6 % slower.
 template <class C, int YOUNGER = 0, bool ZERO_ACC = true>
 __device__ __forceinline__ void mainloop_sr(const TilePair<C>& tp, int nt, char* smem, Acc<C>& acc, int& p, bool counted_first, int wave,
                                             int lane) {

@@ -129,7 +129,16 @@ __global__ __launch_bounds__(512, 2) void probe_rows(const half_t* __restrict__ 
         if (mode == 1) tile = base + xcd * q + idx;
         if (mode == 2) tile = 0;
         if (tile >= ntiles) break;
-        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        if (mode >= 5) {
+            // column groups: ng = mode - 3 (mode 5: 2 groups, 6: 3 - uneven XCD split not handled, 7: 4 groups); XCD x works on group x % ng,
+            // the XCDs of a group walk its (tm, local tn) sequence 32 tiles at a time
+            const int ng = mode == 5 ? 2 : 4, cg = tiles_n / ng, per = 8 / ng;
+            const int grp = xcd % ng, xi = xcd / ng;
+            const int s = ((base / G) * per + xi) * q + idx;
+            tm = s / cg; tn = grp * cg + s % cg;
+            if (tm * 256 >= M) continue;
+        }
         __amdgpu_buffer_rsrc_t rs[2];
         rs[0] = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)tm * 256 * K), 0, 0x7fffffff, 0x00020000);
         rs[1] = __builtin_amdgcn_make_buffer_rsrc((void*)(B + (size_t)tn * 256 * K), 0, 0x7fffffff, 0x00020000);
@@ -195,9 +204,10 @@ int main() {
     half_t *A, *B; int* sink;
     hipMalloc(&A, (size_t)M * KMAX * 2); hipMalloc(&B, (size_t)NMAX * KMAX * 2); hipMalloc(&sink, 4);
     hipMemset(A, 0, (size_t)M * KMAX * 2); hipMemset(B, 0, (size_t)NMAX * KMAX * 2);
-    for (auto [n, k] : std::vector<std::pair<int, int>>{{3072, 768}, {768, 768}, {768, 3072}}) {
-        run<64, 2>(A, B, M, n, k, sink, "BK64 x 2 slots", 1);
-        run<64, 2>(A, B, M, n, k, sink, "BK64 x 2 + L2 touch", 9);
+    for (auto [n, k] : std::vector<std::pair<int, int>>{{3072, 768}, {2048, 768}, {1024,768}, {1024, 3072}}) {
+        run_rows<256, 3>(A, B, M, n, k, sink, 1);
+        if (n % 512 == 0) run_rows<256, 3>(A, B, M, n, k, sink, 5);
+        if (n % 1024 == 0) run_rows<256, 3>(A, B, M, n, k, sink, 7);
         for (int mode = 1; mode < 1; ++mode) {
             run<64, 2>(A, B, M, n, k, sink, "BK64 x 2 slots", mode);
             run_rows<256, 2>(A, B, M, n, k, sink, mode);
