@@ -123,6 +123,13 @@ int pclip_adapter_fc_f16(const void* x, int B, int D, int H, const void* w1, con
                          int l2norm_out, void* y, float* y_sq, void* ws, size_t ws_bytes,
                          pclip_stream_t stream);
 
+/* The last stage of Adapter_FC.forward on its own (model.py:88, 92-95): y = r16(r16(ratio * LN_D(h)) + r16((1-ratio) * x))
+ * with fp16 LayerNorm parameters — the training step launches the stages one by one to keep their activations
+ * (proto_clip_amd/train.py) and must end with exactly the arithmetic of pclip_adapter_fc_f16.  h, x, y [R, D] fp16. */
+int pclip_layernorm_blend_f16(const void* h, const void* gamma, const void* beta, float eps, const void* x, float ratio,
+                              float one_minus_ratio, int l2norm_out, void* y, float* y_sq, int R, int D,
+                              pclip_stream_t stream);
+
 /* Adapter.forward (model.py:49-78), width 16: pad D -> s*s, conv1 1x1 -> LN[16,s,s] ->
  * (three_x: conv2 3x3 pad 1 -> LN[16,s,s]) -> conv3 1x1 -> LN[1,s,s] -> +identity -> crop.  No ReLU.
  * conv1 [16], ln1w/ln1b [16*s*s], conv2 [16*16*3*3], ln2w/ln2b [16*s*s], conv3 [16], ln3w/ln3b [s*s]. */

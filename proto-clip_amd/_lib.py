@@ -41,6 +41,7 @@ _SIGS = {
     "pclip_hp_sweep": [_P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, _P],
     "pclip_adapter_fc_f16": [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P, _P,
                              c_size_t, _P],
+    "pclip_layernorm_blend_f16": [_P, _P, _P, c_float, _P, c_float, c_float, c_int, _P, _P, c_int, c_int, _P],
     "pclip_adapter_conv_f16": [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P],
     "pclip_gemm_f16": [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P],
     "pclip_gemm_splitk_workspace": [c_int, c_int, c_int],
@@ -115,13 +116,27 @@ def ptr(t):
 
 
 def stream():
+    """The current stream of the CURRENT device; `require_cuda` has checked that the operands live there."""
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def require_cuda(*tensors):
+    """Operands must be device tensors, all on one GPU, and that GPU must be the current device: the kernels are launched on the
+    current device's stream (one process per GPU is the deployment model; a bank on another GPU would otherwise be a silent peer
+    access or a fault).  `with torch.cuda.device(x.device):` around the call is the way to drive a second GPU from one process."""
+    dev = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise PclipError("libpclip operates on device tensors only (got a CPU tensor); there is no CPU fallback")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise PclipError(f"operands on different GPUs ({dev} and {t.device}): move them to one device")
+    if dev is not None and dev.index != torch.cuda.current_device():
+        raise PclipError(f"operands live on {dev} but the current device is cuda:{torch.cuda.current_device()}: call "
+                         f"torch.cuda.set_device({dev.index}) or wrap the call in `with torch.cuda.device({dev.index}):`")
 
 
 def workspace_bytes(op: int, Q: int, N: int, D: int) -> int:

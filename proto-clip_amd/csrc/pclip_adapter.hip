@@ -485,14 +485,14 @@ extern "C" int pclip_adapter_conv_backward_f16(const void* x, const void* g, int
     const int s2 = s * s, hp = (s + 2) * (s + 2);
     const size_t lds = (size_t)(1024 + 1024 + 4 + 64) * 4 + (three_x ? (size_t)2 * 8 * hp * 4 + (size_t)CW * s2 * 2 + (size_t)2 * 8 * 9 * CW * 4 : 0);
     hipStream_t st = (hipStream_t)stream;
-    static bool attr[2] = {false, false};
+    static DevOnce attr[2];
     if (three_x) {
-        if (!attr[1]) {
+        if (!attr[1].done()) {
             if (hipFuncSetAttribute((const void*)adapter_conv_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 pclip_set_error("pclip_adapter_conv_backward_f16: cannot raise the dynamic LDS limit");
                 return PCLIP_E_LAUNCH;
             }
-            attr[1] = true;
+            attr[1].set();
         }
         adapter_conv_backward_kernel<true><<<B, 256, lds, st>>>((const half_t*)x, (const half_t*)g, D, s, (const half_t*)conv1, (const half_t*)ln1w,
             (const half_t*)ln1b, (const half_t*)conv2, (const half_t*)ln2w, (const half_t*)ln2b, (const half_t*)conv3, (const half_t*)ln3w,
@@ -530,6 +530,14 @@ extern "C" int pclip_adapter_fc_f16(const void* x, int B, int D, int H, const vo
     return pclip_layernorm_f16p(h2, g2, b2, 1e-5f, y, B, D, x, ratio, one_minus_ratio, l2norm_out, y_sq, s);   // fc.3 + blend
 }
 
+extern "C" int pclip_layernorm_blend_f16(const void* h, const void* gamma, const void* beta, float eps, const void* x, float ratio,
+                                         float one_minus_ratio, int l2norm_out, void* y, float* y_sq, int R, int D,
+                                         pclip_stream_t stream) {
+    PCLIP_REQUIRE(h && gamma && beta && x && y, "pclip_layernorm_blend_f16: null pointer");
+    PCLIP_REQUIRE(R >= 0 && D > 0 && D % 8 == 0 && D <= 4096, "pclip_layernorm_blend_f16: bad shape R=%d D=%d", R, D);
+    return pclip_layernorm_f16p(h, gamma, beta, eps, y, R, D, x, ratio, one_minus_ratio, l2norm_out, y_sq, (hipStream_t)stream);
+}
+
 extern "C" int pclip_adapter_conv_f16(const void* x, int B, int D, int three_x, const void* conv1, const void* ln1w,
                                       const void* ln1b, const void* conv2, const void* ln2w, const void* ln2b,
                                       const void* conv3, const void* ln3w, const void* ln3b, int l2norm_out, void* y,
@@ -545,10 +553,10 @@ extern "C" int pclip_adapter_conv_f16(const void* x, int B, int D, int three_x, 
     if (three_x) lds += (size_t)8 * hp * 4 + (size_t)CW * s2 * 2 + 8 * 9 * CW * 4;
     hipStream_t st = (hipStream_t)stream;
     if (three_x) {
-        static bool attr = false;
-        if (!attr) {
+        static DevOnce attr;
+        if (!attr.done()) {
             (void)hipFuncSetAttribute((const void*)adapter_conv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            attr = true;
+            attr.set();
         }
         adapter_conv_kernel<true><<<B, 256, lds, st>>>((const half_t*)x, D, s, (const half_t*)conv1, (const half_t*)ln1w,
                                                        (const half_t*)ln1b, (const half_t*)conv2, (const half_t*)ln2w,

@@ -587,13 +587,13 @@ template <int NT, bool TWO>
 int launch_classify_small(const void* q, const void* zi, const void* zt, int Q, int N, int D, float alpha, float oma, float beta,
                           float* p, int32_t* argmax, float* topk_p, int32_t* topk_i, int k, int cus, hipStream_t s) {
     const size_t lds = (size_t)(TWO ? 2 : 1) * NT * 16 * (D * 2 + 16);
-    static bool attr = false;
-    if (!attr) {
+    static DevOnce attr;
+    if (!attr.done()) {
         if (hipFuncSetAttribute((const void*)classify_small_kernel<NT, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             pclip_set_error("pclip_classify_f16: cannot raise the dynamic LDS limit");
             return PCLIP_E_LAUNCH;
         }
-        attr = true;
+        attr.set();
     }
     const int ngroups = ceil_div(Q, 16);
     int wg_per_cu = (int)((size_t)160 * 1024 / lds);
@@ -678,13 +678,13 @@ extern "C" int pclip_sqdist_f16(const void* q, const void* zi, const void* zt, i
             big_ok = e ? atoi(e) : 1;
         }
         if (big_ok && ntiles >= 3 * cus && D >= 128 && Q % 4 == 0 && N % 4 == 0 && Q >= 4 && N >= 4) {
-            static bool attr = false;
-            if (!attr) {
+            static DevOnce attr;
+            if (!attr.done()) {
                 if (hipFuncSetAttribute((const void*)sqdist_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CB::LDS_BYTES + 4096) != hipSuccess) {
                     pclip_set_error("pclip_sqdist_f16: cannot raise the dynamic LDS limit to %d", CB::LDS_BYTES + 4096);
                     return PCLIP_E_LAUNCH;
                 }
-                attr = true;
+                attr.set();
             }
             sqdist_big_kernel<<<ntiles < cus ? ntiles : cus, 512, CB::LDS_BYTES + 4096, s>>>((const half_t*)q, (const half_t*)zi, (const half_t*)zt, Q, N, D,
                                                                                     q_sq, zi_sq, zt_sq, d2i, d2t, ldd, tn, per_bank, ntiles);

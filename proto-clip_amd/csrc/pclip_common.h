@@ -57,5 +57,14 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
 __device__ __forceinline__ half8_t ld_half8(const half_t* p) { return *reinterpret_cast<const half8_t*>(p); }
 __device__ __forceinline__ void st_half8(half_t* p, half8_t v) { *reinterpret_cast<half8_t*>(p) = v; }
 
+// One-shot flags for per-DEVICE state (hipFuncSetAttribute applies to the current device only): a bit per device id, so a process
+// that drives several GPUs raises the LDS limit on each of them.
+struct DevOnce {
+    unsigned long long mask = 0;
+    static unsigned long long bit() { int d = 0; (void)hipGetDevice(&d); return 1ull << (d & 63); }
+    bool done() const { return (mask & bit()) != 0; }
+    void set() { mask |= bit(); }
+};
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -372,15 +372,15 @@ using CfgSmall = pgemm::CfgSmall;
 template <class C, bool HAS_BIAS, int ACT, bool M16 = false>
 static int launch_fast2(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const LinearEpi& epi,
                         int slots, hipStream_t s) {
-    static bool attr = false;
+    static DevOnce attr;
     constexpr int LDS = C::LDS_BYTES + ((ACT == 2 || ACT == 3 || ACT == 5) ? 2 * 2 * C::BN * 4 : 2 * C::BN * 2) + 256;   // K-tile ring + double-buffered bias / affine strips + prefetch scrap
-    if (!attr) {
+    if (!attr.done()) {
         if (hipFuncSetAttribute((const void*)linear_fast_kernel<C, HAS_BIAS, ACT, M16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS) != hipSuccess) {
             pclip_set_error("pclip_gemm_f16: cannot raise the dynamic LDS limit to %d", LDS);
             return PCLIP_E_LAUNCH;
         }
-        attr = true;
+        attr.set();
     }
     const int tiles_m = ceil_div(M, C::BM), tiles_n = N / C::BN, ntiles = tiles_m * tiles_n;
     const int grid = ntiles < slots ? ntiles : slots;
@@ -1197,8 +1197,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 inline int small_attr() {
-    static bool done = false;
-    if (!done) {
+    static DevOnce done;
+    if (!done.done()) {
         const void* fns[] = {(const void*)linear_small_kernel<0>, (const void*)linear_small_kernel<1>, (const void*)linear_small_kernel<2>,
                              (const void*)linear_small_kernel<3>, (const void*)linear_small_kernel<5>, (const void*)linear_small_kernel<6>, (const void*)conv3x3_small_kernel<2>, (const void*)conv3x3_small_kernel<3>};
         for (const void* f : fns)
@@ -1206,7 +1206,7 @@ inline int small_attr() {
                 pclip_set_error("gemm_f16 (small M): cannot raise the dynamic LDS limit to %d", kSmallLds);
                 return PCLIP_E_LAUNCH;
             }
-        done = true;
+        done.set();
     }
     return PCLIP_OK;
 }
@@ -1317,14 +1317,14 @@ namespace {
 template <class C, int ACT>
 int launch_conv2(const void* x, const void* zero, const void* w, int B, int H, int W, int Cin, int Cout, const float* scale,
                  const float* shift, void* y, int slots, hipStream_t s) {
-    static bool attr = false;
+    static DevOnce attr;
     constexpr int LDS = C::LDS_BYTES + 2 * 2 * C::BN * 4;
-    if (!attr) {
+    if (!attr.done()) {
         if (hipFuncSetAttribute((const void*)conv3x3_fast_kernel<C, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
             pclip_set_error("pclip_conv3x3_bn_f16: cannot raise the dynamic LDS limit to %d", LDS);
             return PCLIP_E_LAUNCH;
         }
-        attr = true;
+        attr.set();
     }
     const int M = B * H * W, tiles_m = ceil_div(M, C::BM), tiles_n = Cout / C::BN, ntiles = tiles_m * tiles_n;
     conv3x3_fast_kernel<C, ACT><<<ntiles < slots ? ntiles : slots, C::NTHREADS, LDS, s>>>(
@@ -1434,14 +1434,14 @@ extern "C" int pclip_attention_q_f16(const void* q, int ldq, long q_batch_stride
     const int NT = ceil_div(L, 32), LP = NT * 32;
     const int LV = 0;                                       // (unused: V is kept row-major now)
     const size_t lds = 2 * (size_t)LP * ATT_DH * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DevOnce attr_set;
+    if (!attr_set.done()) {
         (void)hipFuncSetAttribute((const void*)attention_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (hipFuncSetAttribute((const void*)attention_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) {
             pclip_set_error("pclip_attention_f16: cannot raise the dynamic LDS limit");
             return PCLIP_E_LAUNCH;
         }
-        attr_set = true;
+        attr_set.set();
     }
     // more than four query tiles (ViT-B/16: 7, ViT-L/14: 9): eight waves, one tile each, two workgroups = four waves per SIMD
     // (VGPRs capped at 128); measured 438 -> 424 us (ViT-B/16), 224 -> 200 us (ViT-L/14), bit-identical.  Short sequences

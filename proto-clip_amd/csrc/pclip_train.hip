@@ -579,13 +579,13 @@ extern "C" int pclip_proto_backward_f16(const void* mem, const float* g, int N, 
     if (N == 0) return PCLIP_OK;
     const size_t base = 4 * (size_t)(D + 32) * sizeof(float), with_rows = 4 * ((size_t)(D + 32) + ((size_t)K * D + 1) / 2) * sizeof(float);
     if (K > 1 && D % 8 == 0 && with_rows <= 150 * 1024) {
-        static bool attr = false;
-        if (!attr) {
+        static DevOnce attr;
+        if (!attr.done()) {
             if (hipFuncSetAttribute((const void*)proto_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
                 pclip_set_error("pclip_proto_backward_f16: cannot raise the dynamic LDS limit");
                 return PCLIP_E_LAUNCH;
             }
-            attr = true;
+            attr.set();
         }
         proto_backward_kernel<true><<<row_grid(N, 8192), 256, with_rows, (hipStream_t)stream>>>((const half_t*)mem, g, N, K, D, per_shot_norm,
                                                                                            final_norm, (half_t*)dmem);

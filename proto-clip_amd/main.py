@@ -1,11 +1,13 @@
 """Experiment driver with the reference's CLI and `run_proto_clip` signature (reference main.py:24-102,
-105-465, 474-548), restricted to the hot path this build accelerates: memory-bank construction,
-zero-shot (alpha, beta) search, and the test pass over saved banks/adapters.  The episodic training loop
-(main.py:216-381) is SURVEY §8(f) item 3 and is not built; `only_test: True` configs run end to end.
+105-465, 474-548): memory-bank construction, zero-shot (alpha, beta) search, the episodic training loop
+(main.py:216-381 -> `train_proto_clip` / proto_clip_amd.train.ProtoClipTrainer; main.qt.py through main_qt.run_proto_clip)
+and the test pass over saved banks / adapters.  `only_test: True` configs skip training as in the reference.
 
 Differences by design: the 957 `P` calls + `.item()` syncs of each grid search (main.py:187-199, 419-430)
 become three distance GEMMs + three sweep kernels; results (the three [319, 3] arrays, their pickle
-files, the selected (alpha, beta)) are the reference's."""
+files, the selected (alpha, beta)) are the reference's.  One CLI difference (also listed in INTEGRATION.md):
+`populate_cfg_using_args` copies --only_test and --train_vis_memory_only into cfg when they are given; the reference parses
+them and then ignores them (its yaml decides)."""
 import argparse
 import os
 import random

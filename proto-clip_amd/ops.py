@@ -14,13 +14,29 @@ _ws_cache = {}
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only per-(device, stream) scratch buffer (the C ABI never allocates)."""
+    """Scratch for one call (the C ABI never allocates).  Outside graph capture: a grow-only buffer per (device, stream) — calls
+    on one stream are ordered, so they can share it.  During a hipGraph capture nothing is cached: the buffer comes from the
+    capture's private memory pool and must belong to THAT graph only (a cached pointer would be baked into later captures whose
+    pool does not own it); torch's caching allocator reuses the block between the calls of one capture."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
+
+
+def evict_workspace(stream_obj):
+    """Forget the scratch buffer cached for `stream_obj` (a torch.cuda.Stream that will not be used again)."""
+    for key in [k for k in _ws_cache if k[1] == stream_obj.cuda_stream]:
+        del _ws_cache[key]
+
+
+def release_workspaces():
+    """Drop the cached scratch buffers (e.g. after a warm-up on a side stream that will not be used again)."""
+    _ws_cache.clear()
 
 
 def _f16c(t: torch.Tensor) -> torch.Tensor:
@@ -222,6 +238,18 @@ def adapter_fc(x, w1, g1, b1, w2, g2, b2, ratio: float = 0.2, l2norm_out: bool =
                                            int(l2norm_out), ptr(y), ptr(sq), ptr(ws), ws.numel(), stream()),
           "pclip_adapter_fc_f16")
     return (y, sq) if want_sq else y
+
+
+def layernorm_blend(h, gamma, beta, x, ratio: float = 0.2, l2norm_out: bool = False, eps: float = 1e-5):
+    """r16(r16(ratio * LN(h)) + r16((1 - ratio) * x)) — the last stage of Adapter_FC.forward (model.py:92-95) on its own."""
+    require_cuda(h, gamma, beta, x)
+    h, x = _f16c(h), _f16c(x)
+    R, D = h.shape
+    y = torch.empty_like(h)
+    r32, omr32 = float(np.float32(ratio)), float(np.float32(1 - ratio))
+    check(_lib.load().pclip_layernorm_blend_f16(ptr(h), ptr(_f16c(gamma)), ptr(_f16c(beta)), eps, ptr(x), r32, omr32, int(l2norm_out),
+                                                ptr(y), None, R, D, stream()), "pclip_layernorm_blend_f16")
+    return y
 
 
 def adapter_conv(x, three_x: bool, conv1, ln1w, ln1b, conv2, ln2w, ln2b, conv3, ln3w, ln3b,

@@ -94,6 +94,7 @@ class ProtoClipClassifier:
                 self._forward(static_in)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        ops.evict_workspace(side)                          # the warm-up stream's scratch buffer is not needed again
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             tp, ti = self._forward(static_in)

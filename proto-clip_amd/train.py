@@ -53,11 +53,16 @@ def cosine_lr(base_lr: float, epoch: int, t_max: int, eta_min: float = 0.0) -> f
 
 # ---------------------------------------------------------------- adapters with saved activations -------------
 def _fc_forward(ad: Adapter_FC, x):
+    """Adapter_FC forward with the activations the backward needs.  The stages are launched one by one (the fused
+    pclip_adapter_fc_f16 keeps them in scratch) with the UNSPLIT GEMM — `ops.low_latency()` must not change which kernel
+    produced the saved h1 / h2 — and the output is formed from exactly those tensors: Linear -> LN -> Linear -> LN, then
+    r16(r16(0.2 * h) + r16(0.8 * x)) (model.py:91-95), the blend riding on the second LayerNorm."""
     fc = ad.fc
-    h1 = ops.gemm(x, fc[0].weight)                                             # Linear, no bias (model.py:85)
-    a1 = ops.layernorm(h1, fc[1].weight.float(), fc[1].bias.float())
-    h2 = ops.gemm(a1, fc[2].weight)
-    out = ops.adapter_fc(x, fc[0].weight, fc[1].weight, fc[1].bias, fc[2].weight, fc[3].weight, fc[3].bias, ratio=0.2)
+    with ops.low_latency(False):
+        h1 = ops.gemm(x, fc[0].weight)                                         # Linear, no bias (model.py:85)
+        a1 = ops.layernorm(h1, fc[1].weight.float(), fc[1].bias.float())
+        h2 = ops.gemm(a1, fc[2].weight)
+    out = ops.layernorm_blend(h2, fc[3].weight, fc[3].bias, x, ratio=0.2)
     return out, (x, h1, a1, h2)
 
 

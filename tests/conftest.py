@@ -104,11 +104,14 @@ def assert_adapter_close(y16, ref16, tag="adapter"):
     assert v_elem < b_elem, v_elem
 
 
-# (row relative L2 max, row relative L2 mean, worst element as a fraction of the row rms)
-ADAPTER_BOUNDS = (1e-2, 1e-3, 0.05)
-# post-adapter (alpha, beta) grids: (max queries of difference at any grid point, mean queries of difference)
-GRID_BOUNDS = (3.0, 0.5)
-# adapter-free grids: (max queries of difference at any grid point, fraction of grid points that differ at all)
+# Bounds = at most 2x the largest value observed on MI355X (profiles/r02_observed_tolerances.json; round 1 had 1e-2 / 1e-3 / 0.05,
+# 3 / 0.5 queries).  The worst adapter case is conv-2x against the reference's own rows (C6: conv3's output has a tiny variance,
+# so one 1-ulp flip upstream moves a whole row by 2.4e-3); against the oracle the GPU rows agree to 3e-4.
+# (row relative L2 max, row relative L2 mean, worst element as a fraction of the row rms) — observed 2.44e-3 / 2.5e-4 / 1.9e-2
+ADAPTER_BOUNDS = (5e-3, 5e-4, 0.04)
+# post-adapter (alpha, beta) grids: (max queries of difference at any grid point, mean queries) — observed 2 / 0.094
+GRID_BOUNDS = (3.0, 0.2)
+# adapter-free grids: (max queries of difference at any grid point, fraction of grid points that differ at all) — observed 1 / 0.0125
 GRID_EXACT_BOUNDS = (1.0, 0.02)
 
 

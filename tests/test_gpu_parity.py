@@ -290,8 +290,8 @@ def test_run_proto_clip_test_pass(ops, name, tmp_path, monkeypatch):
     for s in ("val", "test", "train"):
         assert_grid_close(out["zero_shot"][s][:, 2], g["zs_" + s][:, 2], n[s], exact=True, tag=f"run_proto_clip zero-shot grid {name}")
         assert_grid_close(out["test"][s][:, 2], g["test_" + s][:, 2], n[s], tag=f"run_proto_clip test grid {name} [{cfg['adapter']}]")
-    dq = observe(f"run_proto_clip fixed-(alpha,beta) accuracy {name}: queries differing", abs(out["test"]["fixed_acc"] - float(g["fixed_acc"])) * n["test"], 1.0)
-    assert dq <= 1.0 + 1e-6
+    dq = observe(f"run_proto_clip fixed-(alpha,beta) accuracy {name}: queries differing", abs(out["test"]["fixed_acc"] - float(g["fixed_acc"])) * n["test"], 0.5)
+    assert dq <= 0.5            # observed: identical on all five configurations (round 1 allowed one query)
     # the pickles the reference writes (main.py:205-207) exist with the reference's names
     for s in ("val", "test", "train"):
         assert os.path.exists(os.path.join(get_model_dir_root(cfg), f"zero_shot_hp_search_{s}_ViT_B_16_K_{cfg['shots']}.pkl"))
