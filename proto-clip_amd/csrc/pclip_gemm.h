@@ -408,7 +408,9 @@ __device__ __forceinline__ void mainloop_bl(const TilePair<C>& tp, int nt, char*
 // landed, K-tile t + 2 stays in flight.  Same fragment order as mainloop_bl: bit-identical results.
 // Measured alternatives (same-process A/B, tools/ab_lib.py): ONE mid-iteration barrier with both halves requested at 75 % is
 // 4 - 8 % slower (the spread of the requests matters more than the barrier); reading every fragment earlier so that the halves
-// free up at 25 % / 50 % spills (72 B of scratch) and is 1 - 6 % slower.
+// free up at 25 % / 50 % spills (72 B of scratch) and is 1 - 6 % slower; __builtin_amdgcn_sched_barrier(0) after every block of
+// fragment reads (so that hipcc cannot sink them behind the MFMAs they are meant to overlap) gives the intended read-ahead
+// stream but costs registers: equal where it does not spill (bias + QuickGELU), 30 % slower where it does (88 B, bias only).
 template <class C, int YOUNGER = 0, bool ZERO_ACC = true>
 __device__ __forceinline__ void mainloop_sr(const TilePair<C>& tp, int nt, char* smem, Acc<C>& acc, int& p, bool counted_first, int wave,
                                             int lane) {
