@@ -107,8 +107,8 @@ def measure_gemm(st):
 def pmc_traffic():
     """HBM bytes per GEMM launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE x2 + WRITE_SIZE,
     separate passes, gfx950 correction) — counters cannot be read from inside the process, so the committed summary
-    profiles/r01_pmc_traffic.json (tools/gpu_round.sh) is reported; null when it is absent."""
-    path = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+    profiles/r02_pmc_traffic.json (tools/gpu_round.sh) is reported; null when it is absent."""
+    path = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
     try:
         with open(path) as f:
             return float(json.load(f)["linear_kernel_hbm_bytes_per_launch"])
@@ -238,7 +238,7 @@ def main():
                        "alpha": ALPHA, "beta": BETA, "parallelism": f"dp{world} (support rows and queries sharded; all-gather of class sums)"},
             "roofline": {"bound": "mfma", "kernel": "linear_fast_kernel + linear_small_kernel (fp16 MFMA GEMM: every encoder linear incl. patch embedding and projection; the class-row tail runs the small-M variant)",
                          "achieved": gm["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gm["tflops"] / MFMA_PEAK_TFLOPS,
-                         "traffic": pmc_traffic(), "traffic_unit": "HBM bytes per launch (profiles/r01_pmc_traffic.json)",
+                         "traffic": pmc_traffic(), "traffic_unit": "HBM bytes per launch (profiles/r02_pmc_traffic.json)",
                          "launches_per_step": gm["launches"], "avg_launch_us": gm["avg_us"],
                          "gemm_ms_per_step": gm["total_ms"], "algorithmic_gflop_per_step": gm["flops"] / 1e9},
             "whole_path": {"gflop_per_image": GFLOP_PER_IMG_ENCODER + 0.00452, "achieved_tflops": imgs_per_s / world * (GFLOP_PER_IMG_ENCODER + 0.00452) / 1e3,

@@ -454,6 +454,13 @@ __device__ __forceinline__ void mainloop_sr(const TilePair<C>& tp, int nt, char*
                 for (int b = 0; b < 2; ++b) dst[j][b] = fb(ks, j, b);
         };
         auto group = [&](const half8_t (&af)[HM][2], const half8_t (&bf)[C::TN][2], int half) {
+#if (PCLIP_ABL & 2) && defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (int i = 0; i < HM; ++i) { asm volatile("" ::"v"(af[i][0]), "v"(af[i][1])); }
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j) { asm volatile("" ::"v"(bf[j][0]), "v"(bf[j][1])); }
+            return;
+#endif
 #pragma unroll
             for (int i = 0; i < HM; ++i)
 #pragma unroll
@@ -472,7 +479,7 @@ __device__ __forceinline__ void mainloop_sr(const TilePair<C>& tp, int nt, char*
         const bool refill = t + 2 < nt;                               // workgroup-uniform
         load_b(bcur, 0);
         load_a(acur, 0, 0);
-        if (t == 0 && nt > 1) tp.stage(1, smem + (p ^ 1) * C::STAGE_BYTES, wave);   // the other buffer was the previous tile's epilogue staging area until the barrier above
+        if (t == 0 && nt > 1 && !(PCLIP_ABL & 1)) tp.stage(1, smem + (p ^ 1) * C::STAGE_BYTES, wave);   // the other buffer was the previous tile's epilogue staging area until the barrier above
         load_a(anext, 0, 1);
         group(acur, bcur, 0);                    // ks 0, rows half 0
         load_b(bnext, 1);
@@ -480,13 +487,13 @@ __device__ __forceinline__ void mainloop_sr(const TilePair<C>& tp, int nt, char*
         group(anext, bcur, 1);                   // ks 0, rows half 1
         if (refill) {
             lds_barrier();                       // every wave holds its last B fragments of this K-tile: the B half of `cur` is free
-            tp.b.template stage<0>((t + 2) * (BK * 2), cur + C::A_BYTES, wave);
+            if (!(PCLIP_ABL & 1)) tp.b.template stage<0>((t + 2) * (BK * 2), cur + C::A_BYTES, wave);
         }
         load_a(anext, 1, 1);
         group(acur, bnext, 0);                   // ks 1, rows half 0
         if (refill) {
             lds_barrier();                       // ... and its last A fragments: the A half is free
-            tp.a.template stage<PCLIP_NT_A>((t + 2) * (BK * 2), cur, wave);
+            if (!(PCLIP_ABL & 1)) tp.a.template stage<PCLIP_NT_A>((t + 2) * (BK * 2), cur, wave);
         }
         group(anext, bnext, 1);                  // ks 1, rows half 1
         p ^= 1;
