@@ -144,12 +144,34 @@ def search_scale_step(cfg):
     return cfg
 
 
+def check_shape_envelope(N, K, D, adapter, training, eval_path=True):
+    """The kernels' hard limits, checked up front with one clear message instead of a PclipError from deep inside a step
+    (README 'Supported shapes'; the reference itself has none of these limits — every dataset and backbone it ships fits)."""
+    problems = []
+    if N > 4096:
+        problems.append(f"{N} classes: the softmax / fusion / (alpha, beta)-sweep kernels hold a class row in registers (N <= 4096)")
+    if eval_path and (D % 64 or D > 4096):
+        problems.append(f"feature dim {D}: the fp16 distance GEMM of the evaluation path needs a multiple of 64, <= 4096")
+    if adapter in ("conv-2x", "conv-3x") and D > 1024:
+        problems.append(f"conv adapter at D = {D}: its [16, s, s] stack lives in LDS (D <= 1024)")
+    if adapter == "fc" and (D % 256):
+        problems.append(f"fc adapter at D = {D}: D and D / 4 must be multiples of 64")
+    if training and K > 32:
+        problems.append(f"{K} shots: the prototype backward keeps a class's shots in LDS (K <= 32)")
+    if training and D > 2048:
+        problems.append(f"training at D = {D}: the LayerNorm / prototype backward kernels take D <= 2048")
+    if problems:
+        from ._lib import PclipError
+        raise PclipError("outside the supported shape envelope: " + "; ".join(problems))
+
+
 def run_proto_clip(cfg, visual_memory_keys, visual_memory_values, val_features, val_labels, test_features,
                    test_labels, textual_memory_bank, clip_model, text_prompts, train_loader_F=None, variant="main"):
     """Reference main.py:105-465.  Returns a dict of everything it computed."""
     ndim, NxK = visual_memory_keys.shape
     K = cfg["shots"]
     N = NxK // K
+    check_shape_envelope(N, K, ndim, cfg.get("adapter", "fc"), training=not cfg.get("only_test", False))
     cfg = search_scale_step(cfg)                                        # main.py:111
     qt = variant == "qt"                                               # main.qt.py: queries from the image loader
     subdir = "best-alpha-beta" if qt else "alpha-beta"                 # main.qt.py:292, 327

@@ -103,6 +103,8 @@ class ProtoClipTrainer:
         self.K = int(cfg["shots"])
         self.N = NK // self.K
         self.D = D
+        from .main import check_shape_envelope
+        check_shape_envelope(self.N, self.K, D, "fc" if isinstance(adapter, Adapter_FC) else "conv-3x", training=True, eval_path=False)
         self.alpha, self.beta = float(alpha), float(beta)
         self.losses = list(cfg.get("losses", []))
         self.keys_rows = ops.transpose(visual_memory_keys)                      # constant query source (main.py:266)

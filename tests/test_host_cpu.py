@@ -287,3 +287,16 @@ def test_preprocess_host_rules_match_the_oracle():
     for h, w in [(375, 500), (64, 64), (31, 257)]:
         top, left, ch, cw = t.get_params(h, w)
         assert 0 <= top and 0 <= left and top + ch <= h and left + cw <= w and ch > 0 and cw > 0
+
+
+def test_shape_envelope_is_checked_up_front():
+    """The kernels' hard limits surface as ONE clear error before any launch; every shape the reference ships passes."""
+    from proto_clip_amd._lib import PclipError
+    from proto_clip_amd.main import check_shape_envelope
+    for N, K, D, ad in ((1000, 16, 512, "conv-3x"), (100, 1, 1024, "conv-3x"), (10, 16, 512, "fc"), (198, 16, 768, "fc"), (37, 4, 512, "conv-2x")):
+        check_shape_envelope(N, K, D, ad, training=True)
+    for args, what in (((5000, 16, 512, "fc", False), "classes"), ((10, 64, 512, "fc", True), "shots"), ((10, 4, 2048, "conv-3x", False), "conv adapter"),
+                       ((10, 4, 576, "fc", False), "fc adapter"), ((10, 4, 500, "conv-2x", False), "feature dim")):
+        with pytest.raises(PclipError, match=what):
+            check_shape_envelope(*args)
+    check_shape_envelope(10, 64, 512, "fc", training=False)          # the shot limit only binds the training step
