@@ -6,6 +6,14 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#if PCLIP_TRACE
+__device__ unsigned long long g_pclip_trace[18];
+extern "C" int pclip_debug_trace(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pclip_trace), sizeof(unsigned long long) * 18) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[18] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pclip_trace), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 namespace {
 #ifndef PCLIP_SR
 #define PCLIP_SR 1               // K-loop with staggered refill of the buffer being consumed (pgemm::mainloop_sr); 0: mainloop_bl
@@ -89,6 +97,10 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     // in the epilogue of out_proj / c_proj; Cout may BE residual (the residual stream is updated in place: every 16-byte chunk is
     // read and then written by the same thread)
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#if PCLIP_TRACE && defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long t_entry;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry)::"memory");
+#endif
     half_t* bias_lds = reinterpret_cast<half_t*>(smem + C::LDS_BYTES);       // [2][BN] fp16
     float* affine_lds = reinterpret_cast<float*>(smem + C::LDS_BYTES);       // ACT >= 2: [2][ scale BN | shift BN ] fp32
     constexpr bool AFFINE = ACT == 2 || ACT == 3 || ACT == 5;
@@ -132,6 +144,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     constexpr int YOUNGER = C::NH * C::NPASS + (AFFINE ? 2 : (HAS_BIAS ? 1 : 0));
     bool prev_full = false;
     int parity = 0;
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (; tile < ntiles; tile += G, parity ^= 1) {
         const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
         const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         }
         if (AFFINE) copy_affine(tile + G < ntiles ? tile + G : tile, parity ^ 1);
 #if PCLIP_SR
-        if (M16) pgemm::mainloop_sr<C, YOUNGER, !HAS_BIAS>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane);
+        if (M16) pgemm::mainloop_sr<C, YOUNGER, !HAS_BIAS>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, tr);
 #else
         if (M16) pgemm::mainloop_bl<C, YOUNGER, !HAS_BIAS, PCLIP_PF>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, smem + C::LDS_BYTES + STRIP_BYTES);
 #endif
@@ -235,6 +248,17 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             });
         prev_full = full;
     }
+#if PCLIP_TRACE
+    if (lane == 0 && (wave == 0 || wave == 7))
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_pclip_trace[(wave ? 8 : 0) + i], tr[i]);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (tid == 0) {                                            // kernel span in s_memtime ticks: [16] = min entry stamp, [17] = max exit stamp
+        unsigned long long t_exit;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_exit)::"memory");
+        atomicMax(&g_pclip_trace[17], t_exit - t_entry);        // (the counters of different XCDs are not aligned: per-workgroup spans only)
+    }
+#endif
+#endif
 }
 
 // ---- 3x3 convolution (stride 1, pad 1, NHWC) + eval BatchNorm (+ReLU) as an implicit GEMM -----------------------------------

@@ -411,9 +411,12 @@ __device__ __forceinline__ void mainloop_bl(const TilePair<C>& tp, int nt, char*
 // free up at 25 % / 50 % spills (72 B of scratch) and is 1 - 6 % slower; __builtin_amdgcn_sched_barrier(0) after every block of
 // fragment reads (so that hipcc cannot sink them behind the MFMAs they are meant to overlap) gives the intended read-ahead
 // stream but costs registers: equal where it does not spill (bias + QuickGELU), 30 % slower where it does (88 B, bias only).
+#ifndef PCLIP_TRACE
+#define PCLIP_TRACE 0            // debug build: s_memtime stamps around every wait of the K-loop (tools/trace_gemm.py)
+#endif
 template <class C, int YOUNGER = 0, bool ZERO_ACC = true>
 __device__ __forceinline__ void mainloop_sr(const TilePair<C>& tp, int nt, char* smem, Acc<C>& acc, int& p, bool counted_first, int wave,
-                                            int lane) {
+                                            int lane, unsigned long long* g_tr = nullptr) {
     static_assert(C::TM >= 2 && C::TM % 2 == 0, "group pipeline splits the wave's A rows in two halves");
     constexpr int HM = C::TM / 2;
     constexpr int NA = TileSrc<C::BM, C::NWAVES>::NL, NB = TileSrc<C::BN, C::NWAVES>::NL;
@@ -431,11 +434,23 @@ __device__ __forceinline__ void mainloop_sr(const TilePair<C>& tp, int nt, char*
     const int offa = (wm * (C::BM / C::WM) + (lane & 15)) * ROW_BYTES + col0;
     const int offb = C::A_BYTES + (wn * (C::BN / C::WN) + (lane & 15)) * ROW_BYTES + col0;
 
+#if PCLIP_TRACE && defined(__HIP_DEVICE_COMPILE__)
+#define PCLIP_STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+    PCLIP_STAMP(tr_begin);
+#else
+#define PCLIP_STAMP(var)
+#endif
     for (int t = 0; t < nt; ++t) {
+        PCLIP_STAMP(tr0);
         if (t == 0) { if (counted_first) wait_vm<YOUNGER>(); else wait_vm<0>(); }
         else if (t + 1 < nt) wait_vm<NA + NB>();
         else wait_vm<0>();
+        PCLIP_STAMP(tr1);
         lds_barrier();
+        PCLIP_STAMP(tr2);
+#if PCLIP_TRACE && defined(__HIP_DEVICE_COMPILE__)
+        g_tr[0] += tr1 - tr0; g_tr[1] += tr2 - tr1;
+#endif
         char* cur = smem + p * C::STAGE_BYTES;
         const char* base = cur;
         auto fa = [&](int ks, int i, int a) { return *reinterpret_cast<const half8_t*>(base + (offa ^ (ks << 6)) + (i * 32 + a * 16) * ROW_BYTES); };
@@ -486,18 +501,35 @@ __device__ __forceinline__ void mainloop_sr(const TilePair<C>& tp, int nt, char*
         load_a(acur, 1, 0);
         group(anext, bcur, 1);                   // ks 0, rows half 1
         if (refill) {
+            PCLIP_STAMP(tr3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PCLIP_STAMP(tr4);
             lds_barrier();                       // every wave holds its last B fragments of this K-tile: the B half of `cur` is free
+            PCLIP_STAMP(tr5);
+#if PCLIP_TRACE && defined(__HIP_DEVICE_COMPILE__)
+            g_tr[2] += tr4 - tr3; g_tr[3] += tr5 - tr4;
+#endif
             if (!(PCLIP_ABL & 1)) tp.b.template stage<0>((t + 2) * (BK * 2), cur + C::A_BYTES, wave);
         }
         load_a(anext, 1, 1);
         group(acur, bnext, 0);                   // ks 1, rows half 0
         if (refill) {
+            PCLIP_STAMP(tr6);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PCLIP_STAMP(tr7);
             lds_barrier();                       // ... and its last A fragments: the A half is free
+            PCLIP_STAMP(tr8);
+#if PCLIP_TRACE && defined(__HIP_DEVICE_COMPILE__)
+            g_tr[4] += tr7 - tr6; g_tr[5] += tr8 - tr7;
+#endif
             if (!(PCLIP_ABL & 1)) tp.a.template stage<PCLIP_NT_A>((t + 2) * (BK * 2), cur, wave);
         }
         group(anext, bnext, 1);                  // ks 1, rows half 1
         p ^= 1;
     }
+#if PCLIP_TRACE && defined(__HIP_DEVICE_COMPILE__)
+    { PCLIP_STAMP(tr_end); g_tr[6] += tr_end - tr_begin; g_tr[7] += nt; }
+#endif
 }
 
 // ---- implicit-GEMM gather for a 3x3 / stride 1 / pad 1 convolution on NHWC fp16 activations ------------------------------
