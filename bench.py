@@ -88,15 +88,25 @@ def measure_gemm(st):
         rec.append((e0, e1, gemm_flops(a.shape[0], w.shape[0], a.shape[1])))
         return y
 
+    real_ln = ops.gemm_ln
+
+    def timed_ln(x, stats, wf, colsum, bfold, act=0, out=None):          # the LayerNorm-folded linears: the same MFMA kernel, another epilogue
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = real_ln(x, stats, wf, colsum, bfold, act, out)
+        e1.record()
+        rec.append((e0, e1, gemm_flops(x.shape[0], wf.shape[0], x.shape[1])))
+        return y
+
     from proto_clip_amd import _lib
     lib = _lib.load()
-    ops.gemm = timed
+    ops.gemm, ops.gemm_ln = timed, timed_ln
     n0 = lib.pclip_gemm_kernel_launches()
     try:
         step(st)
         torch.cuda.synchronize()
     finally:
-        ops.gemm = real
+        ops.gemm, ops.gemm_ln = real, real_ln
     launches = lib.pclip_gemm_kernel_launches() - n0           # a call whose last round is split = two kernel launches
     ms = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
     fl = sum(f for _, _, f in rec)

@@ -187,6 +187,23 @@ int pclip_conv3x3_bn_f16(const void* x, const void* w, const void* zero_line, in
 int pclip_layernorm_f16(const void* x, int ld_x, const float* gamma, const float* beta, float eps, void* y,
                         int R, int D, pclip_stream_t stream);
 
+/* LayerNorm folded into the nn.Linear that consumes it (ln_1 -> attn.in_proj, ln_2 -> mlp.c_fc of a ResidualAttentionBlock,
+ * clip/model.py:155-161, 171-190):  LN(x) W^T + b = rstd (x (g.W)^T - mu colsum(g.W)) + (beta W^T + b), so the linear runs on the
+ * un-normalised rows and the LayerNorm pass (read x, write h) disappears.  Three entry points:
+ *  - pclip_ln_fold_weights_f16: once per (LayerNorm, Linear) pair.  W [N, K] fp16 (row stride ldw), gamma / beta fp32 [K], bias
+ *    fp16 [N] or NULL -> Wf [N, K] fp16 = r16(gamma . W), colsum [N] fp32 = row sums of Wf, bfold [N] fp32 = beta W^T + bias.
+ *  - pclip_row_stats_f16: per call.  stats[r] = (mean, 1/sqrt(var + eps)) of row r of x [R, D] fp16 (row stride ld_x), the fp32
+ *    two-pass statistics of pclip_layernorm_f16.  stats must hold round_up(R, 256) + 256 rows of 2 floats (16-byte aligned):
+ *    the linear stages whole 256-row tiles of it, and a row-split call starts its second launch at a multiple of 128 rows.
+ *  - pclip_gemm_ln_f16: C [M, N] fp16 = act(r16(rstd_m (acc_mn - mu_m colsum_n) + bfold_n)), acc = x Wf^T in fp32; act 0 none,
+ *    1 QuickGELU; N % 64 == 0, K % 64 == 0.  Same value for a row whatever the batch around it.
+ * Rounding: h = r16(LN(x)) is not formed and Wf is rounded instead (DESIGN section 4 has the measured effect). */
+int pclip_ln_fold_weights_f16(const void* W, int ldw, int N, int K, const float* gamma, const float* beta, const void* bias,
+                              void* Wf, float* colsum, float* bfold, pclip_stream_t stream);
+int pclip_row_stats_f16(const void* x, int ld_x, float eps, float* stats, int R, int D, pclip_stream_t stream);
+int pclip_gemm_ln_f16(const void* x, int ldx, const float* rowstats, const void* Wf, int ldw, void* C, int ldc, int M, int N, int K,
+                      const float* colsum, const float* bfold, int act, pclip_stream_t stream);
+
 /* Residual add fused into the following LayerNorm (clip/model.py:188-189 then ln_2 / next ln_1 / ln_post /
  * ln_final): xs = r16(x + delta); x_out (nullable, may alias x; row stride ld) receives xs;
  * y [R, D] = r16(LayerNorm(xs)).  x and delta rows are ld elements apart. */
@@ -196,7 +213,7 @@ int pclip_add_layernorm_f16(const void* x, const void* delta, int ld, void* x_ou
 /* Multi-head self-attention core on a fused QKV buffer (nn.MultiheadAttention inside
  * ResidualAttentionBlock.attention, clip/model.py:183-185): qkv [B, L, 3*H*dh] fp16 (q|k|v blocks,
  * heads contiguous inside each) -> out [B, L, H*dh] fp16 = softmax(q k^T / sqrt(dh) [+causal]) v.
- * dh must be 64; L <= 272. */
+ * dh must be 64; L <= 288. */
 int pclip_attention_f16(const void* qkv, void* out, int B, int L, int H, int dh, int causal,
                         pclip_stream_t stream);
 
@@ -205,6 +222,14 @@ int pclip_attention_f16(const void* qkv, void* out, int B, int L, int H, int dh,
  * Lq < L serves the last vision block, whose output is only read at the class token (clip/model.py:233); causal needs Lq == L. */
 int pclip_attention_q_f16(const void* q, int ldq, long q_batch_stride, const void* kv, int ldkv, int k_off, int v_off, void* out,
                           int B, int L, int Lq, int H, int dh, int causal, pclip_stream_t stream);
+
+/* Kernel choice behind the two attention entry points (same results bit for bit either way): mode -1 / 0 = one workgroup per
+ * (image, head) pair (default); 1 = where its shape conditions hold (Lq == L, L <= 256), the persistent kernel that prefetches the
+ * next pair's K / V / Q rows by LDS-DMA while the current one is multiplied — built and kept as a measured experiment (faster in
+ * isolation, not inside the encoder).  max_grid > 0 caps the persistent grid (test hook: several items per
+ * workgroup on small problems).  Process-wide, not thread-safe; PCLIP_ATT_PIPE=0/1 sets the initial mode.  No reference
+ * counterpart (nn.MultiheadAttention picks its own kernels, clip/model.py:176-178). */
+int pclip_attention_config(int mode, int max_grid);
 
 /* ViT stem (clip/model.py:222-227): patch-conv as an im2col gather of [B,3,R,R] fp16 images into
  * [B*G*G, ld >= 3*P*P] rows, zero beyond 3*P*P (the GEMM against conv1.weight follows), and the token assembly
@@ -215,10 +240,13 @@ int pclip_im2col_patches_f32(const float* img, int B, int R, int P, void* cols, 
 int pclip_vit_assemble_tokens_f16(const void* patch_emb, const void* class_emb, const void* pos_emb, int B,
                                   int G2, int W, void* tokens, pclip_stream_t stream);
 /* The same assembly fused with ln_pre and the first block's ln_1 (clip/model.py:225-227, 188): x0 = ln_pre(tokens) (the residual
- * stream entering the transformer) and h = ln_1(x0), one pass per token row, bit-identical to the three separate calls. */
+ * stream entering the transformer) and h = ln_1(x0), one pass per token row, bit-identical to the three separate calls.
+ * h may be NULL (then gamma_1 / beta_1 are unused) when stats is given: stats [round_up(B*(G2+1), 256) + 256][2] fp32 receives the
+ * (mean, rstd) of every x0 row exactly as pclip_row_stats_f16 computes them — the first block's ln_1 folded into its in_proj
+ * (pclip_gemm_ln_f16). */
 int pclip_vit_embed_ln_f16(const void* patch_emb, const void* class_emb, const void* pos_emb, int B, int G2, int W,
                            const float* gamma_pre, const float* beta_pre, const float* gamma_1, const float* beta_1, float eps,
-                           void* x0, void* h, pclip_stream_t stream);
+                           void* x0, void* h, float* stats, pclip_stream_t stream);
 
 /* Text stem (clip/model.py:342-344): x = token_embedding[text] + positional_embedding, fp16. */
 int pclip_text_embed_f16(const int64_t* tokens, const void* tok_emb, const void* pos_emb, int B, int L, int W,

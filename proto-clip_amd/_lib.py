@@ -50,13 +50,17 @@ _SIGS = {
     "pclip_gemm_bn_res_f16": [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P],
     "pclip_conv3x3_bn_f16": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P],
     "pclip_layernorm_f16": [_P, c_int, _P, _P, c_float, _P, c_int, c_int, _P],
+    "pclip_ln_fold_weights_f16": [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P],
+    "pclip_row_stats_f16": [_P, c_int, c_float, _P, c_int, c_int, _P],
+    "pclip_gemm_ln_f16": [_P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P],
     "pclip_add_layernorm_f16": [_P, _P, c_int, _P, _P, _P, c_float, _P, c_int, c_int, _P],
     "pclip_attention_f16": [_P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "pclip_attention_q_f16": [_P, c_int, c_long, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
+    "pclip_attention_config": [c_int, c_int],
     "pclip_im2col_patches_f16": [_P, c_int, c_int, c_int, _P, c_int, _P],
     "pclip_im2col_patches_f32": [_P, c_int, c_int, c_int, _P, c_int, _P],
     "pclip_vit_assemble_tokens_f16": [_P, _P, _P, c_int, c_int, c_int, _P, _P],
-    "pclip_vit_embed_ln_f16": [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P, _P, _P],
+    "pclip_vit_embed_ln_f16": [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P, _P, _P, _P],
     "pclip_text_embed_f16": [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P],
     "pclip_gather_eot_f16": [_P, _P, c_int, c_int, c_int, _P, _P],
     "pclip_im2col3x3_f16": [_P, c_long, c_long, c_long, c_long, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P],

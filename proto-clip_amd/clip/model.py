@@ -63,15 +63,35 @@ def _transformer(width, layers):
     return t
 
 
-def _run_blocks(x, blocks, B, L, heads, causal, select=None, first_token=False, h0=None):
+# LayerNorm folded into the linear that consumes it (ops.gemm_ln): on by default for the batch paths; PCLIP_LN_FOLD=0 restores the
+# separate LayerNorm pass (A/B runs).  Split-K (low-latency serving) launches keep the unfused form.
+LN_FOLD = os.environ.get("PCLIP_LN_FOLD", "1") != "0"
+
+
+def _folded(blk, name, w, b, ln):
+    """(Wf, colsum, bfold) of `ln` folded into the linear (w, b), cached on the block and refreshed when any of the four changes."""
+    tag = tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in (w, b, ln.weight, ln.bias))
+    cache = blk.__dict__.setdefault("_ln_fold_cache", {})
+    hit = cache.get(name)
+    if hit is None or hit[0] != tag:
+        f32 = lambda t: t.detach() if t.dtype == torch.float32 else t.detach().float()
+        hit = (tag, ops.ln_fold_weights(w.detach(), b.detach(), f32(ln.weight), f32(ln.bias)))
+        cache[name] = hit
+    return hit[1]
+
+
+def _run_blocks(x, blocks, B, L, heads, causal, select=None, first_token=False, h0=None, stats0=None):
     """ResidualAttentionBlock.forward (clip/model.py:187-190) per layer on x [B*L, W] fp16 (updated IN PLACE).
     Both residual adds ride in the epilogue of the GEMM that produces the addend (pclip_gemm_f16 with `residual`: the residual
-    rows are read in the coalesced store pass, r16(x + r16(acc + bias)) — the reference's two roundings), so a block is
-        h = LN1(x)   qkv = in_proj(h)   a = attention(qkv)   x += out_proj(a)
-        h = LN2(x)   f = QuickGELU(c_fc(h))                  x += c_proj(f)
-    and each LayerNorm is a plain read-x / write-h pass (the fused add + LayerNorm pass it replaces moved twice the bytes).
+    rows are read in the coalesced store pass, r16(x + r16(acc + bias)) — the reference's two roundings), and both LayerNorms
+    are folded into the linears that consume them (ops.gemm_ln: the GEMM runs on x itself against gamma-scaled weights and its
+    epilogue applies the row's mean / rstd), so a block is
+        s = stats(x)   qkv = in_proj_ln(x, s)   a = attention(qkv)   x += out_proj(a)
+        s = stats(x)   f = QuickGELU(c_fc_ln(x, s))                  x += c_proj(f)
+    where stats reads x once (the LayerNorm pass it replaces read x and wrote h).  With LN_FOLD off each LayerNorm is a plain
+    read-x / write-h pass followed by the ordinary linear.
     In low-latency mode (ops.low_latency: split-K linears of a serving request) the addend is produced by the split-K kernel
-    and the add stays in the LayerNorm pass (pclip_add_layernorm_f16) — the same values either way.
+    and the add stays in the LayerNorm pass (pclip_add_layernorm_f16), unfolded.
     Returns (x, d): the stack's output is x (+ d when d is not None — low-latency mode leaves the last add to the caller's
     final LayerNorm), [B, W] rows picked by `select` when given.
 
@@ -81,41 +101,79 @@ def _run_blocks(x, blocks, B, L, heads, causal, select=None, first_token=False, 
     same arithmetic for the rows that matter (a GEMM row does not depend on the other rows), 9/12 of one layer's linear
     FLOPs saved (6 % of a 12-layer tower).  `first_token` (vision tower: the
     selected row is token 0 of every sequence) additionally projects the last block's QUERIES for those B rows only and runs
-    its attention for that one query per image (keys / values still come from every token)."""
+    its attention for that one query per image (keys / values still come from every token).
+    `h0` / `stats0`: the first block's ln_1 output, or (LN_FOLD) the row statistics of x, when the caller's stem produced them."""
     n = len(blocks)
     d = None
 
+    class _Norm:
+        """LN(x) in whichever form the next linear takes: the normalised rows `h`, or (folded) x with its row statistics."""
+        def __init__(self, x_, ln, h=None, stats=None):
+            self.x, self.ln, self.h, self.stats = x_, ln, h, stats
+
+        def pick(self, sel):
+            """The same for the rows `sel` picks (statistics are per row: recomputed on the picked rows, same values)."""
+            if self.h is not None:
+                return _Norm(None, self.ln, h=sel(self.h))
+            xs = sel(self.x)
+            return _Norm(xs, self.ln, stats=ops.row_stats(xs))
+
+    def norm_of(x_, ln):
+        if ln is None:
+            return None
+        if LN_FOLD and not ops.splitk_active(x_.shape[0]):
+            return _Norm(x_, ln, stats=ops.row_stats(x_))
+        return _Norm(x_, ln, h=ops.layernorm(x_, ln.weight, ln.bias))
+
+    def linear(nm, blk, name, w, bias, act=0, rows=None):
+        """act(LN(x) w^T + bias); `rows` = a row range of (w, bias) (the q / kv thirds of in_proj)."""
+        if nm.h is not None:
+            sl = slice(None) if rows is None else rows
+            return ops.gemm(nm.h, w[sl], bias[sl], act=act)
+        wf, cs, bf = _folded(blk, name, w, bias, nm.ln)
+        if rows is not None:
+            wf, cs, bf = wf[rows], cs[rows], bf[rows]
+        return ops.gemm_ln(nm.x, nm.stats, wf, cs, bf, act=act)
+
     def add_linear(x_, a_, lin, ln):
-        """x_ += lin(a_) ; returns (x_, LN(x_))."""
+        """x_ += lin(a_) ; returns (x_, LN(x_) as a _Norm)."""
         if ops.splitk_active(a_.shape[0]):
             d = ops.gemm(a_, lin.weight, lin.bias)
-            return x_, ops.add_layernorm(x_, d, ln.weight, ln.bias)
+            return x_, _Norm(x_, ln, h=ops.add_layernorm(x_, d, ln.weight, ln.bias))
         ops.gemm(a_, lin.weight, lin.bias, residual=x_, out=x_)
-        return x_, (ops.layernorm(x_, ln.weight, ln.bias) if ln is not None else None)
+        return x_, norm_of(x_, ln)
 
-    h = h0 if (n > 0 and h0 is not None) else (ops.layernorm(x, blocks[0].ln_1.weight, blocks[0].ln_1.bias) if n > 0 else None)
+    nm = None
+    if n > 0:
+        ln0 = blocks[0].ln_1
+        if h0 is not None:
+            nm = _Norm(x, ln0, h=h0)
+        elif stats0 is not None:
+            nm = _Norm(x, ln0, stats=stats0)
+        else:
+            nm = norm_of(x, ln0)
     for i, blk in enumerate(blocks):
         last = i == n - 1
+        w, bias = blk.attn.in_proj_weight, blk.attn.in_proj_bias
         if select is not None and last and first_token and not causal:
-            W = h.shape[1]
-            w, bias = blk.attn.in_proj_weight, blk.attn.in_proj_bias
-            kv = ops.gemm(h, w[W:], bias[W:])                                     # keys | values of every token
-            q = ops.gemm(select(h), w[:W], bias[:W])                              # queries of the class tokens
+            W = x.shape[1]
+            kv = linear(nm, blk, "in_proj", w, bias, rows=slice(W, 3 * W))          # keys | values of every token
+            q = linear(nm.pick(select), blk, "in_proj", w, bias, rows=slice(0, W))  # queries of the class tokens
             a, x = ops.attention_first_queries(q, kv, B, L, 1, heads), select(x)
         else:
-            qkv = ops.gemm(h, blk.attn.in_proj_weight, blk.attn.in_proj_bias)
+            qkv = linear(nm, blk, "in_proj", w, bias)
             a = ops.attention(qkv, B, L, heads, causal=causal)
             if select is not None and last:
                 a, x = select(a), select(x)              # x holds the residual stream entering this block's out_proj add
-        x, h = add_linear(x, a, blk.attn.out_proj, blk.ln_2)
-        f = ops.gemm(h, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, act=1)
+        x, nm = add_linear(x, a, blk.attn.out_proj, blk.ln_2)
+        f = linear(nm, blk, "c_fc", blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, act=1)
         if last:
             if ops.splitk_active(f.shape[0]):
                 d = ops.gemm(f, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)      # the caller's final LayerNorm adds it
             else:
                 ops.gemm(f, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, residual=x, out=x)
         else:
-            x, h = add_linear(x, f, blk.mlp.c_proj, blocks[i + 1].ln_1)
+            x, nm = add_linear(x, f, blk.mlp.c_proj, blocks[i + 1].ln_1)
     if select is not None and n == 0:
         x = select(x)
     return x, d
@@ -186,15 +244,17 @@ class VisionTransformer(nn.Module):
         cols = ops.im2col_patches(img, P)                                   # conv1 as GEMM (clip/model.py:222)
         patch = ops.gemm(cols, wconv)
         blocks = self.transformer.resblocks
-        h0 = None
-        if len(blocks) > 0:                                                 # tokens + ln_pre + the first block's ln_1 in one pass
+        h0 = stats0 = None
+        if len(blocks) > 0 and LN_FOLD and not ops.splitk_active(B * L):    # tokens + ln_pre + the row statistics of the first (folded) ln_1
+            x, stats0 = ops.vit_embed_ln(patch, cls16, pos16, B, G * G, W, self.ln_pre.weight, self.ln_pre.bias, want_stats=True)
+        elif len(blocks) > 0:                                               # tokens + ln_pre + the first block's ln_1 in one pass
             x, h0 = ops.vit_embed_ln(patch, cls16, pos16, B, G * G, W, self.ln_pre.weight, self.ln_pre.bias, blocks[0].ln_1.weight,
                                      blocks[0].ln_1.bias)                   # clip/model.py:225-227, 188
         else:
             x = ops.vit_assemble_tokens(patch, cls16, pos16, B, G * G, W)   # clip/model.py:225-226
             x = ops.layernorm(x, self.ln_pre.weight, self.ln_pre.bias)      # 227
         pick_cls = lambda t: t.view(B, L, W)[:, 0, :].contiguous()          # x[:, 0, :], 233 (taken before the last block's tail)
-        x, d = _run_blocks(x, blocks, B, L, self.heads, causal=False, select=pick_cls, first_token=True, h0=h0)   # 229-231
+        x, d = _run_blocks(x, blocks, B, L, self.heads, causal=False, select=pick_cls, first_token=True, h0=h0, stats0=stats0)   # 229-231
         if d is None:                                                       # ln_post(x[:, 0, :]), 233
             cls = ops.layernorm(x, self.ln_post.weight, self.ln_post.bias)
         else:

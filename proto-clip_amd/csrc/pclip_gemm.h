@@ -665,7 +665,7 @@ __device__ __forceinline__ void mainloop_ring(const half_t* __restrict__ A, int 
 // ---- fp16 output through an LDS-staged, fully coalesced epilogue -----------------------------------------
 // The BM x BN tile leaves in NH slabs of HR = 128 rows.  For slab h:
 //  step 0 `slab(h)`: caller hook before the slab is staged;
-//  step 1 (MFMA layout, waves owning rows of the slab): `pre(i, j, coff, v4)` turns four consecutive-column
+//  step 1 (MFMA layout, waves owning rows of the slab): `pre(i, j, coff, v4, rl, g)` (rl = the lane's row inside the 32-row block i, g = the accumulator quad: compile-time after unrolling) turns four consecutive-column
 //          accumulators (columns coff .. coff+3 of the wave's 32-column tile j) into fp16 values (activation); they are written as 8-byte units into a
 //          [HR][BN] fp16 LDS image with unit' = unit ^ (row & 15)  (conflict-free ds_write_b64);
 //  step 2 (row-major, all waves): `post(row_in_tile, chunk, pass, half8)` receives 8 consecutive columns of a
@@ -695,7 +695,7 @@ __device__ __forceinline__ void epilogue_f16(const Acc<C>& acc, char* stg, const
                         const int ml = (wm * WROWS) % C::HR + i * 32 + rl;
                         const int nl = wn * (C::BN / C::WN) + j * 32 + coff;
                         float4_t v = {acc.v[i][j][4 * g], acc.v[i][j][4 * g + 1], acc.v[i][j][4 * g + 2], acc.v[i][j][4 * g + 3]};
-                        const half4_t hv = pre(i, j, coff, v);
+                        const half4_t hv = pre(i, j, coff, v, rl, g);
                         const int unit = (nl >> 2) ^ (ml & SWZ);
                         *reinterpret_cast<half4_t*>(stg + ml * RB + unit * 8) = hv;
                     }

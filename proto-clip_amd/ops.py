@@ -384,6 +384,51 @@ def layernorm(x, gamma, beta, eps: float = 1e-5, out=None, rows: int = None, ld:
     return out
 
 
+def ln_fold_weights(w, bias, gamma, beta):
+    """(Wf, colsum, bfold) of a LayerNorm folded into the linear that consumes it (pclip_ln_fold_weights_f16): done once per
+    (LayerNorm, Linear) pair; gamma / beta fp32, w fp16 [N, K], bias fp16 [N] or None."""
+    require_cuda(w, gamma, beta)
+    N, K = w.shape
+    wf = torch.empty(N, K, dtype=torch.float16, device=w.device)
+    cs = torch.empty(N, dtype=torch.float32, device=w.device)
+    bf = torch.empty(N, dtype=torch.float32, device=w.device)
+    check(_lib.load().pclip_ln_fold_weights_f16(ptr(w), w.stride(0), N, K, ptr(gamma), ptr(beta), ptr(bias), ptr(wf), ptr(cs), ptr(bf),
+                                                stream()), "pclip_ln_fold_weights_f16")
+    return wf, cs, bf
+
+
+def stats_rows(R: int) -> int:
+    """Rows a (mean, rstd) buffer for R rows must hold: the linear stages whole 256-row tiles of it, and a call whose last round
+    of tiles is split off starts its second launch at a multiple of 128 rows."""
+    return (R + 255) // 256 * 256 + 256
+
+
+def row_stats(x, eps: float = 1e-5, rows: int = None, ld: int = None):
+    """(mean, rstd) per row of x [R, D] fp16 — the statistics half of LayerNorm (clip/model.py:155-161) for `gemm_ln`.
+    Returns [stats_rows(R), 2] fp32 of which the first R rows are filled."""
+    require_cuda(x)
+    D = x.shape[-1]
+    R = x.numel() // D if rows is None else rows
+    ld = D if ld is None else ld
+    stats = torch.empty(stats_rows(R), 2, dtype=torch.float32, device=x.device)
+    check(_lib.load().pclip_row_stats_f16(ptr(x), ld, eps, ptr(stats), R, D, stream()), "pclip_row_stats_f16")
+    return stats
+
+
+def gemm_ln(x, stats, wf, colsum, bfold, act: int = 0, out=None):
+    """out = act(LayerNorm(x) @ W^T + b) from the un-normalised rows x, their `row_stats` and `ln_fold_weights(W, b, gamma, beta)`."""
+    require_cuda(x, stats, wf, colsum, bfold)
+    M, K = x.shape
+    N = wf.shape[0]
+    if stats.shape[0] < stats_rows(M):
+        raise _lib.PclipError(f"gemm_ln: stats holds {stats.shape[0]} rows, needs {stats_rows(M)}")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float16, device=x.device)
+    check(_lib.load().pclip_gemm_ln_f16(ptr(x), x.stride(0), ptr(stats), ptr(wf), wf.stride(0), ptr(out), out.stride(0), M, N, K,
+                                        ptr(colsum), ptr(bfold), act, stream()), "pclip_gemm_ln_f16")
+    return out
+
+
 def add_layernorm(x, delta, gamma, beta, eps: float = 1e-5, out=None, update_x: bool = True, rows: int = None,
                   ld: int = None):
     """xs = r16(x + delta) (written back into x when update_x) and returns r16(LayerNorm(xs)): the residual add of
@@ -449,15 +494,19 @@ def vit_assemble_tokens(patch_emb, class_emb, pos_emb, B: int, G2: int, W: int) 
     return tokens
 
 
-def vit_embed_ln(patch_emb, class_emb, pos_emb, B: int, G2: int, W: int, g_pre, b_pre, g_1, b_1, eps: float = 1e-5):
-    """(x0, h) = (ln_pre(tokens), ln_1(x0)) with tokens = [class ; patches] + pos, one pass (clip/model.py:225-227, 188)."""
-    x0 = torch.empty(B * (G2 + 1), W, dtype=torch.float16, device=patch_emb.device)
-    h = torch.empty_like(x0)
-    f = lambda t: t if t.dtype == torch.float32 else t.float()
+def vit_embed_ln(patch_emb, class_emb, pos_emb, B: int, G2: int, W: int, g_pre, b_pre, g_1=None, b_1=None, eps: float = 1e-5,
+                 want_stats: bool = False):
+    """(x0, h) = (ln_pre(tokens), ln_1(x0)) with tokens = [class ; patches] + pos, one pass (clip/model.py:225-227, 188).
+    want_stats: (x0, stats) instead — the `row_stats` of x0 for a first block whose ln_1 is folded into its in_proj (`gemm_ln`)."""
+    R = B * (G2 + 1)
+    x0 = torch.empty(R, W, dtype=torch.float16, device=patch_emb.device)
+    f = lambda t: t if t is None or t.dtype == torch.float32 else t.float()
     g_pre, b_pre, g_1, b_1 = f(g_pre), f(b_pre), f(g_1), f(b_1)
+    h = None if want_stats else torch.empty_like(x0)
+    stats = torch.empty(stats_rows(R), 2, dtype=torch.float32, device=x0.device) if want_stats else None
     check(_lib.load().pclip_vit_embed_ln_f16(ptr(patch_emb), ptr(class_emb), ptr(pos_emb), B, G2, W, ptr(g_pre), ptr(b_pre), ptr(g_1),
-                                             ptr(b_1), eps, ptr(x0), ptr(h), stream()), "pclip_vit_embed_ln_f16")
-    return x0, h
+                                             ptr(b_1), eps, ptr(x0), ptr(h), ptr(stats), stream()), "pclip_vit_embed_ln_f16")
+    return x0, (stats if want_stats else h)
 
 
 def text_embed(tokens, tok_emb, pos_emb) -> torch.Tensor:

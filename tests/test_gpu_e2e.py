@@ -50,7 +50,10 @@ def test_images_to_logits_against_reference_chain(tmp_path):
     p16, p32 = torch.from_numpy(g["p_f16"]), torch.from_numpy(g["p_f32"])
     gap = (p16 - p32).abs().max().item()
     d16, d32 = (p - p16).abs().max().item(), (p - p32).abs().max().item()
-    tol = max(2 * gap, 1e-3)
+    # `gap` of this ONE fixture pair is itself a noisy draw (5.3e-4 here; the same fp16 <-> fp32 comparison of the reference
+    # arithmetic over eight seeded weight / image sets gives 0.7e-3 .. 1.9e-3, profiles/r02_fold_parity_study.json and
+    # test_chain_parity_over_seeds below), so the floor of the bound is 2e-3, not 1e-3
+    tol = max(2 * gap, 2e-3)
     stage = {k: rel_err(a, torch.from_numpy(g[k + "_f16"])) for k, a in
              (("test_features", test_f), ("text_bank", text_bank), ("adapted", zq), ("proto_img", zi), ("proto_txt", zt))}
     ref_am = torch.from_numpy(g["argmax_f16"]).long()
@@ -75,3 +78,20 @@ def test_images_to_logits_against_reference_chain(tmp_path):
     # and the classification stage on the GPU's own adapted features against the oracle: exact top-1, p to 1e-5
     p_o = po.P(zq.cpu(), zi.cpu(), zt.cpu(), c["alpha"], c["beta"])
     assert (p - p_o).abs().max().item() <= 1e-5 and torch.equal(am, p_o.max(1)[1])
+
+
+def test_chain_parity_over_seeds():
+    """The image -> logits chain on several seeded weight / image sets of the e2e case, with the LayerNorms folded into their
+    linears (the product path) and unfolded, against the oracle's fp32 towers (= the reference CPU path: pinned to the reference's
+    fp32 model at 5e-6) and its fp16 towers (tests/fold_parity_study.py).  At fp16 feature precision the reference arithmetic
+    disagrees with ITSELF (fp16 vs fp32 towers) by ~1.2e-3 in p on these sensitive synthetic splits; the GPU chain must sit inside
+    that same band in either form, and no query whose fp32 top-2 margin exceeds 2e-3 may change its top-1."""
+    import fold_parity_study as fps
+    rows, summary = fps.run(4)
+    for k, v in summary.items():
+        observe(f"chain parity over 4 seeds: {k} (max)", v["max"], 2.5e-3 if "flips" not in k else 0.0)
+    yard = summary["oracle16_vs_32"]["mean"]
+    for tag in ("fold", "unfolded"):
+        assert summary[tag + "_top1_flips_decided"]["max"] == 0
+        assert summary[tag + "_vs_32"]["max"] <= 2.5e-3 and summary[tag + "_vs_16"]["max"] <= 2.5e-3
+        assert summary[tag + "_vs_32"]["mean"] <= 1.25 * yard + 2e-4, (tag, summary[tag + "_vs_32"], yard)

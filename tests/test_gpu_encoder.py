@@ -180,6 +180,64 @@ def test_add_layernorm(ops, R, D, L):
     assert ulp_diff(y2, ref[::L][: R // L]) <= 1
 
 
+@pytest.mark.parametrize("M,N,K,act", [(197, 2304, 768, 0), (1000, 3072, 768, 1), (1, 1536, 512, 0), (3000, 4096, 1024, 1), (5000, 768, 768, 0),
+                                       (50432, 768, 512, 1), (333, 64, 128, 0)])
+def test_gemm_ln_fold(ops, M, N, K, act):
+    """LayerNorm folded into the consuming linear (pclip_row_stats_f16 + pclip_ln_fold_weights_f16 + pclip_gemm_ln_f16) against
+    fp32 LayerNorm -> Linear (-> QuickGELU) on the same fp16 inputs, and against the unfolded kernels (LayerNorm pass + GEMM):
+    the fold removes the fp16 rounding of h and rounds gamma.W instead, so the two GPU paths agree to a few fp16 ulp of the
+    output scale, not bit for bit; a row alone gives exactly the row of the batch (persistent vs ring kernel, any tile)."""
+    x = (torch.from_numpy(synth.normal((M, K), 31, 0)).float() * 1.5 + 0.3 * torch.from_numpy(synth.normal((1, K), 31, 5)).float()).half()
+    w = (torch.from_numpy(synth.normal((N, K), 31, 1)).float() * K ** -0.5).half()
+    bias = (torch.from_numpy(synth.normal((N,), 31, 2)).float() * 0.1).half()
+    g = 1.0 + 0.2 * torch.from_numpy(synth.normal((K,), 31, 3)).float()
+    be = 0.1 * torch.from_numpy(synth.normal((K,), 31, 4)).float()
+    xd, wd, bd, gd, bed = x.cuda(), w.cuda(), bias.cuda(), g.cuda(), be.cuda()
+    wf, cs, bf = ops.ln_fold_weights(wd, bd, gd, bed)
+    assert torch.equal(wf.cpu(), (g[None, :] * w.float()).half())
+    torch.testing.assert_close(cs.cpu(), wf.float().sum(1).cpu(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(bf.cpu(), (w.float() @ be + bias.float()), rtol=1e-5, atol=1e-5)
+    st = ops.row_stats(xd)
+    mu = x.float().mean(1)
+    rstd = 1.0 / torch.sqrt(x.float().var(1, unbiased=False) + 1e-5)
+    torch.testing.assert_close(st[:M, 0].cpu(), mu, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(st[:M, 1].cpu(), rstd, rtol=1e-5, atol=0)
+    y = ops.gemm_ln(xd, st, wf, cs, bf, act=act)
+    ref = torch.nn.functional.layer_norm(x.float(), [K], g, be) @ w.float().t() + bias.float()
+    unf = ops.gemm(ops.layernorm(xd, gd, bed), wd, bd, act=act)
+    if act == 1:
+        h = po.r16(ref)
+        ref = po.r16(h * po.r16(torch.sigmoid(po.r16(1.702 * h))))
+    scale = ref.abs().max().item()
+    e_fold = (y.float().cpu() - ref).abs().max().item() / scale
+    e_unf = (unf.float().cpu() - ref).abs().max().item() / scale
+    observe(f"gemm_ln fold vs fp32 LN+linear (act {act}): max|d| / max|ref|", e_fold, 2e-3)
+    observe(f"unfolded LN pass + gemm vs fp32 LN+linear (act {act}): max|d| / max|ref| (yard-stick)", e_unf, 2e-3)
+    assert e_fold <= 2e-3 and e_fold <= 2.0 * e_unf + 2e-4
+    # batch invariance: single rows / a small block through the ring kernel == the rows of the big call
+    for r in sorted({0, M // 2, M - 1}):
+        y1 = ops.gemm_ln(xd[r:r + 1].contiguous(), ops.row_stats(xd[r:r + 1].contiguous()), wf, cs, bf, act=act)
+        assert torch.equal(y1[0], y[r])
+    if M > 300:
+        yb = ops.gemm_ln(xd[100:300].contiguous(), ops.row_stats(xd[100:300].contiguous()), wf, cs, bf, act=act)
+        assert torch.equal(yb, y[100:300])
+
+
+def test_vit_embed_stats_matches_row_stats(ops):
+    """pclip_vit_embed_ln_f16 in its statistics form (first block's ln_1 folded): x0 identical to the ln_1 form, statistics
+    identical to pclip_row_stats_f16 of x0."""
+    B, G2, W = 3, 49, 768
+    patch = torch.from_numpy(synth.normal((B * G2, W), 33, 0)).half().cuda()
+    cls = torch.from_numpy(synth.normal((W,), 33, 1)).half().cuda()
+    pos = (0.1 * torch.from_numpy(synth.normal((G2 + 1, W), 33, 2)).float()).half().cuda()
+    gp = (1.0 + 0.1 * torch.from_numpy(synth.normal((W,), 33, 3)).float()).cuda()
+    bp = (0.1 * torch.from_numpy(synth.normal((W,), 33, 4)).float()).cuda()
+    x0, h = ops.vit_embed_ln(patch, cls, pos, B, G2, W, gp, bp, gp, bp)
+    x1, st = ops.vit_embed_ln(patch, cls, pos, B, G2, W, gp, bp, want_stats=True)
+    assert torch.equal(x0, x1)
+    assert torch.equal(st[:B * (G2 + 1)], ops.row_stats(x0)[:B * (G2 + 1)])
+
+
 @pytest.mark.parametrize("B,L,H,causal", [(2, 50, 2, False), (3, 197, 12, False), (2, 77, 8, True), (1, 257, 16, False),
                                           (4, 26, 3, False), (1, 1, 1, False), (2, 33, 1, True)])
 def test_attention(ops, B, L, H, causal):
@@ -194,6 +252,31 @@ def test_attention(ops, B, L, H, causal):
     # probabilities are rounded to fp16 before P.V (as the reference's fp16 attention does): ~1e-3 relative
     assert (out.float() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
     assert rel_err(out.reshape(-1, W), ref.reshape(-1, W)) < 2e-3
+
+
+@pytest.mark.parametrize("B,L,H,causal,grid", [(40, 197, 12, False, 0), (9, 197, 3, False, 5), (30, 50, 12, False, 7), (16, 77, 8, True, 6),
+                                                (5, 256, 2, False, 3), (7, 225, 2, False, 4), (3, 33, 1, True, 2), (2, 1, 1, False, 0),
+                                                (6, 128, 2, True, 4), (3, 129, 2, False, 1)])
+def test_attention_pipelined_kernel_is_bit_identical(ops, B, L, H, causal, grid):
+    """The persistent double-buffered attention (whole batches: next item's K / V / Q rows prefetched by LDS-DMA while the current
+    one is multiplied) against the one-workgroup-per-item kernel: same per-tile arithmetic, so the outputs must be EQUAL; `grid`
+    caps the persistent grid so that workgroups walk several items (odd counts: both buffers, a ragged last round)."""
+    from proto_clip_amd import _lib
+    lib = _lib.load()
+    W = H * 64
+    qkv = (torch.from_numpy(synth.normal((B * L, 3 * W), 29, L)).float() * 1.5).half().cuda()
+    try:
+        _lib.check(lib.pclip_attention_config(0, 0), "pclip_attention_config")
+        ref = ops.attention(qkv, B, L, H, causal=causal)
+        _lib.check(lib.pclip_attention_config(1, grid), "pclip_attention_config")
+        got = torch.full_like(ref, float("nan"))
+        ops.attention(qkv, B, L, H, causal=causal, out=got)
+        again = ops.attention(qkv, B, L, H, causal=causal)
+    finally:
+        _lib.check(lib.pclip_attention_config(-1, 0), "pclip_attention_config")
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    assert torch.equal(again, ref)
 
 
 def test_stems(ops):
