@@ -98,15 +98,25 @@ def measure_gemm(st):
         rec.append((e0, e1, gemm_flops(x.shape[0], wf.shape[0], x.shape[1])))
         return y
 
+    real_rs = ops.gemm_res_partials
+
+    def timed_rs(a, w, bias, x):                                          # residual GEMMs whose epilogue also emits the row-statistics partials
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = real_rs(a, w, bias, x)
+        e1.record()
+        rec.append((e0, e1, gemm_flops(a.shape[0], w.shape[0], a.shape[1])))
+        return y
+
     from proto_clip_amd import _lib
     lib = _lib.load()
-    ops.gemm, ops.gemm_ln = timed, timed_ln
+    ops.gemm, ops.gemm_ln, ops.gemm_res_partials = timed, timed_ln, timed_rs
     n0 = lib.pclip_gemm_kernel_launches()
     try:
         step(st)
         torch.cuda.synchronize()
     finally:
-        ops.gemm, ops.gemm_ln = real, real_ln
+        ops.gemm, ops.gemm_ln, ops.gemm_res_partials = real, real_ln, real_rs
     launches = lib.pclip_gemm_kernel_launches() - n0           # a call whose last round is split = two kernel launches
     ms = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
     fl = sum(f for _, _, f in rec)

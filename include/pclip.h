@@ -192,12 +192,21 @@ int pclip_layernorm_f16(const void* x, int ld_x, const float* gamma, const float
  * un-normalised rows and the LayerNorm pass (read x, write h) disappears.  Three entry points:
  *  - pclip_ln_fold_weights_f16: once per (LayerNorm, Linear) pair.  W [N, K] fp16 (row stride ldw), gamma / beta fp32 [K], bias
  *    fp16 [N] or NULL -> Wf [N, K] fp16 = r16(gamma . W), colsum [N] fp32 = row sums of Wf, bfold [N] fp32 = beta W^T + bias.
- *  - pclip_row_stats_f16: per call.  stats[r] = (mean, 1/sqrt(var + eps)) of row r of x [R, D] fp16 (row stride ld_x), the fp32
- *    two-pass statistics of pclip_layernorm_f16.  stats must hold round_up(R, 256) + 256 rows of 2 floats (16-byte aligned):
+ *  - pclip_row_stats_f16: per call.  stats[r] = (mean, 1/sqrt(var + eps)) of row r of x [R, D] fp16 (row stride ld_x), fp32, from
+ *    the row's sum and sum of squares (var = E[x^2] - mean^2, clamped at 0).  stats must hold round_up(R, 256) + 256 rows of 2 floats (16-byte aligned):
  *    the linear stages whole 256-row tiles of it, and a row-split call starts its second launch at a multiple of 128 rows.
  *  - pclip_gemm_ln_f16: C [M, N] fp16 = act(r16(rstd_m (acc_mn - mu_m colsum_n) + bfold_n)), acc = x Wf^T in fp32; act 0 none,
  *    1 QuickGELU; N % 64 == 0, K % 64 == 0.  Same value for a row whatever the batch around it.
  * Rounding: h = r16(LN(x)) is not formed and Wf is rounded instead (DESIGN section 4 has the measured effect). */
+/*  - pclip_gemm_res_stats_f16 + pclip_row_stats_finalize: the statistics for free.  `x = x + linear(a)` (clip/model.py:188-189:
+ *    pclip_gemm_f16 with residual, C may be residual) whose row-major store pass also emits (sum, sum of squares) of every
+ *    updated row per 64 output columns into partials [M][N / 64][2] fp32; pclip_row_stats_finalize turns partials [R][D / 64][2]
+ *    into stats [R][2] (stats sized as for pclip_row_stats_f16).  Both routes use one association order (chunks of 8 columns,
+ *    butterfly per 64 / 128 / 256 columns, 256-column blocks left to right), so stats are bit-identical whichever kernel or
+ *    tile width produced them — and identical to pclip_row_stats_f16 of the same rows. */
+int pclip_gemm_res_stats_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* bias,
+                             const void* residual, float* partials, pclip_stream_t stream);
+int pclip_row_stats_finalize(const float* partials, int R, int D, float eps, float* stats, pclip_stream_t stream);
 int pclip_ln_fold_weights_f16(const void* W, int ldw, int N, int K, const float* gamma, const float* beta, const void* bias,
                               void* Wf, float* colsum, float* bfold, pclip_stream_t stream);
 int pclip_row_stats_f16(const void* x, int ld_x, float eps, float* stats, int R, int D, pclip_stream_t stream);

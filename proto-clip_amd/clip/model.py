@@ -66,6 +66,9 @@ def _transformer(width, layers):
 # LayerNorm folded into the linear that consumes it (ops.gemm_ln): on by default for the batch paths; PCLIP_LN_FOLD=0 restores the
 # separate LayerNorm pass (A/B runs).  Split-K (low-latency serving) launches keep the unfused form.
 LN_FOLD = os.environ.get("PCLIP_LN_FOLD", "1") != "0"
+# ... and the row statistics come out of the epilogue of the residual GEMM that writes x (ops.gemm_res_stats) instead of a pass
+# over x; PCLIP_LN_STATS_EPI=0 keeps the separate pass (same values bit for bit).
+STATS_IN_EPILOGUE = os.environ.get("PCLIP_LN_STATS_EPI", "1") != "0"
 
 
 def _folded(blk, name, w, b, ln):
@@ -140,6 +143,9 @@ def _run_blocks(x, blocks, B, L, heads, causal, select=None, first_token=False, 
         if ops.splitk_active(a_.shape[0]):
             d = ops.gemm(a_, lin.weight, lin.bias)
             return x_, _Norm(x_, ln, h=ops.add_layernorm(x_, d, ln.weight, ln.bias))
+        if ln is not None and LN_FOLD and STATS_IN_EPILOGUE and not ops.splitk_active(x_.shape[0]):
+            stats = ops.gemm_res_stats(a_, lin.weight, lin.bias, x_)       # the add, and the statistics of the updated rows with it
+            return x_, (_Norm(x_, ln, stats=stats) if stats is not None else norm_of(x_, ln))
         ops.gemm(a_, lin.weight, lin.bias, residual=x_, out=x_)
         return x_, norm_of(x_, ln)
 

@@ -25,6 +25,7 @@ namespace {
 // ---- nn.Linear on MFMA ------------------------------------------------------------------------
 // Rounding points follow the reference's fp16 tensors: r16(acc + bias); QuickGELU as three fp16
 // elementwise ops (clip/model.py:166); residual add rounds once more (clip/model.py:188-189).
+typedef float float2_t __attribute__((ext_vector_type(2)));
 struct LinearEpi {
     const half_t* __restrict__ bias;
     const half_t* __restrict__ residual;
@@ -33,7 +34,8 @@ struct LinearEpi {
     int act;                          // 0 none, 1 QuickGELU, 2 per-column affine (eval BatchNorm), 3 affine + ReLU
     const float* __restrict__ scale;  // act 2 / 3 / 5: y = r16(r16(acc) * scale[n] + shift[n]);  act 7 / 8: column sums of the folded weight
     const float* __restrict__ shift;  //                                                           act 7 / 8: folded bias
-    const float* __restrict__ rowstats = nullptr;   // act 7 / 8: (mean, rstd) per row of A, [round_up(M, 256)][2] fp32
+    const float* __restrict__ rowstats = nullptr;   // act 7 / 8: (mean, rstd) per row of A, [round_up(M, 256) + 256][2] fp32
+    float* __restrict__ partials = nullptr;         // act 9: (sum, sum of squares) per row and 64 output columns, [M][N / 64][2] fp32
 };
 
 // LayerNorm folded into the linear that consumes it (act 7; 8 = + QuickGELU):  LN(x) W^T + b with LN(x) = (x - mu) rstd g + beta
@@ -47,6 +49,65 @@ __device__ __forceinline__ float ln_fold(float acc, float mu, float rstd, float 
     return fmaf(rstd, fmaf(-mu, cs, acc), bf);
 }
 
+// ---- row statistics in ONE association order, whoever produces them -------------------------------------------------------------
+// The (mean, rstd) pairs ln_fold consumes come from (sum, sum of squares) of the row's fp16 values.  They are produced either by
+// the standalone pass (row_stats_kernel: reads x) or, for free, by the epilogue of the residual GEMM that writes x (act 9: the
+// row-major store pass already holds the final values) — as PARTIALS per 64 columns, finished by stats_finalize_kernel.  A row's
+// statistics must not depend on the producer (a row alone == the row in a batch, ring kernel == persistent kernel, any tile
+// width), so the association order is fixed:
+//   chunk (8 consecutive columns): v_dot2_f32_f16 chains over its four column pairs, in column order;
+//   64-column group: butterfly over its 8 chunks (xor 1, 2, 4); 256-column block: the tree (g0 + g1) + (g2 + g3) of its groups
+//   (= the butterfly continued with xor 8, 16: fp32 addition commutes, so every lane of the butterfly holds the tree's value);
+//   row: the blocks added left to right.
+// The GEMM epilogues write one partial per 64-column group whatever their tile width (three butterfly levels inside 8 lanes,
+// one 8-byte store per row segment and group); stats_finalize_kernel and row_stats_kernel continue the same tree.
+__device__ __forceinline__ void stats_chunk(const half8_t& h, float& s, float& q) {
+    // two columns per instruction, straight from the packed halves: v_dot2_f32_f16 (fp32 accumulate), pairs in column order
+    const half2_t one = {(half_t)1.f, (half_t)1.f};
+    s = 0.f;
+    q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const half2_t p = {h[j], h[j + 1]};
+#if defined(__HIP_DEVICE_COMPILE__)
+        s = __builtin_amdgcn_fdot2(p, one, s, false);
+        q = __builtin_amdgcn_fdot2(p, p, q, false);
+#endif
+    }
+}
+// One butterfly level on the VALU (DPP / v_permlane16_swap) instead of a ds_bpermute through the LDS pipe (as __shfl_xor compiles:
+// 320 of them per tile made the act-9 epilogue cost what the statistics pass it replaces cost).  Levels 4 and 8 use the mirror
+// patterns: after the lower levels every lane of an aligned group holds the group's sum (identical bits: a + b == b + a), so
+// "lane 7 - i" / "lane 15 - i" supply exactly the partner group's value that "lane i ^ 4" / "lane i ^ 8" would.
+template <int OFF>
+__device__ __forceinline__ float stats_level(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int iv = __builtin_bit_cast(int, v);
+    if (OFF == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)iv, (unsigned)iv, false, false);   // {own, partner row} / {partner row, own}
+        const unsigned a = r[0], b = r[1];
+        return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+    }
+    constexpr int ctrl = OFF == 1 ? 0xB1 : OFF == 2 ? 0x4E : OFF == 4 ? 0x141 : 0x140;   // quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, ctrl, 0xF, 0xF, false));
+#else
+    return v;
+#endif
+}
+template <int LANES>   // 8, 16 or 32 consecutive lanes hold the chunks of one row segment
+__device__ __forceinline__ void stats_butterfly(float& s, float& q) {
+    s = stats_level<1>(s); q = stats_level<1>(q);
+    s = stats_level<2>(s); q = stats_level<2>(q);
+    s = stats_level<4>(s); q = stats_level<4>(q);
+    if (LANES >= 16) { s = stats_level<8>(s); q = stats_level<8>(q); }
+    if (LANES >= 32) { s = stats_level<16>(s); q = stats_level<16>(q); }
+}
+__device__ __forceinline__ float2_t stats_from_sums(float s, float q, int D, float eps) {
+    const float mean = s / (float)D;
+    const float var = fmaxf(fmaf(-mean, mean, q / (float)D), 0.f);
+    return float2_t{mean, 1.f / sqrtf(var + eps)};
+}
+
 // QuickGELU with the reference's three fp16 roundings.  exp / reciprocal use the hardware approximations
 // (v_exp_f32, v_rcp_f32: ~1-2 ulp in fp32), far inside the fp16 rounding that follows each step.
 __device__ __forceinline__ float quick_gelu16(float v) {
@@ -57,7 +118,6 @@ __device__ __forceinline__ float quick_gelu16(float v) {
 
 // Four at a time with packed fp16 instructions where the arithmetic IS fp16: the two conversions are v_cvt_pk_f16_f32 and the
 // final product h * s of two fp16 values is one correctly rounded v_pk_mul_f16 (= r16 of the exact fp32 product).
-typedef float float2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ half4_t quick_gelu16x4(float4_t v) {
     const half2_t h01 = __builtin_convertvector(float2_t{v[0], v[1]}, half2_t), h23 = __builtin_convertvector(float2_t{v[2], v[3]}, half2_t);
     const half_t h[4] = {h01[0], h01[1], h23[0], h23[1]};
@@ -103,9 +163,11 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
                                                                      const float* __restrict__ shift,
                                                                      half_t* Cout, int ldc, int tiles_n,
                                                                      int ntiles, const half_t* residual = nullptr,
-                                                                     const float* __restrict__ rowstats = nullptr) {
+                                                                     const float* __restrict__ rowstats = nullptr,
+                                                                     float* __restrict__ partials = nullptr) {
     // ACT 5: relu(r16(r16(r16(acc) * scale + shift) + residual)) — bn3 + `out += identity` + ReLU of a bottleneck (clip/model.py:49-52)
     // in the epilogue of its conv3 GEMM; the residual rows are read row-major in the coalesced store pass.
+    // ACT 9: ACT 6 + the row-statistics partials of the updated rows (stats_chunk / stats_butterfly) into `partials` [M][N/64][2]
     // ACT 6: r16(residual + r16(acc + bias)) — `x = x + attn(..)` / `x = x + mlp(..)` of a transformer block (clip/model.py:188-189)
     // in the epilogue of out_proj / c_proj; Cout may BE residual (the residual stream is updated in place: every 16-byte chunk is
     // read and then written by the same thread)
@@ -168,7 +230,8 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         } else
             pgemm::stage_first<C>(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, smem, p);
     }
-    constexpr int YOUNGER = C::NH * C::NPASS + (AFFINE ? 2 : (HAS_BIAS ? 1 : 0)) + NSTAT;
+    constexpr int PST = ACT == 9 ? 1 : 0;                                     // act 9: one store of statistics partials per pass
+    constexpr int YOUNGER = C::NH * C::NPASS * (1 + PST) + (AFFINE ? 2 : (HAS_BIAS ? 1 : 0)) + NSTAT;
     bool prev_full = false;
     int parity = 0;
     unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -282,7 +345,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         // the slab is staged (they fly during the LDS write pass) — Cout may alias residual (in-place residual stream), so the
         // compiler cannot hoist a later pass's load above an earlier pass's store by itself: load -> wait -> store per pass was
         // 16 dependent round trips per tile.
-        constexpr bool RES = ACT == 5 || ACT == 6;
+        constexpr bool RES = ACT == 5 || ACT == 6 || ACT == 9;
         half8_t rr[RES ? C::NPASS : 1];
         auto slab = [&](int h) {
             if (!RES) return;
@@ -301,6 +364,16 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             }
             return h;
         };
+        // act 9: (sum, sum of squares) of the row segment this tile covers, from the values just stored; the CPR lanes of a row are
+        // consecutive, lane c == 0 of each writes the segment's slots (every lane takes part in the butterfly: `valid` only
+        // predicates the store)
+        auto put_partials = [&](int r, int c, const half8_t& hv, bool valid) {
+            float ps, pq;
+            stats_chunk(hv, ps, pq);
+            stats_butterfly<8>(ps, pq);                        // the 8 lanes of a 64-column group
+            if (valid && (c & 7) == 0)
+                *reinterpret_cast<float2_t*>(partials + ((size_t)(m0 + r) * (N >> 6) + (n0 >> 6) + (c >> 3)) * 2) = float2_t{ps, pq};
+        };
 #if (PCLIP_ABL & 4) && defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
         for (int i = 0; i < C::TM; ++i)
@@ -310,14 +383,18 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
 #else
         if (full)
 #endif
-            pgemm::epilogue_f16<C, M16>(acc, stg, slab, pre, [&](int r, int, int pass, half8_t h) {
+            pgemm::epilogue_f16<C, M16>(acc, stg, slab, pre, [&](int r, int c, int pass, half8_t h) {
                 const size_t o = (size_t)(m0 + r) * ldc + col;
-                st_out(Cout + o, RES ? add_res(pass, h) : h);
+                if (RES) h = add_res(pass, h);
+                st_out(Cout + o, h);
+                if (ACT == 9) put_partials(r, c, h, true);
             });
         else
-            pgemm::epilogue_f16<C, M16>(acc, stg, slab, pre, [&](int r, int, int pass, half8_t h) {
+            pgemm::epilogue_f16<C, M16>(acc, stg, slab, pre, [&](int r, int c, int pass, half8_t h) {
                 const size_t o = (size_t)(m0 + r) * ldc + col;
-                if (m0 + r < M) st_out(Cout + o, RES ? add_res(pass, h) : h);
+                if (RES) h = add_res(pass, h);
+                if (m0 + r < M) st_out(Cout + o, h);
+                if (ACT == 9) put_partials(r, c, h, m0 + r < M);
             });
         prev_full = full;
     }
@@ -485,7 +562,7 @@ static int launch_fast2(const void* A, int lda, const void* B, int ldb, int M, i
     const int grid = ntiles < slots ? ntiles : slots;
     linear_fast_kernel<C, HAS_BIAS, ACT, M16><<<grid, C::NTHREADS, LDS, s>>>(
         (const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi.bias, epi.scale, epi.shift, epi.C, epi.ldc, tiles_n, ntiles, epi.residual,
-        epi.rowstats);
+        epi.rowstats, epi.partials);
     return pclip_check_launch("gemm_f16");
 }
 
@@ -498,6 +575,7 @@ static int launch_fast_m(const void* A, int lda, const void* B, int ldb, int M, 
     if (epi.act == 3) return launch_fast2<C, false, 3, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
     if (epi.act == 5) return launch_fast2<C, false, 5, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
     if (epi.act == 6) return launch_fast2<C, true, 6, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
+    if (epi.act == 9) return launch_fast2<C, true, 9, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
     if (epi.act == 7) return launch_fast2<C, false, 7, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
     if (epi.act == 8) return launch_fast2<C, false, 8, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
     if (epi.bias) {
@@ -601,50 +679,61 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
 // (mean, rstd) of every row, the statistics of layernorm_kernel (same two-pass fp32 arithmetic, same reduction order): what is
 // left of a LayerNorm whose affine part has been folded into the consuming linear (ln_fold).  One wave per row: the values do not
 // depend on how many rows the call carries.
-// v: the row's values (fp16-representable floats), lane-major chunks of 8 as every row kernel here holds them
+// v: the row's values (fp16-representable floats), lane-major chunks of 8 as every row kernel here holds them (chunk c*64 + lane =
+// columns c*512 + 8*lane ..): the canonical (sum, sum of squares) of the row (see stats_chunk) and from them (mean, rstd).
+// Lanes 0-31 / 32-63 of chunk set c are the 256-column blocks 2c / 2c+1; columns >= D contribute exact zeros.
 template <int NCH>
-__device__ __forceinline__ void row_mean_rstd(const float (&v)[NCH][8], int D, int lane, float eps, float& mean, float& rstd) {
-    float s = 0.f;
+__device__ __forceinline__ float2_t row_mean_rstd(const half8_t (&hv)[NCH], int D, int lane, float eps) {
+    float S = 0.f, Q = 0.f;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
-        if (c * 512 + lane * 8 < D) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s += v[c][j];
-        }
-    mean = wave_sum(s) / (float)D;
-    float q = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-        if (c * 512 + lane * 8 < D) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float t = v[c][j] - mean; q += t * t; }
-        }
-    rstd = 1.f / sqrtf(wave_sum(q) / (float)D + eps);
+    for (int c = 0; c < NCH; ++c) {
+        float s = 0.f, q = 0.f;
+        if (c * 512 + lane * 8 < D) stats_chunk(hv[c], s, q);
+        stats_butterfly<32>(s, q);
+        const float s0 = __shfl(s, 0, WAVE), q0 = __shfl(q, 0, WAVE), s1 = __shfl(s, 32, WAVE), q1 = __shfl(q, 32, WAVE);
+        if (c * 512 < D) { S += s0; Q += q0; }
+        if (c * 512 + 256 < D) { S += s1; Q += q1; }
+    }
+    return stats_from_sums(S, Q, D, eps);
 }
 
+// (mean, rstd) of every row: what is left of a LayerNorm whose affine part has been folded into the consuming linear (ln_fold).
+// One wave per row: the values do not depend on how many rows the call carries, and they are the values stats_finalize_kernel
+// derives from the partials a residual GEMM wrote (same association order, stats_chunk).
 template <int NCH>
 __global__ __launch_bounds__(256) void row_stats_kernel(const half_t* __restrict__ x, int ld_x, float eps, float* __restrict__ stats, int R,
                                                         int D) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
         const half_t* xr = x + (size_t)row * ld_x;
-        float v[NCH][8];
+        half8_t hv[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int d = c * 512 + lane * 8;
-            if (d < D) {
-                half8_t h = ld_half8(xr + d);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[c][j] = (float)h[j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
-            }
+            if (d < D) hv[c] = ld_half8(xr + d);
         }
-        float mean, rstd;
-        row_mean_rstd<NCH>(v, D, lane, eps, mean, rstd);
-        if (lane == 0) *reinterpret_cast<float2_t*>(stats + (size_t)row * 2) = float2_t{mean, rstd};
+        const float2_t ms = row_mean_rstd<NCH>(hv, D, lane, eps);
+        if (lane == 0) *reinterpret_cast<float2_t*>(stats + (size_t)row * 2) = ms;
     }
+}
+
+// partials [R][D / 64][2] (sum, sum of squares per 64 columns, written by the act-9 epilogues) -> stats [R][2] = (mean, rstd):
+// per 256-column block the tree (g0 + g1) + (g2 + g3), blocks left to right.  One thread per row.
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ partials, int R, int D, float eps,
+                                                             float* __restrict__ stats) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= R) return;
+    const int ns = D >> 6;
+    const float2_t* p = reinterpret_cast<const float2_t*>(partials) + (size_t)row * ns;
+    float S = 0.f, Q = 0.f;
+    for (int b = 0; b < ns; b += 4) {
+        float2_t g[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = b + k < ns ? p[b + k] : float2_t{0.f, 0.f};
+        S += (g[0][0] + g[1][0]) + (g[2][0] + g[3][0]);
+        Q += (g[0][1] + g[1][1]) + (g[2][1] + g[3][1]);
+    }
+    *reinterpret_cast<float2_t*>(stats + (size_t)row * 2) = stats_from_sums(S, Q, D, eps);
 }
 
 // Wf[n, :] = r16(gamma . W[n, :]),  colsum[n] = sum_k Wf[n, k] (of the ROUNDED values: it cancels the mean against exactly the
@@ -1255,20 +1344,19 @@ __global__ __launch_bounds__(256) void vit_embed_ln_kernel(const half_t* __restr
             }
         }
         ln_row_inplace<NCH>(v, W, lane, g0, b0, eps);
+        half8_t xh[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int d = c * 512 + lane * 8;
             if (d < W) {
-                half8_t o;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (half_t)v[c][j];
-                st_half8(x0 + row * W + d, o);
+                for (int j = 0; j < 8; ++j) xh[c][j] = (half_t)v[c][j];
+                st_half8(x0 + row * W + d, xh[c]);
             }
         }
         if (stats) {                                         // the first block's ln_1 is folded into its in_proj: (mean, rstd) of x0 instead of h
-            float mean, rstd;
-            row_mean_rstd<NCH>(v, W, lane, eps, mean, rstd);
-            if (lane == 0) *reinterpret_cast<float2_t*>(stats + row * 2) = float2_t{mean, rstd};
+            const float2_t ms = row_mean_rstd<NCH>(xh, W, lane, eps);
+            if (lane == 0) *reinterpret_cast<float2_t*>(stats + row * 2) = ms;
         }
         if (!h) continue;
         ln_row_inplace<NCH>(v, W, lane, g1, b1, eps);
@@ -1336,8 +1424,9 @@ constexpr int kNumCfgs = 5;
 constexpr TileCfg kTileCfgs[kNumCfgs] = {{128, 128, 2, 0.85}, {256, 128, 1, 0.85}, {256, 256, 1, 1.0}, {256, 64, 1, 0.6}, {256, 32, 2, 0.4}};
 constexpr double kLaunchCost = 0.5;          // extra launch of a split, in the same units
 
+thread_local int g_min_bn = 0;               // act 9 (statistics partials per 64 columns): tiles narrower than 64 columns are excluded
 inline double tile_cost(const TileCfg& c, long M, int N, int cus) {
-    if (N % c.bn) return 1e30;
+    if (N % c.bn || c.bn < g_min_bn) return 1e30;
     const long slots = (long)c.wg_per_cu * cus, nt = ((M + c.bm - 1) / c.bm) * (N / c.bn);
     return (double)((nt + slots - 1) / slots) * (c.bm / 128.0) * (c.bn / 128.0) * c.wg_per_cu / c.eff;
 }
@@ -1358,15 +1447,17 @@ int launch_small_one(const half_t* A, int lda, const half_t* B, int ldb, int M, 
 
 int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int N, int K, LinearEpi epi, int cus, int forced,
                   bool may_split, hipStream_t s) {
-    const bool aligned = (!epi.residual || ((epi.act == 5 || epi.act == 6) && ((uintptr_t)epi.residual & 15) == 0)) && epi.ldc % 8 == 0 && ((uintptr_t)epi.C & 15) == 0 &&
+    struct MinBn { int old; MinBn(int v) : old(g_min_bn) { g_min_bn = v; } ~MinBn() { g_min_bn = old; } } min_bn(epi.act == 9 ? 64 : 0);
+    const bool aligned = (!epi.residual || ((epi.act == 5 || epi.act == 6 || epi.act == 9) && ((uintptr_t)epi.residual & 15) == 0)) && epi.ldc % 8 == 0 && ((uintptr_t)epi.C & 15) == 0 &&
                          (!epi.bias || ((uintptr_t)epi.bias & 15) == 0);
     static const bool small_on = !(getenv("PCLIP_GEMM_SMALL") && getenv("PCLIP_GEMM_SMALL")[0] == '0');
-    if (aligned && forced == -1 && small_on && (epi.act <= 1 || epi.act == 6 || (((uintptr_t)epi.scale | (uintptr_t)epi.shift) & 15) == 0) && small_applies(M, N, cus))
+    if (aligned && forced == -1 && small_on && (epi.act <= 1 || epi.act == 6 || epi.act == 9 || (((uintptr_t)epi.scale | (uintptr_t)epi.shift) & 15) == 0) && small_applies(M, N, cus))
         return launch_small_one(A, lda, B, ldb, M, N, K, epi, s);
     double cost = 1e30;
     int pick = aligned ? best_cfg(M, N, cus, &cost) : -1;
     if (forced == -2) { may_split = false; pick = -1; }        // generic kernel
     if (epi.act == 5 && pick < 0) { pclip_set_error("pclip_gemm_bn_res_f16: N=%d / alignment not supported by the fused epilogue", N); return PCLIP_E_INVALID; }
+    if (epi.act == 9 && pick < 0) { pclip_set_error("pclip_gemm_res_stats_f16: N=%d / alignment not supported by the fused epilogue", N); return PCLIP_E_INVALID; }
     if (epi.act >= 7 && pick < 0) { pclip_set_error("pclip_gemm_ln_f16: N=%d / alignment not supported by the fused epilogue", N); return PCLIP_E_INVALID; }
     if (forced >= 0) {
         may_split = false;
@@ -1393,6 +1484,7 @@ int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int
             tail.C = epi.C + (size_t)split_rows * epi.ldc;
             if (epi.residual) tail.residual = epi.residual + (size_t)split_rows * epi.ldc;   // act 5 / 6: same row stride as C
             if (epi.rowstats) tail.rowstats = epi.rowstats + (size_t)split_rows * 2;         // act 7 / 8 (split_rows is a multiple of 128: 16-byte aligned)
+            if (epi.partials) tail.partials = epi.partials + (size_t)split_rows * (N / 64) * 2;   // act 9
             return gemm_dispatch(A + (size_t)split_rows * lda, lda, B, ldb, M - (int)split_rows, N, K, tail, cus, -1, true, s);
         }
     }
@@ -1434,6 +1526,22 @@ extern "C" int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, vo
         g_m16 = !(getenv("PCLIP_GEMM_M16") != nullptr && getenv("PCLIP_GEMM_M16")[0] == '0');
     }
     return gemm_dispatch((const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, cus, forced, !nosplit, (hipStream_t)stream);
+}
+
+// x += A W^T + bias in place of C = residual (pclip_gemm_f16 with `residual`), and the statistics partials of the updated rows.
+extern "C" int pclip_gemm_res_stats_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                                        const void* bias, const void* residual, float* partials, pclip_stream_t stream) {
+    PCLIP_REQUIRE(A && B && C && bias && residual && partials, "pclip_gemm_res_stats_f16: null pointer");
+    PCLIP_REQUIRE(M >= 0 && N > 0 && K > 0, "pclip_gemm_res_stats_f16: bad shape M=%d N=%d K=%d", M, N, K);
+    PCLIP_REQUIRE(K % pgemm::BK == 0 && N % 64 == 0, "pclip_gemm_res_stats_f16: K=%d / N=%d must be multiples of 64", K, N);
+    PCLIP_REQUIRE(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0, "pclip_gemm_res_stats_f16: bad leading dims");
+    PCLIP_REQUIRE((((uintptr_t)C | (uintptr_t)residual | (uintptr_t)bias | (uintptr_t)partials) & 15) == 0, "pclip_gemm_res_stats_f16: operands must be 16-byte aligned");
+    if (M == 0) return PCLIP_OK;
+    LinearEpi epi{(const half_t*)bias, (const half_t*)residual, (half_t*)C, ldc, 9, nullptr, nullptr, nullptr, partials};
+    int cus = pclip_device_cus();
+    if (cus <= 0) cus = 256;
+    static const bool nosplit = getenv("PCLIP_GEMM_NOSPLIT") != nullptr;
+    return gemm_dispatch((const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, cus, -1, !nosplit, (hipStream_t)stream);
 }
 
 // LayerNorm folded into the linear that consumes it (see ln_fold): y = act(LN(x) W^T + b) from the un-normalised rows x, their
@@ -1478,7 +1586,8 @@ __global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void linear_small_kernel(con
                                                                            const float* __restrict__ scale,
                                                                            const float* __restrict__ shift,
                                                                            const half_t* residual = nullptr,
-                                                                           const float* __restrict__ rowstats = nullptr) {
+                                                                           const float* __restrict__ rowstats = nullptr,
+                                                                           float* __restrict__ partials = nullptr) {
     using C = CfgSplit;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = blockIdx.x / S, ks = blockIdx.x - tile * S;
@@ -1536,10 +1645,10 @@ __global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void linear_small_kernel(con
             return h;
         };
         // slot 0 of the ring is the staging buffer: the epilogue's first barrier comes after every wave's last K-tile
-        pgemm::epilogue_f16<C, true>(acc, smem, [](int) {}, pre, [&](int r, int, int, half8_t h) {
-            if (m0 + r >= M) return;
+        pgemm::epilogue_f16<C, true>(acc, smem, [](int) {}, pre, [&](int r, int c, int, half8_t h) {
+            const bool valid = m0 + r < M;
             const size_t o = (size_t)(m0 + r) * ldc + col;
-            if (ACT == 5 || ACT == 6) {
+            if ((ACT == 5 || ACT == 6 || ACT == 9) && valid) {
                 const half8_t rr = ld_half8(residual + o);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -1547,7 +1656,13 @@ __global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void linear_small_kernel(con
                     h[j] = (half_t)(ACT == 5 ? fmaxf(y, 0.f) : y);
                 }
             }
-            st_half8(Cout + o, h);
+            if (valid) st_half8(Cout + o, h);
+            if (ACT == 9) {                                  // statistics partials of the updated row segment: as linear_fast_kernel (CPR = 8: one slot)
+                float ps, pq;
+                stats_chunk(h, ps, pq);
+                stats_butterfly<8>(ps, pq);
+                if (valid && c == 0) *reinterpret_cast<float2_t*>(partials + ((size_t)(m0 + r) * (N >> 6) + (n0 >> 6)) * 2) = float2_t{ps, pq};
+            }
         });
         return;
     }
@@ -1646,7 +1761,7 @@ inline int small_attr() {
     if (!done.done()) {
         const void* fns[] = {(const void*)linear_small_kernel<0>, (const void*)linear_small_kernel<1>, (const void*)linear_small_kernel<2>,
                              (const void*)linear_small_kernel<3>, (const void*)linear_small_kernel<5>, (const void*)linear_small_kernel<6>,
-                             (const void*)linear_small_kernel<7>, (const void*)linear_small_kernel<8>, (const void*)conv3x3_small_kernel<2>, (const void*)conv3x3_small_kernel<3>};
+                             (const void*)linear_small_kernel<7>, (const void*)linear_small_kernel<8>, (const void*)linear_small_kernel<9>, (const void*)conv3x3_small_kernel<2>, (const void*)conv3x3_small_kernel<3>};
         for (const void* f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kSmallLds) != hipSuccess) {
                 pclip_set_error("gemm_f16 (small M): cannot raise the dynamic LDS limit to %d", kSmallLds);
@@ -1667,8 +1782,9 @@ int launch_small_one(const half_t* A, int lda, const half_t* B, int ldb, int M, 
     ++g_gemm_launches;
 #define PCLIP_SMALL_LAUNCH(ACT)                                                                                                          \
     linear_small_kernel<ACT><<<grid, CfgSplit::NTHREADS, kSmallLds, s>>>(A, lda, B, ldb, M, N, K, tiles_n, 1, steps, nullptr, epi.bias, epi.C, \
-                                                                        epi.ldc, epi.scale, epi.shift, epi.residual, epi.rowstats)
+                                                                        epi.ldc, epi.scale, epi.shift, epi.residual, epi.rowstats, epi.partials)
     if (epi.act == 5) PCLIP_SMALL_LAUNCH(5);
+    else if (epi.act == 9) PCLIP_SMALL_LAUNCH(9);
     else if (epi.act == 7) PCLIP_SMALL_LAUNCH(7);
     else if (epi.act == 8) PCLIP_SMALL_LAUNCH(8);
     else if (epi.act == 6) PCLIP_SMALL_LAUNCH(6);
@@ -1849,6 +1965,14 @@ extern "C" int pclip_row_stats_f16(const void* x, int ld_x, float eps, float* st
     hipStream_t s = (hipStream_t)stream;
     DISPATCH_NCH(D, (row_stats_kernel<NCH><<<row_grid(R), 256, 0, s>>>((const half_t*)x, ld_x, eps, stats, R, D)));
     return pclip_check_launch("row_stats_f16");
+}
+
+extern "C" int pclip_row_stats_finalize(const float* partials, int R, int D, float eps, float* stats, pclip_stream_t stream) {
+    PCLIP_REQUIRE(partials && stats, "pclip_row_stats_finalize: null pointer");
+    PCLIP_REQUIRE(R >= 0 && D > 0 && D % 64 == 0, "pclip_row_stats_finalize: bad R=%d D=%d", R, D);
+    if (R == 0) return PCLIP_OK;
+    stats_finalize_kernel<<<ceil_div(R, 256), 256, 0, (hipStream_t)stream>>>(partials, R, D, eps, stats);
+    return pclip_check_launch("row_stats_finalize");
 }
 
 extern "C" int pclip_ln_fold_weights_f16(const void* W, int ldw, int N, int K, const float* gamma, const float* beta, const void* bias,

@@ -415,6 +415,37 @@ def row_stats(x, eps: float = 1e-5, rows: int = None, ld: int = None):
     return stats
 
 
+def gemm_res_partials(a, w, bias, x):
+    """x += a @ w^T + bias IN PLACE and returns the statistics partials [M, N/64, 2] fp32 its epilogue wrote (pclip_gemm_res_stats_f16)."""
+    M, K = a.shape
+    N = w.shape[0]
+    partials = torch.empty(M, N // 64, 2, dtype=torch.float32, device=x.device)
+    check(_lib.load().pclip_gemm_res_stats_f16(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(x), x.stride(0), M, N, K, ptr(bias), ptr(x),
+                                               ptr(partials), stream()), "pclip_gemm_res_stats_f16")
+    return partials
+
+
+def finalize_stats(partials, eps: float = 1e-5):
+    """partials [R, D/64, 2] -> `row_stats`-shaped (mean, rstd) buffer (pclip_row_stats_finalize)."""
+    R, D = partials.shape[0], partials.shape[1] * 64
+    stats = torch.empty(stats_rows(R), 2, dtype=torch.float32, device=partials.device)
+    check(_lib.load().pclip_row_stats_finalize(ptr(partials), R, D, eps, ptr(stats), stream()), "pclip_row_stats_finalize")
+    return stats
+
+
+def gemm_res_stats(a, w, bias, x, eps: float = 1e-5):
+    """x += a @ w^T + bias IN PLACE (the residual add of clip/model.py:188-189 in the GEMM epilogue) and returns the `row_stats` of
+    the updated x, produced by that same epilogue (partials per 64 columns) + one tiny finishing launch — bit-identical to
+    `row_stats(x)` afterwards.  Returns None (after doing the add) when the shape has no fused form; the caller then takes
+    `row_stats`."""
+    require_cuda(a, w, bias, x)
+    N = w.shape[0]
+    if N % 64 or x.stride(0) % 8 or (x.data_ptr() | bias.data_ptr()) & 15 or a.stride(0) % 8 or w.stride(0) % 8:
+        gemm(a, w, bias, residual=x, out=x)
+        return None
+    return finalize_stats(gemm_res_partials(a, w, bias, x), eps)
+
+
 def gemm_ln(x, stats, wf, colsum, bfold, act: int = 0, out=None):
     """out = act(LayerNorm(x) @ W^T + b) from the un-normalised rows x, their `row_stats` and `ln_fold_weights(W, b, gamma, beta)`."""
     require_cuda(x, stats, wf, colsum, bfold)

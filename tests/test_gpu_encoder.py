@@ -223,6 +223,34 @@ def test_gemm_ln_fold(ops, M, N, K, act):
         assert torch.equal(yb, y[100:300])
 
 
+@pytest.mark.parametrize("M,N,K", [(197, 768, 768), (1, 768, 3072), (5000, 768, 768), (50432, 768, 64), (3000, 1024, 256), (70001, 512, 64),
+                                   (900, 64, 128), (2600, 192, 64), (1386, 128, 512), (201728, 768, 64)])
+def test_gemm_res_stats_epilogue(ops, M, N, K):
+    """x += a W^T + b with the row statistics of the updated x out of the same epilogue (pclip_gemm_res_stats_f16 +
+    pclip_row_stats_finalize): x is EXACTLY what pclip_gemm_f16 with a residual writes, and the statistics are EXACTLY
+    pclip_row_stats_f16 of it — for the persistent kernel in every tile width (256 / 128 / 64 columns), the row-split second
+    launch, and the ring kernel; and they are the row's mean / rstd."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = (torch.randn(M, K, device="cuda", generator=g) * 0.7).half()
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).half()
+    b = (torch.randn(N, device="cuda", generator=g) * 0.1).half()
+    x0 = (torch.randn(M, N, device="cuda", generator=g) * 1.5 + 0.4).half()
+    ref = x0.clone()
+    ops.gemm(a, w, b, residual=ref, out=ref)
+    x = x0.clone()
+    st = ops.gemm_res_stats(a, w, b, x)
+    assert st is not None and torch.equal(x, ref)
+    want = ops.row_stats(ref)
+    assert torch.equal(st[:M], want[:M])
+    xf = ref.float()
+    torch.testing.assert_close(st[:M, 0], xf.mean(1), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(st[:M, 1], 1.0 / torch.sqrt(xf.var(1, unbiased=False) + 1e-5), rtol=2e-5, atol=0)
+    r = M // 2                                               # a row alone (ring kernel) == the row in the batch
+    x1 = x0[r:r + 1].clone()
+    s1 = ops.gemm_res_stats(a[r:r + 1].contiguous(), w, b, x1)
+    assert torch.equal(x1[0], ref[r]) and torch.equal(s1[0], st[r])
+
+
 def test_vit_embed_stats_matches_row_stats(ops):
     """pclip_vit_embed_ln_f16 in its statistics form (first block's ln_1 folded): x0 identical to the ln_1 form, statistics
     identical to pclip_row_stats_f16 of x0."""
