@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Residual GEMM with and without the row-statistics epilogue (act 6 vs act 9), and ablations of act 9 built with -DPCLIP_ABL9=N
-(proto-clip_amd/libpclip_r9_<N>.so: 1 no partial stores, 2 no statistics arithmetic), on the bench's two residual shapes."""
+"""Residual GEMM with and without the row-statistics epilogue (act 6 vs act 9) on the bench's two residual shapes; any
+proto-clip_amd/libpclip_r9_<tag>.so next to the library is timed as a further act-9 variant (the ablation builds behind
+profiles/r02_ab_res_stats_ablation.txt — no partial stores / no statistics arithmetic — were compile-time edits of put_partials)."""
 import ctypes, glob, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kernel_bench import timeit
