@@ -256,7 +256,7 @@ def main():
             "config": {"workload": "C3 ImageNet 16-shot ViT-B/16 conv-3x: prototype reduce + encode_image + adapter + dual-bank classify",
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "classes": N_CLASS, "shots": SHOTS, "embed_dim": DIM,
                        "alpha": ALPHA, "beta": BETA, "parallelism": f"dp{world} (support rows and queries sharded; all-gather of class sums)"},
-            "roofline": {"bound": "mfma", "kernel": "linear_fast_kernel + linear_small_kernel (fp16 MFMA GEMM: every encoder linear incl. patch embedding and projection; the class-row tail runs the small-M variant)",
+            "roofline": {"bound": "mfma", "kernel": "linear_fast_kernel + linear_small_kernel (fp16 MFMA GEMM: every encoder linear incl. patch embedding and projection, with the LayerNorm correction / QuickGELU / residual add / row statistics of the block in its epilogue; the class-row tail runs the small-M variant)",
                          "achieved": gm["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gm["tflops"] / MFMA_PEAK_TFLOPS,
                          "traffic": pmc_traffic(), "traffic_unit": "HBM bytes per launch (profiles/r02_pmc_traffic.json)",
                          "launches_per_step": gm["launches"], "avg_launch_us": gm["avg_us"],
