@@ -55,9 +55,14 @@ def build_state(device, rank, world):
     lo, hi = shard_bounds(N_CLASS * SHOTS, rank, world)                   # this rank's slab of the support set
     st = dict(model=model, adapter=adapter, bank=bank_rows[lo:hi].to(device), bank_labels=labels[lo:hi].to(device),
               text=ops.l2norm_rows(split.textual_memory_bank.t().contiguous().to(device)))
-    # synthetic pre-processed images, fp32 like the reference's loader output; distinct seed per rank
-    imgs = synth.make_images(64, 224, seed=100 + rank, n_class=N_CLASS)
-    st["images"] = imgs.repeat(BATCH // 64, 1, 1, 1).to(device).contiguous()
+    # synthetic pre-processed images, fp32 like the reference's loader output: BATCH DISTINCT images (the GEMMs run at a
+    # data-dependent power cap, so a tiled batch is not a neutral stand-in), distinct seed per rank; generated in chunks on a
+    # few host threads (numpy releases the GIL), each chunk from its own PRNG stream
+    from concurrent.futures import ThreadPoolExecutor
+    chunk = 64
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        parts = list(pool.map(lambda c: synth.make_images(chunk, 224, seed=100 + rank, stream=50 + 2 * c, n_class=N_CLASS), range(BATCH // chunk)))
+    st["images"] = torch.cat(parts).to(device).contiguous()
     return st
 
 
@@ -124,19 +129,35 @@ def measure_gemm(st):
                 tflops=fl / (ms * 1e-3) / 1e12, flops=fl)
 
 
+PMC_TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json")     # newest committed summary first
+
+
 def pmc_traffic():
     """HBM bytes per GEMM launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE x2 + WRITE_SIZE,
     separate passes, gfx950 correction) — counters cannot be read from inside the process, so the committed summary
-    profiles/r02_pmc_traffic.json (tools/gpu_round.sh) is reported; null when it is absent."""
-    path = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return float(json.load(f)["linear_kernel_hbm_bytes_per_launch"])
-    except Exception:
-        return None
+    profiles/rNN_pmc_traffic.json (tools/gpu_pmc.sh) is reported; null when it is absent.  Returns (bytes, file name)."""
+    for name in PMC_TRAFFIC_FILES:
+        try:
+            with open(os.path.join(REPO, "profiles", name)) as f:
+                return float(json.load(f)["linear_kernel_hbm_bytes_per_launch"]), name
+        except Exception:
+            continue
+    return None, None
 
 
-def cpu_baseline(batch=64, budget_s=25.0):
+def measure_clock(st, min_steps=40):
+    """Shader clock and socket power while the step loop runs (proto_clip_amd.telemetry, 50 Hz), in a separate UN-TIMED loop so
+    that the sampling thread cannot touch the timed region.  The GEMMs run at a data-dependent power cap (MI355X_MICROARCH.md,
+    DVFS give-back): the roofline fraction is also stated against the dense peak at the clock the chip actually sustained."""
+    from proto_clip_amd.telemetry import Sampler
+    with Sampler(period=0.02, skip_s=0.3) as s:
+        for _ in range(min_steps):
+            step(st)
+        torch.cuda.synchronize()
+    return s.summary()
+
+
+def cpu_baseline(batch=64, budget_s=32.0):
     """The ORACLE (CPU restatement of the reference path, fp32 model as clip.load(device='cpu') yields)
     timed on the host cores on a bounded sample of the same workload: batches of 64 images, a small sweep of
     torch thread counts (an over-subscribed pool is slower than a well-sized one), best rate reported."""
@@ -165,7 +186,7 @@ def cpu_baseline(batch=64, budget_s=25.0):
 
     ncpu = os.cpu_count() or 1
     prev = torch.get_num_threads()
-    sweep = sorted({t for t in (16, 32, 64, 128, ncpu) if t <= ncpu})
+    sweep = [t for t in (16, 8, 32, 4) if t <= ncpu] or [ncpu]      # the rate peaks at 8 - 16 threads for a batch of 64 and falls on either side
     t_start = time.perf_counter()
     rates = {}
     try:
@@ -173,7 +194,7 @@ def cpu_baseline(batch=64, budget_s=25.0):
             if time.perf_counter() - t_start > budget_s and rates:
                 break
             torch.set_num_threads(nt)
-            run(imgs[:8])                                # warm-up (thread pool, allocator)
+            run(imgs[:4])                                # warm-up (thread pool, allocator)
             t0 = time.perf_counter()
             run(imgs)
             rates[nt] = batch / (time.perf_counter() - t0)
@@ -245,7 +266,11 @@ def main():
         dt = t.item()
 
     gm = measure_gemm(st)          # every rank runs it: the instrumented step contains the all-gather
+    clk = measure_clock(st) if world == 1 else {"source": None}
     if rank == 0:
+        traffic, traffic_file = pmc_traffic()
+        sclk = (clk.get("sclk_mhz") or {}).get("median")
+        power = (clk.get("power_w") or {}).get("median")
         imgs_per_s = args.steps * BATCH * world / dt
         line = {
             "metric": "query images/sec, ImageNet 16-shot ViT-B/16 (few-shot top-1 parity: tests/)",
@@ -253,12 +278,15 @@ def main():
             "rccl_world_size": dist.get_world_size() if launched else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
+            "sclk_mhz_under_load": sclk, "power_w": power,
+            "clock_source": {k: clk.get(k) for k in ("source", "samples", "sclk_mhz", "power_w")},
             "config": {"workload": "C3 ImageNet 16-shot ViT-B/16 conv-3x: prototype reduce + encode_image + adapter + dual-bank classify",
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "classes": N_CLASS, "shots": SHOTS, "embed_dim": DIM,
                        "alpha": ALPHA, "beta": BETA, "parallelism": f"dp{world} (support rows and queries sharded; all-gather of class sums)"},
             "roofline": {"bound": "mfma", "kernel": "linear_fast_kernel + linear_small_kernel (fp16 MFMA GEMM: every encoder linear incl. patch embedding and projection, with the LayerNorm correction / QuickGELU / residual add / row statistics of the block in its epilogue; the class-row tail runs the small-M variant)",
                          "achieved": gm["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gm["tflops"] / MFMA_PEAK_TFLOPS,
-                         "traffic": pmc_traffic(), "traffic_unit": "HBM bytes per launch (profiles/r02_pmc_traffic.json)",
+                         "frac_at_sustained_clock": (gm["tflops"] / (MFMA_PEAK_TFLOPS * sclk / 2400.0)) if sclk else None,
+                         "traffic": traffic, "traffic_unit": f"HBM bytes per launch (profiles/{traffic_file})",
                          "launches_per_step": gm["launches"], "avg_launch_us": gm["avg_us"],
                          "gemm_ms_per_step": gm["total_ms"], "algorithmic_gflop_per_step": gm["flops"] / 1e9},
             "whole_path": {"gflop_per_image": GFLOP_PER_IMG_ENCODER + 0.00452, "achieved_tflops": imgs_per_s / world * (GFLOP_PER_IMG_ENCODER + 0.00452) / 1e3,

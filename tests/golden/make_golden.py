@@ -28,8 +28,8 @@ sys.path.insert(0, REPO)
 from proto_clip_amd import synth                                   # noqa: E402
 from proto_clip_amd.clip.model import random_state_dict            # noqa: E402
 sys.path.insert(0, HERE)
-from spec import (E2E, E2E_CASE, ENCODERS, FEWSHOT, RESNETS, TRAIN, e2e_images, fewshot_inputs, randomize_adapter_,   # noqa: E402
-                  train_inputs)
+from spec import (E2E, E2E_CASE, E2E_VARIANTS, ENCODERS, FEWSHOT, RESNETS, TRAIN, e2e_images, e2e_state_dict, fewshot_inputs,   # noqa: E402
+                  randomize_adapter_, train_inputs)
 
 
 # ---------------------------------------------------------------- Appendix-B shim -----------------
@@ -327,29 +327,31 @@ def make_tokenizer(ref_clip):
 
 
 # ---------------------------------------------------------------- image -> logits chain ------------------
-def make_e2e(ref_main, ref_utils, ref_model, ref_clip_model, scratch):
-    """Images through the reference's whole hot path (utils.py:256-361 bank builders on the reference's CLIP towers, then
+def make_e2e(name, ref_main, ref_utils, ref_model, ref_clip_model, scratch):
+    """Fixture `name` of spec.E2E_VARIANTS (seeded weights / images / adapter; the `trained` ones carry trained-CLIP-like LayerNorm
+    parameters and residual-stream outlier channels, spec.trained_like_).  Images through the reference's whole hot path (utils.py:256-361 bank builders on the reference's CLIP towers, then
     main.py:383-441 via run_proto_clip with a spy on P): support images -> build_cache_model, prompts -> clip_classifier,
     query images -> pre_load_features -> adapter -> normalise -> P.  Run twice: fp16-weight towers (the reference's GPU
     precision) and fp32 towers with the features cast to fp16 (the reference CPU path) — their disagreement is the
     yard-stick the GPU test's tolerance is stated against."""
     from datasets.imagenet import imagenet_classes, imagenet_templates
-    c = E2E_CASE
+    var = E2E_VARIANTS[name]
+    c = var["case"]
     N, K = c["N"], c["K"]
     classnames = [imagenet_classes[i] for i in (0, 1, 2, 21, 15, 43)][:N]
     templates = imagenet_templates[:c["n_templates"]]
-    sd = random_state_dict(seed=17, **E2E)
-    (sup_x, sup_y), (val_x, val_y), (test_x, test_y) = e2e_images()
-    ad = adapter_state(ref_model, c["adapter"], E2E["embed_dim"], seed=9)
+    sd = e2e_state_dict(name)
+    (sup_x, sup_y), (val_x, val_y), (test_x, test_y) = e2e_images(c)
+    ad = adapter_state(ref_model, c["adapter"], E2E["embed_dim"], seed=var["adapter_seed"])
     out = {}
     for tag in ("f16", "f32"):
         with contextlib.redirect_stdout(io.StringIO()):
             m = ref_clip_model.build_model({k: v.clone() for k, v in sd.items()})
         if tag == "f32":
             m = m.float()
-        cfg = dict(shots=K, backbone="ViT-B/16", dataset="synthetic_e2e_" + tag, only_test=True, lr=0.0001, augment_epoch=c["augment_epoch"],
+        cfg = dict(shots=K, backbone="ViT-B/16", dataset="synthetic_" + name + "_" + tag, only_test=True, lr=0.0001, augment_epoch=c["augment_epoch"],
                    train_epoch=1, alpha=c["alpha"], beta=c["beta"], adapter=c["adapter"], train_vis_mem_only=True, losses=["L1"],
-                   cache_dir=os.path.join(scratch, "caches", "e2e_" + tag), logs_dir_path="logs")
+                   cache_dir=os.path.join(scratch, "caches", name + "_" + tag), logs_dir_path="logs")
         with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
             keys, values = ref_utils.build_cache_model(cfg, m, [(sup_x[:10], sup_y[:10]), (sup_x[10:], sup_y[10:])])
             val_f, val_l = ref_utils.pre_load_features(cfg, "val", m, [(val_x, val_y)])
@@ -383,10 +385,10 @@ def make_e2e(ref_main, ref_utils, ref_model, ref_clip_model, scratch):
                     f"acc_{tag}": (p.max(1)[1] == test_l).float().mean().item()})
         if tag == "f16":
             out["values"] = values.to(torch.int16)
-    print("e2e: acc f16 %.3f, f32 %.3f; max|p16 - p32| %.3e; argmax agree %d/%d" % (
-        out["acc_f16"], out["acc_f32"], (out["p_f16"] - out["p_f32"]).abs().max().item(),
+    print("%s: acc f16 %.3f, f32 %.3f; max|p16 - p32| %.3e; argmax agree %d/%d" % (
+        name, out["acc_f16"], out["acc_f32"], (out["p_f16"] - out["p_f32"]).abs().max().item(),
         int((out["argmax_f16"] == out["argmax_f32"]).sum()), len(test_y)))
-    savez("e2e_small", classnames=np.array(classnames), templates=np.array(templates), adapter_keys=np.array(list(ad.state_dict().keys())),
+    savez(name, classnames=np.array(classnames), templates=np.array(templates), adapter_keys=np.array(list(ad.state_dict().keys())),
           **{"adapter__" + k: v for k, v in ad.state_dict().items()}, **out)
 
 
@@ -410,8 +412,9 @@ def main():
             make_resnet(tag, kw, ref_clip_model)
     if todo("tokenizer"):
         make_tokenizer(ref_clip)
-    if todo("e2e"):
-        make_e2e(ref_main, ref_utils, ref_model, ref_clip_model, scratch)
+    for name in E2E_VARIANTS:
+        if todo(name) or "e2e" in want:
+            make_e2e(name, ref_main, ref_utils, ref_model, ref_clip_model, scratch)
 
 
 if __name__ == "__main__":

@@ -24,6 +24,53 @@ E2E = dict(SMALL, vocab_size=49408)
 E2E_CASE = dict(N=6, K=4, Q_val=24, Q_test=48, augment_epoch=2, alpha=0.5, beta=12.0, adapter="conv-3x", n_templates=3, seed=31)
 
 
+# The image -> logits fixtures: name -> (weight seed, case, adapter seed, trained-like LayerNorms / outlier channels).
+# `e2e_small` is round 2's single draw; s1 .. s3 are further seeded draws of the same case (the seeds tests/fold_parity_study.py
+# walks); `e2e_trained` puts the statistics of a TRAINED CLIP on the random towers (trained_like_ below): LayerNorm gains spread over
+# a factor 25, non-zero LayerNorm biases, and a few residual-stream channels that carry ~50 sigma outliers through every block —
+# the regime in which a LayerNorm folded into its linear (r16(gamma * W), one-pass variance, acc - mu * colsum) cancels hardest.
+E2E_VARIANTS = {
+    "e2e_small": dict(sd_seed=17, case=E2E_CASE, adapter_seed=9, trained=False),
+    "e2e_s1": dict(sd_seed=18, case=dict(E2E_CASE, seed=38), adapter_seed=10, trained=False),
+    "e2e_s2": dict(sd_seed=19, case=dict(E2E_CASE, seed=45), adapter_seed=11, trained=False),
+    "e2e_s3": dict(sd_seed=20, case=dict(E2E_CASE, seed=52), adapter_seed=12, trained=False),
+    "e2e_trained": dict(sd_seed=21, case=dict(E2E_CASE, seed=59), adapter_seed=13, trained=True),
+    "e2e_trained2": dict(sd_seed=22, case=dict(E2E_CASE, seed=66), adapter_seed=14, trained=True),
+}
+
+
+def trained_like_(sd, seed, n_outlier=4, outlier=50.0):
+    """In place on a `random_state_dict`: every LayerNorm gets gamma log-uniform in [0.2, 5] and beta ~ N(0, 0.5) (a trained CLIP
+    spans about that range; random init is 1 +- 0.02 / +- 0.02), and `n_outlier` channels of each tower's residual stream get a
+    constant offset of +-`outlier` (about 50 sigma of the other channels) through the out_proj / c_proj biases of the FIRST block,
+    so every later LayerNorm sees rows with a large mean, a variance dominated by four elements, and |x| ~ 50 beside |x| ~ 1."""
+    import math
+    g = torch.Generator().manual_seed(1000 + seed)
+    for k in list(sd):
+        if (".ln_" in k or k.startswith("ln_final") or k.startswith("visual.ln_")) and k.endswith(".weight"):
+            n = sd[k].shape[0]
+            sd[k] = torch.exp(torch.rand(n, generator=g) * (math.log(5.0) - math.log(0.2)) + math.log(0.2))
+            sd[k[:-6] + "bias"] = torch.randn(n, generator=g) * 0.5
+    for prefix in ("visual.transformer.resblocks.0.", "transformer.resblocks.0."):
+        if prefix + "attn.out_proj.bias" not in sd:
+            continue
+        n = sd[prefix + "attn.out_proj.bias"].shape[0]
+        ch = torch.randperm(n, generator=g)[:n_outlier]
+        sign = torch.where(torch.rand(n_outlier, generator=g) < 0.5, -1.0, 1.0)
+        for name in ("attn.out_proj.bias", "mlp.c_proj.bias"):
+            sd[prefix + name] = sd[prefix + name].clone()
+            sd[prefix + name][ch] += 0.5 * outlier * sign
+    return sd
+
+
+def e2e_state_dict(variant):
+    """Seeded weights of an image -> logits fixture (shared by make_golden.py and the tests)."""
+    from proto_clip_amd.clip.model import random_state_dict
+    v = E2E_VARIANTS[variant]
+    sd = random_state_dict(seed=v["sd_seed"], **E2E)
+    return trained_like_(sd, v["sd_seed"]) if v["trained"] else sd
+
+
 def e2e_images(case=E2E_CASE, res=64):
     """Seeded support / val / test image batches (+ labels) of the image -> logits case: K shots per class in shuffled order
     (build_cache_model sorts by label), random query labels."""

@@ -1,0 +1,3 @@
+#!/bin/sh
+# Builds the probe libraries next to their sources (they travel to the GPU box with the snapshot; *.so is git-ignored).
+cd "$(dirname "$0")" && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -shared -fPIC -o libclock_probe.so clock_probe.hip
