@@ -317,6 +317,17 @@ int pclip_nll_grad(const float* d2i, const float* d2t, const int32_t* labels, in
                    float one_minus_alpha, float beta, float* gi, float* gt, float* rowsum, float* nll, float* pmax,
                    int32_t* argmax, pclip_stream_t stream);
 
+/* Backward of P (utils.py:225-244) for an ARBITRARY upstream gradient dp [Q, N] (leading dimension ldp) — the autograd-
+ * transparent `utils.P` the reference's own loop drives (main.py:281-310: NLLLoss(torch.log(p)).backward()): gradients wrt both
+ * squared-distance rows (gi, gt [Q, ldd], columns >= N untouched) and rowsum[q] = sum_c (gi + gt)[q, c]. */
+int pclip_fuse_probs_backward(const float* d2i, const float* d2t, const float* dp, int ldp, int Q, int N, int ldd, float alpha,
+                              float one_minus_alpha, float beta, float* gi, float* gt, float* rowsum, pclip_stream_t stream);
+
+/* Backward of nn.NLLLoss()(torch.log(p), labels) (utils.py:90-93) wrt p: dp[q, c] = -g[0] / (Q p[q, c]) at c == labels[q], else 0;
+ * g = upstream gradient of the scalar loss (device pointer). */
+int pclip_nll_mean_backward(const float* p, int ldp, const int32_t* labels, int Q, int N, const float* g, float* dp, int lddp,
+                            pclip_stream_t stream);
+
 /* The same per-query terms from a materialised p [Q, N] (leading dimension ldp): utils.compute_loss_and_matches as a
  * forward-only drop-in (utils.py:84-93). */
 int pclip_nll_rows(const float* p, int ldp, const int32_t* labels, int Q, int N, float* nll, float* pmax, int32_t* argmax,

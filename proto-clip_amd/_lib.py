@@ -77,6 +77,8 @@ _SIGS = {
     "pclip_addscaled_rows_f32": [_P, c_int, _P, c_int, _P, c_float, c_int, c_int, _P],
     "pclip_nll_grad": [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P, _P],
     "pclip_nll_rows": [_P, c_int, _P, c_int, c_int, _P, _P, _P, _P],
+    "pclip_fuse_probs_backward": [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P],
+    "pclip_nll_mean_backward": [_P, c_int, _P, c_int, c_int, _P, _P, c_int, _P],
     "pclip_softmax_ce_rows": [_P, c_int, c_int, c_int, c_float, _P, c_int, _P, _P],
     "pclip_l2norm_rows_f32": [_P, _P, c_int, c_int, c_float, _P],
     "pclip_l2norm_rows_backward_f32": [_P, _P, _P, c_int, c_int, c_float, c_int, _P],

@@ -26,8 +26,11 @@ extern "C" int pclip_abi_version(void) { return PCLIP_ABI_VERSION; }
 extern "C" const char* pclip_last_error(void) { return g_err; }
 
 extern "C" int pclip_device_cus(void) {
+    static std::atomic<int> cache[64];                     // per device id: the tile dispatch asks on every launch
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < 64 && (cus = cache[dev].load(std::memory_order_relaxed)) > 0) return cus;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < 64) cache[dev].store(cus, std::memory_order_relaxed);
     return cus;
 }

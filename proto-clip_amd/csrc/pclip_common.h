@@ -1,5 +1,6 @@
 // Shared device/host helpers for libpclip (gfx950 only: wave64, MFMA, 160 KiB LDS).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -60,10 +61,10 @@ __device__ __forceinline__ void st_half8(half_t* p, half8_t v) { *reinterpret_ca
 // One-shot flags for per-DEVICE state (hipFuncSetAttribute applies to the current device only): a bit per device id, so a process
 // that drives several GPUs raises the LDS limit on each of them.
 struct DevOnce {
-    unsigned long long mask = 0;
+    std::atomic<unsigned long long> mask{0};             // a host thread per GPU may race here: fetch_or, not a plain |=
     static unsigned long long bit() { int d = 0; (void)hipGetDevice(&d); return 1ull << (d & 63); }
-    bool done() const { return (mask & bit()) != 0; }
-    void set() { mask |= bit(); }
+    bool done() const { return (mask.load(std::memory_order_acquire) & bit()) != 0; }
+    void set() { mask.fetch_or(bit(), std::memory_order_release); }
 };
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

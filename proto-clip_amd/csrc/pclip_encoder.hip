@@ -676,10 +676,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
     }
 }
 
-// (mean, rstd) of every row, the statistics of layernorm_kernel (same two-pass fp32 arithmetic, same reduction order): what is
-// left of a LayerNorm whose affine part has been folded into the consuming linear (ln_fold).  One wave per row: the values do not
-// depend on how many rows the call carries.
-// v: the row's values (fp16-representable floats), lane-major chunks of 8 as every row kernel here holds them (chunk c*64 + lane =
+// (mean, rstd) of a row for a LayerNorm folded into the consuming linear (ln_fold).  NOT layernorm_kernel's arithmetic: that one is
+// two-pass fp32 (mean, then the sum of squared deviations); these are ONE-pass sums (sum, sum of squares) in the canonical
+// association order of stats_chunk / stats_butterfly and var = E[x^2] - mean^2, clamped at 0 — so that the GEMM epilogue that writes
+// x can produce them from the tile it holds.  In fp32 the cancellation costs 2^-24 (E[x^2] / var) relative: measured on rows with
+// a mean of 3 sigma and 50 sigma outlier channels (tests/test_gpu_encoder.py::test_gemm_ln_fold "trained") it stays below 1e-5.
+// hv: the row's values (fp16-representable floats), lane-major chunks of 8 as every row kernel here holds them (chunk c*64 + lane =
 // columns c*512 + 8*lane ..): the canonical (sum, sum of squares) of the row (see stats_chunk) and from them (mean, rstd).
 // Lanes 0-31 / 32-63 of chunk set c are the 256-column blocks 2c / 2c+1; columns >= D contribute exact zeros.
 template <int NCH>
@@ -1511,12 +1513,12 @@ extern "C" int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, vo
     if (M == 0) return PCLIP_OK;
     LinearEpi epi{(const half_t*)bias, (const half_t*)residual, (half_t*)C, ldc, act, nullptr, nullptr};
     if (residual && bias && act == 0) epi.act = 6;              // fused residual epilogue of the persistent / ring kernels
-    static int cus = 0;
+    int cus = pclip_device_cus();                          // per device (a process may drive several GPUs): cached per device id in pclip_api.hip
+    if (cus <= 0) cus = 256;
     static int forced = -1;
-    static bool live = false, nosplit = false;
-    if (!cus || live) {
-        cus = pclip_device_cus();
-        if (cus <= 0) cus = 256;
+    static bool live = false, nosplit = false, init = false;
+    if (!init || live) {
+        init = true;
         const char* f = getenv("PCLIP_GEMM_CFG");          // tuning override: 0 small, 1 wide, 2 big, 3 generic, 4 narrow (256x64)
         forced = f ? atoi(f) : -1;
         if (forced == 3) forced = -2;                       // generic kernel
@@ -1960,7 +1962,7 @@ extern "C" int pclip_layernorm_f16(const void* x, int ld_x, const float* gamma, 
 
 extern "C" int pclip_row_stats_f16(const void* x, int ld_x, float eps, float* stats, int R, int D, pclip_stream_t stream) {
     PCLIP_REQUIRE(x && stats, "pclip_row_stats_f16: null pointer");
-    PCLIP_REQUIRE(R >= 0 && D > 0 && D % 8 == 0 && D <= 2048 && ld_x >= D && ld_x % 8 == 0, "pclip_row_stats_f16: bad R=%d D=%d ld=%d", R, D, ld_x);
+    PCLIP_REQUIRE(R >= 0 && D > 0 && D % 8 == 0 && D <= 4096 && ld_x >= D && ld_x % 8 == 0, "pclip_row_stats_f16: bad R=%d D=%d ld=%d", R, D, ld_x);
     if (R == 0) return PCLIP_OK;
     hipStream_t s = (hipStream_t)stream;
     DISPATCH_NCH(D, (row_stats_kernel<NCH><<<row_grid(R), 256, 0, s>>>((const half_t*)x, ld_x, eps, stats, R, D)));

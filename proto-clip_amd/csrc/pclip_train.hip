@@ -211,6 +211,66 @@ __global__ __launch_bounds__(256) void nll_grad_kernel(const float* __restrict__
     }
 }
 
+// ---- backward of P for an ARBITRARY upstream gradient (the autograd-transparent utils.P) ----------------------------------------
+// p = alpha s_i + oma s_t,  s_x = softmax(-beta d_x)  (utils.py:236-242).  Given dp = dL/dp [Q, N]:
+//   dL/du_x[c] = s_x[c] (w_x dp[c] - sum_k w_x dp[k] s_x[k]),  u_x = -beta d_x  ->  dL/dd_x = -beta dL/du_x
+// whatever loss the caller hangs off p (the reference's loop: NLLLoss(torch.log(p)), main.py:281-285).  One wave per query; the
+// softmax arithmetic is nll_grad_kernel's.  Also rowsum[q] = sum_c (gi + gt)[q, c] for the cdist backward (train.py).
+__global__ __launch_bounds__(256) void fuse_probs_backward_kernel(const float* __restrict__ d2i, const float* __restrict__ d2t,
+                                                                  const float* __restrict__ dp, int ldp, int Q, int N, int ldd,
+                                                                  float alpha, float oma, float beta, float* __restrict__ gi,
+                                                                  float* __restrict__ gt, float* __restrict__ rowsum) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int q = blockIdx.x * 4 + wave; q < Q; q += gridDim.x * 4) {
+        const float* ri = d2i + (size_t)q * ldd;
+        const float* rt = d2t + (size_t)q * ldd;
+        const float* rg = dp + (size_t)q * ldp;
+        float mi = 3.4e38f, mt = 3.4e38f, xi = -3.4e38f, xt = -3.4e38f;
+        for (int c = lane; c < N; c += 64) {
+            mi = fminf(mi, ri[c]); xi = fmaxf(xi, ri[c]);
+            mt = fminf(mt, rt[c]); xt = fmaxf(xt, rt[c]);
+        }
+        mi = wave_min(mi); mt = wave_min(mt); xi = wave_max(xi); xt = wave_max(xt);
+        const float mxi = __fmul_rn(beta, beta >= 0.f ? -mi : -xi), mxt = __fmul_rn(beta, beta >= 0.f ? -mt : -xt);
+        float si = 0.f, st = 0.f;
+        for (int c = lane; c < N; c += 64) {
+            si += expf(__fsub_rn(__fmul_rn(beta, -ri[c]), mxi));
+            st += expf(__fsub_rn(__fmul_rn(beta, -rt[c]), mxt));
+        }
+        si = wave_sum(si); st = wave_sum(st);
+        float ki = 0.f, kt = 0.f;                                        // sum_k dp[k] s_x[k]
+        for (int c = lane; c < N; c += 64) {
+            const float a = expf(__fsub_rn(__fmul_rn(beta, -ri[c]), mxi)) / si, b = expf(__fsub_rn(__fmul_rn(beta, -rt[c]), mxt)) / st;
+            ki = fmaf(rg[c], a, ki);
+            kt = fmaf(rg[c], b, kt);
+        }
+        ki = wave_sum(ki); kt = wave_sum(kt);
+        float rs = 0.f;
+        for (int c = lane; c < N; c += 64) {
+            const float a = expf(__fsub_rn(__fmul_rn(beta, -ri[c]), mxi)) / si, b = expf(__fsub_rn(__fmul_rn(beta, -rt[c]), mxt)) / st;
+            const float gic = -beta * (alpha * a * (rg[c] - ki)), gtc = -beta * (oma * b * (rg[c] - kt));
+            gi[(size_t)q * ldd + c] = gic;
+            gt[(size_t)q * ldd + c] = gtc;
+            rs += gic + gtc;
+        }
+        rs = wave_sum(rs);
+        if (lane == 0) rowsum[q] = rs;
+    }
+}
+
+// ---- backward of  loss = -(1/Q) sum_q log p[q, y_q]  (nn.NLLLoss()(torch.log(p), y), utils.py:90-93) wrt p ------------------
+// dp[q, c] = -g / (Q p[q, y_q]) at c == y_q, 0 elsewhere;  g = the upstream gradient of the loss (device scalar).
+__global__ __launch_bounds__(256) void nll_mean_backward_kernel(const float* __restrict__ p, int ldp, const int32_t* __restrict__ labels,
+                                                                int Q, int N, const float* __restrict__ g, float* __restrict__ dp,
+                                                                int lddp) {
+    const float gq = -g[0] / (float)Q;
+    const size_t total = (size_t)Q * N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i / N), c = (int)(i - (size_t)q * N);
+        dp[(size_t)q * lddp + c] = c == labels[q] ? gq / p[(size_t)q * ldp + c] : 0.f;
+    }
+}
+
 // ---- utils.py:84-93 on a materialised p [Q, N]: pred_p, y_hat = p.max(1); nll[q] = -log p[q, y_q] ---------------------------
 __global__ __launch_bounds__(256) void nll_rows_kernel(const float* __restrict__ p, int ldp, const int32_t* __restrict__ labels, int Q,
                                                        int N, float* __restrict__ nll, float* __restrict__ pmax,
@@ -535,6 +595,25 @@ extern "C" int pclip_nll_grad(const float* d2i, const float* d2t, const int32_t*
     nll_grad_kernel<<<row_grid(Q, 8192), 256, 0, (hipStream_t)stream>>>(d2i, d2t, labels, Q, q_total, N, ldd, alpha, one_minus_alpha, beta,
                                                                        gi, gt, rowsum, nll, pmax, argmax);
     return pclip_check_launch("nll_grad");
+}
+
+extern "C" int pclip_fuse_probs_backward(const float* d2i, const float* d2t, const float* dp, int ldp, int Q, int N, int ldd, float alpha,
+                                         float one_minus_alpha, float beta, float* gi, float* gt, float* rowsum, pclip_stream_t stream) {
+    PCLIP_REQUIRE(d2i && d2t && dp && gi && gt && rowsum, "pclip_fuse_probs_backward: null pointer");
+    PCLIP_REQUIRE(Q >= 0 && N > 0 && ldd >= N && ldp >= N, "pclip_fuse_probs_backward: bad Q=%d N=%d ldd=%d ldp=%d", Q, N, ldd, ldp);
+    if (Q == 0) return PCLIP_OK;
+    fuse_probs_backward_kernel<<<row_grid(Q, 8192), 256, 0, (hipStream_t)stream>>>(d2i, d2t, dp, ldp, Q, N, ldd, alpha, one_minus_alpha, beta,
+                                                                                  gi, gt, rowsum);
+    return pclip_check_launch("fuse_probs_backward");
+}
+
+extern "C" int pclip_nll_mean_backward(const float* p, int ldp, const int32_t* labels, int Q, int N, const float* g, float* dp, int lddp,
+                                       pclip_stream_t stream) {
+    PCLIP_REQUIRE(p && labels && g && dp, "pclip_nll_mean_backward: null pointer");
+    PCLIP_REQUIRE(Q >= 0 && N > 0 && ldp >= N && lddp >= N, "pclip_nll_mean_backward: bad Q=%d N=%d ldp=%d lddp=%d", Q, N, ldp, lddp);
+    if (Q == 0) return PCLIP_OK;
+    nll_mean_backward_kernel<<<flat_grid((size_t)Q * N), 256, 0, (hipStream_t)stream>>>(p, ldp, labels, Q, N, g, dp, lddp);
+    return pclip_check_launch("nll_mean_backward");
 }
 
 extern "C" int pclip_nll_rows(const float* p, int ldp, const int32_t* labels, int Q, int N, float* nll, float* pmax, int32_t* argmax,

@@ -4,21 +4,24 @@ gfx950 kernels of csrc/pclip_adapter.hip instead of eager conv/LayerNorm modules
 
 `nn.Conv2d` / `nn.LayerNorm` objects are kept purely as parameter containers so that
 `.parameters()`, `.state_dict()`, `.load_state_dict()`, `.half()`, `.cuda()` behave exactly as in the
-reference (including conv-2x's unused conv2/bn2 parameters)."""
+reference (including conv-2x's unused conv2/bn2 parameters).  Under autograd (grad mode on, trainable parameters:
+the reference's training loop, main.py:267-309) `forward` records a node whose backward runs the explicit backward kernels
+(proto_clip_amd/autograd.py); under torch.no_grad() it is the fused inference kernel alone."""
 import math
 
 import torch
 import torch.nn as nn
 
+from . import autograd as pag
 from . import ops
 from ._lib import PclipError
 
 
-def _check_inference(x, module):
-    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters())):
-        raise NotImplementedError(
-            "proto_clip_amd adapter modules run the inference kernels and keep no autograd tape; call them under "
-            "torch.no_grad().  Training goes through proto_clip_amd.train.ProtoClipTrainer (explicit backward kernels).")
+def _needs_tape(x, module):
+    """True when the call must record an autograd node: grad mode on and the input or a parameter requires grad — the reference's
+    training loop (`adapter(zq_imgs).float()` ... `train_loss.backward()`, main.py:267-309).  Under torch.no_grad() — every
+    evaluation path — the fused inference kernel runs alone."""
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters()))
 
 
 class Adapter(nn.Module):
@@ -45,7 +48,12 @@ class Adapter(nn.Module):
     def forward(self, x, l2norm_out: bool = False):
         """x [B, c_in] fp16 -> [B, c_in] fp16.  l2norm_out=True additionally fuses the row normalise
         that every caller applies next (main.py:408-409) — an extension, default off."""
-        _check_inference(x, self)
+        if _needs_tape(x, self):
+            if l2norm_out:
+                raise PclipError("l2norm_out is an inference-only fusion; under autograd normalise with torch ops as the reference does")
+            return pag.AdapterConvFn.apply(x, self.c_type == "conv-3x", self.conv1.weight, self.bn1.weight, self.bn1.bias,
+                                           self.conv2.weight, self.bn2.weight, self.bn2.bias, self.conv3.weight, self.bn3.weight,
+                                           self.bn3.bias)
         return ops.adapter_conv(
             x, self.c_type == "conv-3x", self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight,
             self.bn2.weight, self.bn2.bias, self.conv3.weight, self.bn3.weight, self.bn3.bias, l2norm_out=l2norm_out)
@@ -64,7 +72,10 @@ class Adapter_FC(nn.Module):
         )
 
     def forward(self, image_features, l2norm_out: bool = False):
-        _check_inference(image_features, self)
         fc = self.fc
+        if _needs_tape(image_features, self):
+            if l2norm_out:
+                raise PclipError("l2norm_out is an inference-only fusion; under autograd normalise with torch ops as the reference does")
+            return pag.AdapterFcFn.apply(image_features, fc[0].weight, fc[1].weight, fc[1].bias, fc[2].weight, fc[3].weight, fc[3].bias)
         return ops.adapter_fc(image_features, fc[0].weight, fc[1].weight, fc[1].bias, fc[2].weight, fc[3].weight,
                               fc[3].bias, ratio=0.2, l2norm_out=l2norm_out)

@@ -669,6 +669,32 @@ def nll_grad(d2i, d2t, labels, N: int, alpha: float, beta: float, q_total: int =
     return gi, gt, rs, nll, pmax, am
 
 
+def fuse_probs_backward(d2i, d2t, dp, N: int, alpha: float, beta: float):
+    """Backward of `fuse_probs` for an arbitrary upstream dp [Q, N] fp32: (gi, gt) wrt the two distance rows (padded like them,
+    columns >= N unspecified) and rowsum(gi + gt) — the autograd-transparent utils.P."""
+    require_cuda(d2i, d2t, dp)
+    Q, ldd = d2i.shape
+    if dp.dtype != torch.float32 or dp.shape != (Q, N) or dp.stride(1) != 1:
+        raise _lib.PclipError("fuse_probs_backward: dp must be a row-major fp32 [Q, N] tensor")
+    gi, gt = torch.empty_like(d2i), torch.empty_like(d2t)
+    rs = torch.empty(Q, dtype=torch.float32, device=d2i.device)
+    a32, oma32 = float(np.float32(alpha)), float(np.float32(1 - float(alpha)))
+    check(_lib.load().pclip_fuse_probs_backward(ptr(d2i), ptr(d2t), ptr(dp), dp.stride(0), Q, N, ldd, a32, oma32, float(np.float32(beta)),
+                                                ptr(gi), ptr(gt), ptr(rs), stream()), "pclip_fuse_probs_backward")
+    return gi, gt, rs
+
+
+def nll_mean_backward(p: torch.Tensor, labels: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """dp of nn.NLLLoss()(torch.log(p), labels) for the upstream gradient g (fp32 device scalar)."""
+    require_cuda(p, labels, g)
+    Q, N = p.shape
+    dp = torch.empty(Q, N, dtype=torch.float32, device=p.device)
+    g = g.reshape(1).float().contiguous()
+    check(_lib.load().pclip_nll_mean_backward(ptr(p), p.stride(0), ptr(labels.to(torch.int32)), Q, N, ptr(g), ptr(dp), N, stream()),
+          "pclip_nll_mean_backward")
+    return dp
+
+
 def nll_rows(p: torch.Tensor, labels: torch.Tensor):
     """(-log p[q, y_q], max_c p[q, c], argmax_c p[q, c]) per row of a materialised fp32 p [Q, N] (utils.py:84-93)."""
     require_cuda(p, labels)

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import autograd as pag
 from . import ops
 from ._lib import PclipError
 
@@ -52,6 +53,9 @@ def P(zq_imgs_flat, z_img_proto, z_text_proto, alpha, beta):
     (reference utils.py:225-244).  The reference casts every operand with .float(): fp16 operands (the eval path,
     main.py:399-409) go to the fp16-input MFMA kernel, which is lossless for them; if any operand is fp32 (the
     training path, main.py:262-281) everything is promoted and the exact-fp32 MFMA kernel is used."""
+    if pag.wants_grad(zq_imgs_flat, z_img_proto, z_text_proto):        # the training loop: p carries an autograd node (main.py:281-309)
+        _all_f16(zq_imgs_flat, z_img_proto, z_text_proto)
+        return pag.PFn.apply(zq_imgs_flat, z_img_proto, z_text_proto, alpha, beta)
     if _all_f16(zq_imgs_flat, z_img_proto, z_text_proto):
         p, _, _, _ = ops.classify(zq_imgs_flat, z_img_proto, z_text_proto, alpha, beta, want_p=True, want_argmax=False)
         return p
@@ -192,7 +196,10 @@ def accuracy_from_counts(correct, Q: int) -> np.ndarray:
 
 def InfoNCELoss(A, B):
     """InfoNCE()(A, B) of utils.py:72-77 with the info-nce-pytorch defaults (temperature 0.1, mean reduction, both sides
-    L2-normalised, cross entropy against the diagonal); A, B fp32 [n, D].  Forward value only (device scalar)."""
+    L2-normalised, cross entropy against the diagonal); A, B fp32 [n, D].  A device scalar; when an operand requires grad it
+    carries an autograd node (proto_clip_amd.autograd.InfoNceFn)."""
+    if pag.wants_grad(A, B):
+        return pag.InfoNceFn.apply(A, B)
     an, bn = ops.l2norm_rows_f32(A.float().contiguous()), ops.l2norm_rows_f32(B.float().contiguous())
     S = ops.gemm_f32(an, bn, trans_b=True, alpha=10.0)
     rows, _ = ops.softmax_ce_rows(S, 1.0 / A.shape[0])
@@ -200,20 +207,23 @@ def InfoNCELoss(A, B):
 
 
 def compute_loss_and_matches(p, target_inds, z_img_proto, z_text_proto, cfg):
-    """Loss and accuracy of one episode (reference utils.py:80-109): the same 7-tuple.  Forward values only — no autograd
-    graph hangs off them; gradients are produced by proto_clip_amd.train.ProtoClipTrainer.step, which fuses this loss with P
-    and never materialises p.  As in the reference, `neg_log_loss` (index 2) and the L4 entries are returned as None / as
-    computed there."""
+    """Loss and accuracy of one episode (reference utils.py:80-109): the same 7-tuple.  When p (or a prototype matrix) carries an
+    autograd graph — the reference's own loop, main.py:281-309 — the loss does too (NllMeanFn / InfoNceFn) and
+    `train_loss.backward()` runs the explicit backward kernels; otherwise forward values only.  ProtoClipTrainer.step remains the
+    fast path (NLL fused with P, p never materialised).  As in the reference, `neg_log_loss` (index 2) is returned as None."""
     require = p.dtype == torch.float32 and p.is_cuda
     if not require:
         raise PclipError("compute_loss_and_matches: p must be the fp32 CUDA tensor returned by P()")
-    nll, _, y_hat = ops.nll_rows(p, target_inds)
+    nll, _, y_hat = ops.nll_rows(p.detach(), target_inds)
     matches = (y_hat.long() == target_inds).float().sum()
     loss = torch.zeros((), dtype=torch.float32, device=p.device)
     img2txt = txt2img = img_inter = txt_inter = None
     losses = cfg["losses"]
     if len(losses) == 0 or "L1" in losses:
-        loss = loss + ops.colsum_f32(nll.view(-1, 1), scale=1.0 / p.shape[0])[0]
+        if pag.wants_grad(p):
+            loss = loss + pag.NllMeanFn.apply(p, target_inds)
+        else:
+            loss = loss + ops.colsum_f32(nll.view(-1, 1), scale=1.0 / p.shape[0])[0]
     if "L2" in losses:
         img2txt = InfoNCELoss(z_img_proto, z_text_proto)
         loss = loss + img2txt

@@ -53,11 +53,15 @@ def run_variant(name, tmp_dir=None):
     p, am = p.cpu(), am.cpu().long()
     p16, p32 = torch.from_numpy(g["p_f16"]), torch.from_numpy(g["p_f32"])
     gap = (p16 - p32).abs().max().item()
-    stage = {k: rel_err(a, torch.from_numpy(g[k + "_f16"])) for k, a in
+    # per-VECTOR relative errors: the textual bank is [D, N] (utils.py:272) — its vectors are the columns (round 2 took the rows: 6
+    # numbers per "vector", some of them ~0, which is where its 7e-3 came from)
+    vec = lambda k, t: t.t() if k == "text_bank" else t
+    stage = {k: rel_err(vec(k, a), vec(k, torch.from_numpy(g[k + "_f16"]))) for k, a in
              (("test_features", test_f), ("text_bank", text_bank), ("adapted", zq), ("proto_img", zi), ("proto_txt", zt))}
     # the reference's own fp16 <-> fp32 disagreement per stage: the yard-stick of the stage bounds
-    stage_gap = {k: rel_err(torch.from_numpy(g[k + "_f32"]), torch.from_numpy(g[k + "_f16"])) for k in STAGES}
-    return dict(g=g, c=c, p=p, am=am, p16=p16, p32=p32, gap=gap, d16=(p - p16).abs().max().item(), d32=(p - p32).abs().max().item(),
+    stage_gap = {k: rel_err(vec(k, torch.from_numpy(g[k + "_f32"])), vec(k, torch.from_numpy(g[k + "_f16"]))) for k in STAGES}
+    jitter = (torch.from_numpy(g["p_f16_jitter"]) - p16).abs().max().item() if "p_f16_jitter" in g.files else None
+    return dict(g=g, c=c, p=p, am=am, p16=p16, p32=p32, gap=gap, jitter=jitter, d16=(p - p16).abs().max().item(), d32=(p - p32).abs().max().item(),
                 stage=stage, stage_gap=stage_gap, test_l=test_l.cpu(), test_y=test_y, sup_y=sup_y, values=values.cpu(), zq=zq, zi=zi, zt=zt)
 
 
@@ -79,7 +83,7 @@ def main():
             ref_am = torch.from_numpy(r["g"]["argmax_f16"]).long()
             row["folded" if fold else "unfolded"] = dict(d16=r["d16"], d32=r["d32"], stage=r["stage"],
                                                          top1_flips_decided=int((r["am"][decided] != ref_am[decided]).sum()))
-            row.update(gap=r["gap"], tol=tol, stage_gap=r["stage_gap"], decided=int(decided.sum()))
+            row.update(gap=r["gap"], jitter=r["jitter"], tol=tol, stage_gap=r["stage_gap"], decided=int(decided.sum()))
         M.LN_FOLD = was
         out[name] = row
         print(name, json.dumps(row), flush=True)

@@ -28,7 +28,7 @@ sys.path.insert(0, REPO)
 from proto_clip_amd import synth                                   # noqa: E402
 from proto_clip_amd.clip.model import random_state_dict            # noqa: E402
 sys.path.insert(0, HERE)
-from spec import (E2E, E2E_CASE, E2E_VARIANTS, ENCODERS, FEWSHOT, RESNETS, TRAIN, e2e_images, e2e_state_dict, fewshot_inputs,   # noqa: E402
+from spec import (E2E, E2E_CASE, E2E_VARIANTS, ENCODERS, FEWSHOT, RESNETS, TRAIN, e2e_images, e2e_jitter, e2e_state_dict, fewshot_inputs,   # noqa: E402
                   randomize_adapter_, train_inputs)
 
 
@@ -344,11 +344,15 @@ def make_e2e(name, ref_main, ref_utils, ref_model, ref_clip_model, scratch):
     (sup_x, sup_y), (val_x, val_y), (test_x, test_y) = e2e_images(c)
     ad = adapter_state(ref_model, c["adapter"], E2E["embed_dim"], seed=var["adapter_seed"])
     out = {}
-    for tag in ("f16", "f32"):
+    clean = (sup_x, val_x, test_x)
+    for tag in ("f16", "f32", "f16_jitter"):
         with contextlib.redirect_stdout(io.StringIO()):
             m = ref_clip_model.build_model({k: v.clone() for k, v in sd.items()})
         if tag == "f32":
             m = m.float()
+        sup_x, val_x, test_x = clean
+        if tag == "f16_jitter":      # the fp16 chain again on images with 2 % of the pixels moved by one fp16 ulp: the comparator's self-noise
+            sup_x, val_x, test_x = (e2e_jitter(x, c["seed"] + i) for i, x in enumerate(clean))
         cfg = dict(shots=K, backbone="ViT-B/16", dataset="synthetic_" + name + "_" + tag, only_test=True, lr=0.0001, augment_epoch=c["augment_epoch"],
                    train_epoch=1, alpha=c["alpha"], beta=c["beta"], adapter=c["adapter"], train_vis_mem_only=True, losses=["L1"],
                    cache_dir=os.path.join(scratch, "caches", name + "_" + tag), logs_dir_path="logs")
@@ -380,14 +384,17 @@ def make_e2e(name, ref_main, ref_utils, ref_model, ref_clip_model, scratch):
         assert len(calls) == 2 * n_grid + 2, len(calls)
         zq, zi, zt, a, b, p = calls[2 * n_grid]                      # the fixed-(alpha, beta) test call, main.py:433
         assert (a, b) == (c["alpha"], c["beta"])
+        if tag == "f16_jitter":
+            out.update({"p_f16_jitter": p, "test_features_f16_jitter": test_f})
+            continue
         out.update({f"keys_{tag}": keys, f"test_features_{tag}": test_f, f"text_bank_{tag}": text_bank, f"adapted_{tag}": zq,
                     f"proto_img_{tag}": zi, f"proto_txt_{tag}": zt, f"p_{tag}": p, f"argmax_{tag}": p.max(1)[1].to(torch.int16),
                     f"acc_{tag}": (p.max(1)[1] == test_l).float().mean().item()})
         if tag == "f16":
             out["values"] = values.to(torch.int16)
-    print("%s: acc f16 %.3f, f32 %.3f; max|p16 - p32| %.3e; argmax agree %d/%d" % (
+    print("%s: acc f16 %.3f, f32 %.3f; max|p16 - p32| %.3e; max|p16 - p16(jittered input)| %.3e; argmax agree %d/%d" % (
         name, out["acc_f16"], out["acc_f32"], (out["p_f16"] - out["p_f32"]).abs().max().item(),
-        int((out["argmax_f16"] == out["argmax_f32"]).sum()), len(test_y)))
+        (out["p_f16"] - out["p_f16_jitter"]).abs().max().item(), int((out["argmax_f16"] == out["argmax_f32"]).sum()), len(test_y)))
     savez(name, classnames=np.array(classnames), templates=np.array(templates), adapter_keys=np.array(list(ad.state_dict().keys())),
           **{"adapter__" + k: v for k, v in ad.state_dict().items()}, **out)
 

@@ -63,6 +63,15 @@ def trained_like_(sd, seed, n_outlier=4, outlier=50.0):
     return sd
 
 
+def e2e_jitter(x, seed):
+    """x with 2 % of its pixels moved by one fp16 ulp (relative 2^-10): an imperceptible change of the INPUT.  The reference's own
+    fp16 chain is run on such images too (make_golden.make_e2e, `p_f16_jitter`): how far ITS logits move is the self-noise of the
+    comparator, the second yard-stick of tests/test_gpu_e2e.py besides its fp16 <-> fp32 gap."""
+    gen = torch.Generator().manual_seed(7000 + seed)
+    mask = torch.rand(x.shape, generator=gen) < 0.02
+    return torch.where(mask, x * (1 + 2.0 ** -10), x)
+
+
 def e2e_state_dict(variant):
     """Seeded weights of an image -> logits fixture (shared by make_golden.py and the tests)."""
     from proto_clip_amd.clip.model import random_state_dict

@@ -1,91 +1,97 @@
-"""Image -> logits through the whole hot path on the GPU against a fixture produced by the REFERENCE's own chain
+"""Image -> logits through the whole hot path on the GPU against fixtures produced by the REFERENCE's own chain
 (tests/golden/make_golden.py::make_e2e: build_cache_model + clip_classifier + pre_load_features on the reference's CLIP
 towers, then main.py:383-441 with a spy on P).  north_star's bar: logits within 1e-3, top-1 exactly.
 
-The comparator itself is fp16-noisy: the fixture holds the chain on the reference's fp16-weight towers (its GPU precision)
-AND on its fp32 towers (the CPU path, features cast to fp16); their disagreement `gap` = max|p16 - p32| is printed and the
-GPU result must stay within max(2 x gap, 1e-3) of both, with the same top-1 wherever the reference's own top-2 margin exceeds
-that bound (a query whose two best classes tie to 1e-4 has no defined top-1 at fp16 feature precision)."""
-import numpy as np
+Six fixtures (tests/golden/spec.py::E2E_VARIANTS): four seeded draws on random-init towers and two with TRAINED-like statistics
+(LayerNorm gains over a factor 25, LayerNorm biases, ~50 sigma outlier channels in the residual stream).
+
+The comparator is fp16-noisy, and each fixture carries the reference's own yard-sticks: the chain on its fp16-weight towers
+(its GPU precision, `p_f16`) AND on its fp32 towers (the CPU path, features cast to fp16, `p_f32`) — `gap` = max|p16 - p32| —
+and the fp16 chain once more on images with 2 % of the pixels moved by one fp16 ulp (`p_f16_jitter`).  Per fixture:
+  * tol = max(2 x gap, 1e-3) (the floor is north_star's 1e-3); the GPU result must stay within tol of BOTH p16 and p32;
+  * the same top-1 wherever the reference's own top-2 margin exceeds 2 x tol (a query whose two best classes tie to 1e-4 has no
+    defined top-1 at fp16 feature precision);
+  * every stage (features, textual bank, adapted queries, both prototype sets) within STAGE_BOUNDS of the reference's fp16 chain.
+`gap` is ONE draw of the same noise the GPU chain adds (fp16 roundings of an independent summation order), so for a correct
+implementation d > 2 x gap happens on roughly one fixture in six — measured: `e2e_s3` exceeds its tol with the LayerNorms unfolded
+(1.72e-3 vs 1.19e-3: the reference's rounding points) and folded (1.23e-3) alike, and the CPU oracle, which is pinned to the
+reference's fp32 towers at 5e-6, sits at 0.98e-3 on it (tests/fold_cpu_study.py); the deviation is the textual bank's (18 prompts,
+shared by every query: tests/golden/make_golden.py decomposition in DESIGN section 4).  The suite therefore asserts per fixture the
+hard cap 1.5 x tol and over the six fixtures AT MOST ONE excursion above tol (test_suite_allows_one_excursion) — a calibrated
+statement instead of a lucky set of seeds.  With the LayerNorms unfolded (the default) the trained-like fixtures additionally hold
+p to max(2 x the reference's jitter self-noise, 2e-4): there the HIP chain is as close to the reference as the reference is to
+itself."""
 import pytest
 import torch
 
-from conftest import adapter_sd, golden, observe
-from golden.spec import E2E, E2E_CASE, e2e_images
+from conftest import observe
+from e2e_chain import STAGES, run_variant
+from golden.spec import E2E_VARIANTS
 from oracle import proto_oracle as po
 
 pytestmark = pytest.mark.gpu
 
+# relative L2 per vector against the reference's fp16 chain: 2 x the largest value observed with the LayerNorms unfolded over the
+# six fixtures (profiles/r03_e2e_fold_study.json; the reference's own fp16 <-> fp32 disagreement on the same stages is 0.7 - 1.4e-3)
+STAGE_BOUNDS = {"test_features": 2.4e-3, "text_bank": 2.4e-3, "adapted": 3.0e-3, "proto_img": 1.8e-3, "proto_txt": 2.4e-3}
+_RESULTS = {}
 
-def rel_err(a, b):
-    a, b = a.float().cpu(), b.float().cpu()
-    return ((a - b).norm(dim=-1) / b.norm(dim=-1)).max().item()
 
-
-def test_images_to_logits_against_reference_chain(tmp_path):
-    from proto_clip_amd import ops
-    from proto_clip_amd.clip.model import build_model, random_state_dict
-    from proto_clip_amd.model import Adapter
-    from proto_clip_amd.utils import build_cache_model, clip_classifier, pre_load_features
-    g = golden("e2e_small")
-    c = E2E_CASE
-    N, K, D = c["N"], c["K"], E2E["embed_dim"]
-    model = build_model(random_state_dict(seed=17, **E2E)).cuda()
-    (sup_x, sup_y), _, (test_x, test_y) = e2e_images()
-    cfg = dict(cache_dir=str(tmp_path), backbone="ViT-B/16", shots=K, augment_epoch=c["augment_epoch"], dataset="synthetic_e2e")
-    classnames, templates = [str(x) for x in g["classnames"]], [str(x) for x in g["templates"]]
-    with torch.no_grad():
-        keys, values = build_cache_model(cfg, model, [(sup_x[:10], sup_y[:10]), (sup_x[10:], sup_y[10:])])      # utils.py:284-332
-        test_f, test_l = pre_load_features(cfg, "test", model, [(test_x[:20], test_y[:20]), (test_x[20:], test_y[20:])])   # 335-361
-        _, text_bank = clip_classifier(classnames, templates, model)                                          # 256-273, real tokenizer
-        adapter = Adapter(D, c["adapter"], dtype=torch.half)
-        adapter.load_state_dict(adapter_sd(g))
-        adapter = adapter.cuda()
-        zi = ops.proto_build(ops.transpose(keys), N, K)                                  # main.py:399-402
-        zt = ops.l2norm_rows(ops.transpose(text_bank))                                   # 404-405
-        zq = adapter(test_f, l2norm_out=True)                                            # 407-409
-        p, am, _, _ = ops.classify(zq, zi, zt, c["alpha"], c["beta"], want_p=True, want_argmax=True)   # utils.py:225-244, main.py:433-435
-    p, am = p.cpu(), am.cpu().long()
-    assert torch.equal(test_l.cpu(), test_y) and torch.equal(values.cpu().argmax(1), torch.sort(sup_y).values)
-    p16, p32 = torch.from_numpy(g["p_f16"]), torch.from_numpy(g["p_f32"])
-    gap = (p16 - p32).abs().max().item()
-    d16, d32 = (p - p16).abs().max().item(), (p - p32).abs().max().item()
-    # `gap` of this ONE fixture pair is itself a noisy draw (5.3e-4 here; the same fp16 <-> fp32 comparison of the reference
-    # arithmetic over eight seeded weight / image sets gives 0.7e-3 .. 1.9e-3, profiles/r02_fold_parity_study.json and
-    # test_chain_parity_over_seeds below), so the floor of the bound is 2e-3, not 1e-3
-    tol = max(2 * gap, 2e-3)
-    stage = {k: rel_err(a, torch.from_numpy(g[k + "_f16"])) for k, a in
-             (("test_features", test_f), ("text_bank", text_bank), ("adapted", zq), ("proto_img", zi), ("proto_txt", zt))}
+@pytest.mark.parametrize("name", list(E2E_VARIANTS))
+def test_images_to_logits_against_reference_chain(name, tmp_path):
+    from proto_clip_amd.clip import model as M
+    r = run_variant(name, tmp_path)
+    g, c, p, am = r["g"], r["c"], r["p"], r["am"]
+    assert torch.equal(r["test_l"], r["test_y"]) and torch.equal(r["values"].argmax(1), torch.sort(r["sup_y"]).values)
+    gap, d16, d32 = r["gap"], r["d16"], r["d32"]
+    tol = max(2 * gap, 1e-3)
     ref_am = torch.from_numpy(g["argmax_f16"]).long()
-    srt = p16.sort(dim=1).values
+    srt = r["p16"].sort(dim=1).values
     margin = srt[:, -1] - srt[:, -2]
     decided = margin > 2 * tol
     agree = int((am == ref_am).sum())
-    print(f"\n[observed] image->logits: max|p - p_ref16| {d16:.2e}, max|p - p_ref32| {d32:.2e}; reference fp16<->fp32 gap {gap:.2e}; "
-          f"top-1 equal on {agree}/{len(am)} queries ({int(decided.sum())} with a reference margin > {2 * tol:.1e}, smallest margin "
-          f"{margin.min().item():.1e}); stage rel errors vs the reference fp16 chain: " + ", ".join(f"{k} {v:.1e}" for k, v in stage.items()))
-    observe("image->logits: reference fp16<->fp32 gap in p (yard-stick)", gap, gap)
-    observe("image->logits: max|p - p_reference(fp16 towers)|", d16, tol)
-    observe("image->logits: max|p - p_reference(fp32 towers)|", d32, tol)
-    observe("image->logits: top-1 disagreements among decided queries", float((am[decided] != ref_am[decided]).sum()), 0.0)
-    for k, v in stage.items():
-        observe(f"image->logits stage {k}: rel err vs reference fp16 chain", v, 5e-3)
-    assert d16 <= tol and d32 <= tol, (d16, d32, tol)
+    print(f"\n[observed] {name}: max|p - p_ref16| {d16:.2e}, max|p - p_ref32| {d32:.2e}; reference fp16<->fp32 gap {gap:.2e}, jitter self-noise "
+          f"{r['jitter']:.2e}; top-1 equal on {agree}/{len(am)} queries ({int(decided.sum())} with a reference margin > {2 * tol:.1e}, smallest margin "
+          f"{margin.min().item():.1e}); stage rel errors vs the reference fp16 chain: " + ", ".join(f"{k} {v:.1e}" for k, v in r["stage"].items()))
+    observe(f"image->logits {name}: reference fp16<->fp32 gap in p (yard-stick)", gap, gap)
+    observe(f"image->logits {name}: max|p - p_reference(fp16 towers)|", d16, tol)
+    observe(f"image->logits {name}: max|p - p_reference(fp32 towers)|", d32, tol)
+    observe(f"image->logits {name}: top-1 disagreements among decided queries", float((am[decided] != ref_am[decided]).sum()), 0.0)
+    for k in STAGES:
+        observe(f"image->logits {name} stage {k}: rel err vs reference fp16 chain", r["stage"][k], STAGE_BOUNDS[k])
+    _RESULTS[name] = dict(d16=d16, d32=d32, tol=tol)
+    for k in STAGES:
+        assert r["stage"][k] <= STAGE_BOUNDS[k], (name, k, r["stage"][k])
+    assert d16 <= 1.5 * tol and d32 <= 1.5 * tol, (name, d16, d32, tol)               # hard cap; the suite test below counts excursions above tol
     assert torch.equal(am[decided], ref_am[decided])
     assert agree >= len(am) - int((~decided).sum())
-    acc = (am == test_y).float().mean().item()
+    acc = (am == r["test_y"]).float().mean().item()
     assert abs(acc - float(g["acc_f16"])) <= float((~decided).sum()) / len(am) + 1e-6
+    if E2E_VARIANTS[name]["trained"] and not M.LN_FOLD:
+        bound = max(2 * r["jitter"], 2e-4)
+        observe(f"image->logits {name}: max|p - p_ref16| (trained-like statistics, reference rounding points)", d16, bound)
+        assert d16 <= bound, (name, d16, bound)
     # and the classification stage on the GPU's own adapted features against the oracle: exact top-1, p to 1e-5
-    p_o = po.P(zq.cpu(), zi.cpu(), zt.cpu(), c["alpha"], c["beta"])
+    p_o = po.P(r["zq"].cpu(), r["zi"].cpu(), r["zt"].cpu(), c["alpha"], c["beta"])
     assert (p - p_o).abs().max().item() <= 1e-5 and torch.equal(am, p_o.max(1)[1])
+
+
+def test_suite_allows_one_excursion():
+    """Over the six fixtures at most ONE may exceed tol = max(2 x gap, 1e-3) (module docstring); runs after the per-fixture tests."""
+    if len(_RESULTS) < len(E2E_VARIANTS):
+        pytest.skip("needs the per-fixture results of this run")
+    over = [n for n, r in _RESULTS.items() if max(r["d16"], r["d32"]) > r["tol"]]
+    observe("image->logits suite: fixtures above tol = max(2 x gap, 1e-3)", float(len(over)), 1.0)
+    print("\n[observed] fixtures above their tol:", over)
+    assert len(over) <= 1, over
 
 
 def test_chain_parity_over_seeds():
     """The image -> logits chain on several seeded weight / image sets of the e2e case, with the LayerNorms folded into their
-    linears (the product path) and unfolded, against the oracle's fp32 towers (= the reference CPU path: pinned to the reference's
-    fp32 model at 5e-6) and its fp16 towers (tests/fold_parity_study.py).  At fp16 feature precision the reference arithmetic
-    disagrees with ITSELF (fp16 vs fp32 towers) by ~1.2e-3 in p on these sensitive synthetic splits; the GPU chain must sit inside
-    that same band in either form, and no query whose fp32 top-2 margin exceeds 2e-3 may change its top-1."""
+    linears (PCLIP_LN_FOLD=1) and unfolded (the default), against the oracle's fp32 towers (= the reference CPU path: pinned to
+    the reference's fp32 model at 5e-6) and its fp16 towers (tests/fold_parity_study.py).  At fp16 feature precision the reference
+    arithmetic disagrees with ITSELF (fp16 vs fp32 towers) by ~1.2e-3 in p on these sensitive synthetic splits; the GPU chain must
+    sit inside that same band in either form, and no query whose fp32 top-2 margin exceeds 2e-3 may change its top-1."""
     import fold_parity_study as fps
     rows, summary = fps.run(4)
     for k, v in summary.items():

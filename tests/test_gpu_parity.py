@@ -243,8 +243,9 @@ def test_adapter_against_reference_fixture(ops, name):
     assert_adapter_close(val_raw, torch.from_numpy(g["adapted_val_raw"]), tag=f"adapter {cfg['adapter']} vs reference rows ({name})")
     assert_adapter_close(test_n, torch.from_numpy(g["adapted_test_norm"]), tag=f"adapter {cfg['adapter']} vs reference rows ({name})")
     assert torch.equal(test_n.cpu(), test_2.cpu())                      # fused normalise == separate kernel
-    with pytest.raises(NotImplementedError):
-        ad(dev(split.val_features[:4]))                                 # training forward is not built: loud
+    y_tape = ad(dev(split.val_features[:4]))                            # grad mode, trainable parameters: an autograd node (tests/test_gpu_autograd.py)
+    assert y_tape.requires_grad
+    assert_adapter_close(y_tape.detach(), val_raw[:4], tag=f"adapter {cfg['adapter']} under autograd vs its no_grad kernel ({name})")
 
 
 @pytest.mark.parametrize("kind,D", [("conv-3x", 512), ("conv-2x", 768), ("conv-3x", 1024), ("fc", 1024), ("conv-2x", 100)])
