@@ -67,15 +67,13 @@ def build_state(device, rank, world):
 
 
 def step(st):
-    from proto_clip_amd import ops
-    from proto_clip_amd.dist import sharded_prototypes
+    """proto_clip_amd.dist.hot_path_step: the prototype reduction (main.py:399-402) + all-gather run on a side stream under the
+    encoder (clip/model.py:338 -> utils.py:352 -> model.py:49-78 + main.py:408-409); the classification (utils.py:225) joins them."""
+    from proto_clip_amd.dist import HipPath, PrototypeExchange, hot_path_step
+    if "path" not in st:
+        st["path"], st["exchange"] = HipPath(st["model"], st["adapter"]), PrototypeExchange()
     with torch.no_grad():
-        zi = sharded_prototypes(st["bank"], st["bank_labels"], N_CLASS)          # main.py:399-402 (+ all-gather)
-        f = st["model"].encode_image(st["images"])                               # clip/model.py:338
-        f = ops.l2norm_rows(f, out=f)                                            # utils.py:352
-        a = st["adapter"](f, l2norm_out=True)                                    # model.py:49-78 + main.py:408-409
-        _, am, _, _ = ops.classify(a, zi, st["text"], ALPHA, BETA, want_p=False, want_argmax=True)   # utils.py:225
-    return am
+        return hot_path_step(st["path"], st["exchange"], st["bank"], st["bank_labels"], N_CLASS, st["images"], st["text"], ALPHA, BETA)
 
 
 def measure_gemm(st):

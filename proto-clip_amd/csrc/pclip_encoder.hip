@@ -837,6 +837,25 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const half_t* __rest
 // the register footprint at ~100 VGPRs (2 workgroups per CU) for any L <= 288.
 constexpr int ATT_DH = 64;
 constexpr int ATT_MAX_L = 288;
+// Softmax variants of attn_query_tile (bit mask VAR; same-process A/B of the seven combinations, tools/ab_multi.py attn,
+// profiles/r03_ab_attention_var.txt — ViT-B/16, B = 1024: 336 us -> 306 us with all four, each contributing):
+//   1  deferred maximum: the running maximum only moves when some row of the wave outgrew it by more than 2^kAttDefer; in between the
+//      probabilities are taken against the OLD maximum (they reach 2^kAttDefer instead of 1: exact in fp32, and the fp16 rounding of
+//      P is relative) and the rescale of the 32 output accumulators (+ its v_exp) is skipped.  On N(0,1) data the maximum of a later
+//      key tile practically never exceeds the first tiles' by a factor 4, so the rescale runs once per query tile instead of 4 times.
+//   2  the row sum as two interleaved partial sums (v_pk_add_f32: 16 instead of 32 dependent adds per pair of key tiles)
+//   4  scale-and-shift of two scores per instruction (v_pk_fma_f32)
+//   8  s_setprio(1) around the MFMA clusters (four waves per SIMD at different phases: the guide's T5 regime)
+// The eight-wave kernel (long sequences: ViT-B/16, ViT-L/14) takes all four; the four-wave kernel (ViT-B/32, the text tower) only the
+// deferred maximum — the packed forms and the priority flips cost the causal L = 77 kernel 4 %.  Not bit-identical to round 2's
+// kernel: outputs differ by one fp16 ulp on ~1e-4 of the elements, error against fp32 attention unchanged (tests/test_gpu_encoder.py).
+constexpr float kAttDefer = 2.f;
+#ifndef PCLIP_ATT_VAR_LONG
+#define PCLIP_ATT_VAR_LONG 15
+#endif
+#ifndef PCLIP_ATT_VAR_SHORT
+#define PCLIP_ATT_VAR_SHORT 1
+#endif
 
 // ds_read_b64_tr_b16: 64 bits per lane, 16-bit elements transposed inside each 16-lane group (see attention_kernel)
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -884,7 +903,7 @@ __device__ __forceinline__ float half_wave_sum(float v) { float a, b; half_wave_
 // DEEP (the persistent kernel: two waves per SIMD, registers to spare): the K fragments of the NEXT pair of key tiles and the
 // V^T fragments of THIS pair are requested right after the pair's score MFMAs, so their LDS latency passes under the softmax
 // arithmetic instead of in front of every MFMA (+64 VGPRs).  Same operations in the same order per accumulator: same bits.
-template <bool DEEP = false>
+template <bool DEEP = false, int VAR = 0>
 __device__ __forceinline__ void attn_query_tile(const half_t* Ks, const half_t* Vs, const half8_t (&qf)[4], int q, int qb, int L, int causal,
                                                 int NT, int hi, int ql, const int (&voff)[2], float16_t (&o)[2], float& lrun_out) {
 #pragma unroll
@@ -926,6 +945,9 @@ __device__ __forceinline__ void attn_query_tile(const half_t* Ks, const half_t* 
         for (int u = 0; u < NTILE; ++u)
 #pragma unroll
             for (int e = 0; e < 16; ++e) st[u][e] = 0.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (VAR & 8) __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int sidx = 0; sidx < 4; ++sidx)
 #pragma unroll
@@ -933,6 +955,9 @@ __device__ __forceinline__ void attn_query_tile(const half_t* Ks, const half_t* 
                 const half8_t kf = DEEP ? kpre[u][sidx] : k_frag(t0 + u, sidx);
                 st[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[sidx], st[u], 0, 0, 0);
             }
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (VAR & 8) __builtin_amdgcn_s_setprio(0);
+#endif
         half8_t vpre[NTILE][2][2];
         if (DEEP) {
 #pragma unroll
@@ -962,14 +987,37 @@ __device__ __forceinline__ void attn_query_tile(const half_t* Ks, const half_t* 
             for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, st[u][e]);
         }
         tmax = half_wave_max(tmax) * kScale;                       // kScale > 0: max commutes with the scaling
-        const float mnew = fmaxf(mrun, tmax);                      // finite from the first tile on: key 0 is never masked
+        // VAR & 1: deferred maximum (see above); -inf + kAttDefer = -inf, so the first tile always sets the maximum
+        const bool grow = (VAR & 1) ? __any(tmax > mrun + kAttDefer) : __any(fmaxf(mrun, tmax) != mrun);
+        const float mnew = ((VAR & 1) && !grow) ? mrun : fmaxf(mrun, tmax);     // finite from the first tile on: key 0 is never masked
         float psum = 0.f;
+        if (VAR & 6) {
+            float2_t ps2 = {0.f, 0.f};
+            const float2_t ks2 = {kScale, kScale}, nm2 = {-mnew, -mnew};
 #pragma unroll
-        for (int u = 0; u < NTILE; ++u)
+            for (int u = 0; u < NTILE; ++u)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { st[u][e] = __builtin_amdgcn_exp2f(fmaf(st[u][e], kScale, -mnew)); psum += st[u][e]; }
+                for (int e = 0; e < 16; e += 2) {
+                    float2_t v = {st[u][e], st[u][e + 1]};
+                    if (VAR & 4) {
+                        v = v * ks2 + nm2;                         // v_pk_fma_f32
+                        v = float2_t{__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])};
+                    } else
+                        v = float2_t{__builtin_amdgcn_exp2f(fmaf(v[0], kScale, -mnew)), __builtin_amdgcn_exp2f(fmaf(v[1], kScale, -mnew))};
+                    st[u][e] = v[0];
+                    st[u][e + 1] = v[1];
+                    if (VAR & 2) ps2 += v;                         // v_pk_add_f32: two partial sums
+                    else { psum += v[0]; psum += v[1]; }
+                }
+            psum += ps2[0] + ps2[1];
+        } else {
+#pragma unroll
+            for (int u = 0; u < NTILE; ++u)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { st[u][e] = __builtin_amdgcn_exp2f(fmaf(st[u][e], kScale, -mnew)); psum += st[u][e]; }
+        }
         psum = half_wave_sum(psum);
-        if (__any(mnew != mrun)) {
+        if (grow) {
             const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
             lrun *= alpha;
 #pragma unroll
@@ -986,11 +1034,17 @@ __device__ __forceinline__ void attn_query_tile(const half_t* Ks, const half_t* 
                 half8_t pf;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pf[e] = (half_t)st[u][sidx * 8 + e];
+#if defined(__HIP_DEVICE_COMPILE__)
+                if (VAR & 8) __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const half8_t vf = DEEP ? vpre[u][sidx][j] : v_frag(t0 + u, sidx, j);
                     o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[j], 0, 0, 0);
                 }
+#if defined(__HIP_DEVICE_COMPILE__)
+                if (VAR & 8) __builtin_amdgcn_s_setprio(0);
+#endif
             }
     };
     int t = 0;
@@ -1035,7 +1089,7 @@ __device__ __forceinline__ void attn_store_tile(half_t* orow, const float16_t (&
 // General operand form: queries q [B][Lq rows, row stride ldq] (the FIRST Lq tokens of each sequence), keys / values in
 // kv [B*L rows, row stride ldkv] at column offsets k_off / v_off; the fused-QKV case is q = kv = qkv, ldq = ldkv = 3W,
 // k_off = W, v_off = 2W, Lq = L.  Lq < L serves the last vision block, whose output is only read at the class token.
-template <int NW>   // waves per workgroup; __launch_bounds__'s second argument = waves per SIMD (two workgroups per CU)
+template <int NW, int VAR>   // waves per workgroup (__launch_bounds__'s second argument = waves per SIMD: two workgroups per CU); softmax variant
 __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const half_t* __restrict__ qp, int ldq, long q_batch,
                                                            const half_t* __restrict__ kvp, int ldkv, int k_off, int v_off,
                                                            half_t* __restrict__ out, int L, int Lq, int H, int causal, int NT,
@@ -1083,7 +1137,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const half_t
         for (int s = 0; s < 4; ++s) qf[s] = ld_half8(qbase + (size_t)qc * ldq + s * 16 + hi * 8);
         float16_t o[2];
         float lrun;
-        attn_query_tile(Ks, Vs, qf, q, qb, L, causal, NT, hi, ql, voff, o, lrun);
+        attn_query_tile<false, VAR>(Ks, Vs, qf, q, qb, L, causal, NT, hi, ql, voff, o, lrun);
         attn_store_tile(out + ((size_t)b * Lq + q) * W + h * ATT_DH, o, lrun, hi, q < Lq);
     }
 }
@@ -1127,7 +1181,7 @@ __device__ __forceinline__ uint4_t attn_rsrc(const void* base) {
     return uint4_t{lo, hi & 0xffffu, 0x7fffffffu, 0x00020000u};   // stride 0, num_records 2 GiB, raw 32-bit data format
 }
 
-template <int NW, int WPS>   // waves per workgroup, waves per SIMD the register budget must allow
+template <int NW, int WPS, int VAR>   // waves per workgroup, waves per SIMD the register budget must allow, softmax variant
 __global__ __launch_bounds__(NW * 64, WPS) void attention_pipe_kernel(const half_t* __restrict__ qp, int ldq, long q_batch,
                                                                       const half_t* __restrict__ kvp, int ldkv, int k_off, int v_off,
                                                                       half_t* __restrict__ out, int L, int H, int causal, int NT, int KR,
@@ -1218,7 +1272,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attention_pipe_kernel(const half
                     for (int e = 0; e < 16; ++e) o[j][e] = (float)qf[e & 3][e & 7];
                 lrun = 1.f;
             } else
-                attn_query_tile<true>(Ks, Vs, qf, q, wave, L, causal, NT, hi, ql, voff, o, lrun);
+                attn_query_tile<true, VAR>(Ks, Vs, qf, q, wave, L, causal, NT, hi, ql, voff, o, lrun);
             const int b = item / H, h = item - b * H;
             attn_store_tile(out + ((size_t)b * L + q) * W + h * ATT_DH, o, lrun, hi, q < L && !(PCLIP_ATT_ABL & 4));
         }
@@ -2050,8 +2104,8 @@ extern "C" int pclip_attention_q_f16(const void* q, int ldq, long q_batch_stride
     if (Lq == L && g_att_mode != 0 && NT <= 8 && plds <= 160 * 1024 && cus > 0 && g_att_mode == 1) {
         static DevOnce pipe_attr;
         if (!pipe_attr.done()) {
-            if (hipFuncSetAttribute((const void*)attention_pipe_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-                hipFuncSetAttribute((const void*)attention_pipe_kernel<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            if (hipFuncSetAttribute((const void*)attention_pipe_kernel<4, 2, PCLIP_ATT_VAR_SHORT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void*)attention_pipe_kernel<8, 2, PCLIP_ATT_VAR_LONG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 pclip_set_error("pclip_attention_f16: cannot raise the dynamic LDS limit");
                 return PCLIP_E_LAUNCH;
             }
@@ -2063,32 +2117,37 @@ extern "C" int pclip_attention_q_f16(const void* q, int ldq, long q_batch_stride
         if (g_att_grid > 0 && g_att_grid < grid) grid = g_att_grid;
         if (grid > nitems) grid = nitems;
         if (NT <= 4)
-            attention_pipe_kernel<4, 2><<<(int)grid, 256, plds, (hipStream_t)stream>>>((const half_t*)q, ldq, q_batch_stride, (const half_t*)kv, ldkv,
+            attention_pipe_kernel<4, 2, PCLIP_ATT_VAR_SHORT><<<(int)grid, 256, plds, (hipStream_t)stream>>>((const half_t*)q, ldq, q_batch_stride, (const half_t*)kv, ldkv,
                                                                                       k_off, v_off, (half_t*)out, L, H, causal, NT, KR, (int)nitems);
         else
-            attention_pipe_kernel<8, 2><<<(int)grid, 512, plds, (hipStream_t)stream>>>((const half_t*)q, ldq, q_batch_stride, (const half_t*)kv, ldkv,
+            attention_pipe_kernel<8, 2, PCLIP_ATT_VAR_LONG><<<(int)grid, 512, plds, (hipStream_t)stream>>>((const half_t*)q, ldq, q_batch_stride, (const half_t*)kv, ldkv,
                                                                                       k_off, v_off, (half_t*)out, L, H, causal, NT, KR, (int)nitems);
         return pclip_check_launch("attention (pipelined)");
     }
     const size_t lds = 2 * (size_t)LP * ATT_DH * 2;
+    // The softmax variant follows the SEQUENCE (more than four key tiles: the long form), not the kernel: the one-query form of the
+    // last vision block (Lq = 1, four waves) must produce the bits of the full attention over the same keys.
     static DevOnce attr_set;
     if (!attr_set.done()) {
-        (void)hipFuncSetAttribute((const void*)attention_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        if (hipFuncSetAttribute((const void*)attention_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) {
-            pclip_set_error("pclip_attention_f16: cannot raise the dynamic LDS limit");
-            return PCLIP_E_LAUNCH;
-        }
+        const void* fns[] = {(const void*)attention_kernel<8, PCLIP_ATT_VAR_LONG>, (const void*)attention_kernel<4, PCLIP_ATT_VAR_LONG>,
+                             (const void*)attention_kernel<4, PCLIP_ATT_VAR_SHORT>};
+        for (const void* f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) {
+                pclip_set_error("pclip_attention_f16: cannot raise the dynamic LDS limit");
+                return PCLIP_E_LAUNCH;
+            }
         attr_set.set();
     }
     // more than four query tiles (ViT-B/16: 7, ViT-L/14: 9): eight waves, one tile each, two workgroups = four waves per SIMD
     // (VGPRs capped at 128); measured 438 -> 424 us (ViT-B/16), 224 -> 200 us (ViT-L/14), bit-identical.  Short sequences
     // (ViT-B/32: 2 tiles, text: 3) keep the four-wave workgroup, whose idle waves cost less.
-    if ((Lq + 31) / 32 > 4)
-        attention_kernel<8><<<B * H, 512, lds, (hipStream_t)stream>>>((const half_t*)q, ldq, q_batch_stride, (const half_t*)kv, ldkv, k_off, v_off,
-                                                                   (half_t*)out, L, Lq, H, causal, NT, LV);
-    else
-    attention_kernel<4><<<B * H, 256, lds, (hipStream_t)stream>>>((const half_t*)q, ldq, q_batch_stride, (const half_t*)kv, ldkv, k_off, v_off,
-                                                                (half_t*)out, L, Lq, H, causal, NT, LV);
+#define PCLIP_ATT_LAUNCH(NW, VAR)                                                                                                         \
+    attention_kernel<NW, VAR><<<B * H, NW * 64, lds, (hipStream_t)stream>>>((const half_t*)q, ldq, q_batch_stride, (const half_t*)kv, ldkv, k_off, \
+                                                                             v_off, (half_t*)out, L, Lq, H, causal, NT, LV)
+    if ((Lq + 31) / 32 > 4) PCLIP_ATT_LAUNCH(8, PCLIP_ATT_VAR_LONG);
+    else if (NT > 4) PCLIP_ATT_LAUNCH(4, PCLIP_ATT_VAR_LONG);
+    else PCLIP_ATT_LAUNCH(4, PCLIP_ATT_VAR_SHORT);
+#undef PCLIP_ATT_LAUNCH
     return pclip_check_launch("attention");
 }
 

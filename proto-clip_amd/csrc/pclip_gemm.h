@@ -433,6 +433,8 @@ __device__ __forceinline__ void mainloop_sr(const TilePair<C>& tp, int nt, char*
     const int col0 = (q ^ key) << 4;
     const int offa = (wm * (C::BM / C::WM) + (lane & 15)) * ROW_BYTES + col0;
     const int offb = C::A_BYTES + (wn * (C::BN / C::WN) + (lane & 15)) * ROW_BYTES + col0;
+    // (s_setprio measured on this loop, tools/ab_multi.py gemm, profiles/r03_ab_gemm_prio.txt: priority 1 around every MFMA group
+    // is neutral at N = 3072 and 5 - 32 % SLOWER at N = 768 / 2304; a static priority for the younger half of the waves is +-0.5 %.)
 
 #if PCLIP_TRACE && defined(__HIP_DEVICE_COMPILE__)
 #define PCLIP_STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")

@@ -69,6 +69,73 @@ def sharded_prototypes(mem_shard, labels_shard, N: int, per_shot_norm: bool = Tr
     return finalize_fn(all_sums, all_counts, fp32_out=fp32_out)
 
 
+class PrototypeExchange:
+    """The prototype reduction + all-gather of a step on a SIDE stream, overlapped with the encoder forward (the only coupling
+    between ranks is 2.05 MB per rank, needed only by the classification at the END of the step):
+
+        ex.launch(bank_shard, labels_shard, N)      # step start: partial sums -> all-gather -> rank-ordered combine, side stream
+        ... encode_image, normalise, adapter on the current stream ...
+        zi = ex.result()                            # the current stream waits for the side stream here
+
+    so that at N > 1 the step costs what the encoder costs.  CPU tensors (the gloo tests) run inline."""
+
+    def __init__(self):
+        self.stream = None
+        self.out = None
+
+    def launch(self, mem_shard, labels_shard, N, **kw):
+        if not mem_shard.is_cuda:
+            self.out = sharded_prototypes(mem_shard, labels_shard, N, **kw)
+            return self
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(mem_shard.device)
+        self.stream.wait_stream(torch.cuda.current_stream(mem_shard.device))      # the bank may have been written on the main stream
+        with torch.cuda.stream(self.stream):
+            self.out = sharded_prototypes(mem_shard, labels_shard, N, **kw)
+        return self
+
+    def result(self):
+        out, self.out = self.out, None
+        if self.stream is not None and out is not None and out.is_cuda:
+            cur = torch.cuda.current_stream(out.device)
+            cur.wait_stream(self.stream)
+            out.record_stream(cur)                                                # allocated on the side stream, consumed on this one
+        return out
+
+
+class HipPath:
+    """The stages of one hot-path step on the HIP kernels (`hot_path_step`'s default implementation)."""
+
+    def __init__(self, model, adapter):
+        self.model, self.adapter = model, adapter
+
+    def encode(self, images):
+        return self.model.encode_image(images)                                    # clip/model.py:338
+
+    def l2norm(self, f):
+        from . import ops
+        return ops.l2norm_rows(f, out=f)                                          # utils.py:352
+
+    def adapt(self, f):
+        return self.adapter(f, l2norm_out=True)                                   # model.py:49-78 + main.py:408-409
+
+    def classify(self, a, zi, zt, alpha, beta):
+        from . import ops
+        return ops.classify(a, zi, zt, alpha, beta, want_p=False, want_argmax=True)[1]   # utils.py:225-244 + main.py:190
+
+
+def hot_path_step(path, exchange, bank_shard, labels_shard, N, images, text_proto, alpha, beta, **proto_kw):
+    """One step of the sharded hot path on THIS rank (bench.py's step): prototypes from the rank-sharded support bank
+    (exchanged on the side stream), this rank's query images through encoder -> normalise -> adapter, classification against both
+    banks.  Returns the top-1 class of this rank's queries.  `path` supplies the stage implementations (HipPath on the GPU; the
+    gloo test injects the oracle's)."""
+    exchange.launch(bank_shard, labels_shard, N, **proto_kw)
+    f = path.l2norm(path.encode(images))
+    a = path.adapt(f)
+    zi = exchange.result()
+    return path.classify(a, zi, text_proto, alpha, beta)
+
+
 def allreduce_counts(correct: torch.Tensor, total: int, group=None):
     """Sum integer correct-counts (e.g. the [na, nb] sweep grid) and sample totals over ranks."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:

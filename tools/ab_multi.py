@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Interleaved A/B of several builds of libpclip in ONE process (same tensors, round-robin order that reverses every round):
+    python tools/ab_multi.py attn base av1 av3 ...      pclip_attention_f16 on the encoder shapes; also max|d| vs the base build and vs fp32 torch
+    python tools/ab_multi.py gemm base gp1 gp2 ...      pclip_gemm_f16 on the bench's four linear shapes (bias / bias + QuickGELU / bias + residual)
+`base` = proto-clip_amd/libpclip.so, any other tag = proto-clip_amd/libpclip_<tag>.so (tools/build_variants.sh)."""
+import ctypes, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from kernel_bench import timeit
+root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "proto-clip_amd")
+mode, tags = sys.argv[1], sys.argv[2:]
+libs = {t: ctypes.CDLL(os.path.join(root, "libpclip.so" if t == "base" else f"libpclip_{t}.so")) for t in tags}
+P = ctypes.c_void_p
+st = lambda: P(torch.cuda.current_stream().cuda_stream)
+
+
+def rounds(call, n=6, iters=8):
+    res = {x: [] for x in libs}
+    for r in range(n):
+        for x in (list(libs) if r % 2 == 0 else list(libs)[::-1]):
+            res[x].append(timeit(lambda: call(x), iters=iters, warm=2) * 1e6)
+    return {x: sorted(v)[len(v) // 2] for x, v in res.items()}
+
+
+if mode == "attn":
+    for l in libs.values():
+        l.pclip_attention_f16.argtypes = [P, P] + [ctypes.c_int] * 5 + [P]
+    for name, B, L, H, causal in (("ViT-B/16", 1024, 197, 12, 0), ("ViT-L/14", 256, 257, 16, 0), ("ViT-B/32", 1024, 50, 12, 0), ("text", 7000, 77, 8, 1)):
+        g = torch.Generator(device="cuda").manual_seed(L)
+        qkv = torch.randn(B * L, 3 * H * 64, device="cuda", generator=g).half()
+        out = {x: torch.zeros(B * L, H * 64, device="cuda", dtype=torch.float16) for x in libs}
+        def call(x):
+            assert libs[x].pclip_attention_f16(P(qkv.data_ptr()), P(out[x].data_ptr()), B, L, H, 64, causal, st()) == 0
+        med = rounds(call)
+        # accuracy on a slice: fp32 softmax attention of the first 8 images
+        nb = min(B, 8)
+        q, k, v = (t.float().view(nb, L, H, 64).transpose(1, 2) for t in qkv[:nb * L].split(H * 64, dim=1))
+        s = q @ k.transpose(-1, -2) * 0.125
+        if causal:
+            s = s + torch.full((L, L), float("-inf"), device="cuda").triu_(1)
+        ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(nb * L, H * 64)
+        base = next(iter(libs))
+        print(f"{name:9s} " + " | ".join(f"{x} {med[x]:7.1f} us (d_base {(out[x].float() - out[base].float()).abs().max().item():.1e}, err {(out[x][:nb * L].float() - ref).abs().max().item():.1e})"
+                                         for x in libs), flush=True)
+else:
+    for l in libs.values():
+        l.pclip_gemm_f16.argtypes = [P, ctypes.c_int, P, ctypes.c_int, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, P, ctypes.c_int, P, P]
+    for m, n, k in [(201728, 3072, 768), (201728, 2304, 768), (201728, 768, 768), (201728, 768, 3072)]:
+        a = torch.randn(m, k, device="cuda").half(); w = (torch.randn(n, k, device="cuda") * k ** -0.5).half()
+        bias = torch.randn(n, device="cuda").half(); out = {x: torch.empty(m, n, device="cuda", dtype=torch.float16) for x in libs}
+        resid = torch.randn(m, n, device="cuda").half() if n <= 1024 else None
+        cases = {"bias+gelu": (bias, 1, None)} if n == 3072 else ({"bias+res": (bias, 0, resid)} if resid is not None else {"bias": (bias, 0, None)})
+        for name, (b, act, rs) in cases.items():
+            def call(x):
+                assert libs[x].pclip_gemm_f16(P(a.data_ptr()), k, P(w.data_ptr()), k, P(out[x].data_ptr()), n, m, n, k, P(b.data_ptr()), act,
+                                              P(rs.data_ptr()) if rs is not None else None, st()) == 0
+            med = rounds(call, n=6, iters=6)
+            base = next(iter(libs))
+            print(f"{m}x{n}x{k} {name:9s} " + " | ".join(f"{x} {med[x]:7.1f} us ({2.0 * m * n * k / med[x] / 1e6:5.0f} TF{'' if torch.equal(out[x], out[base]) else ' DIFF'})" for x in libs), flush=True)
