@@ -261,6 +261,9 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         }
         if (AFFINE) copy_affine(tile + G < ntiles ? tile + G : tile, parity ^ 1);
         if (LNF) copy_stats(tile + G < ntiles ? tile + G : tile, parity ^ 1);
+        // (Measured and rejected, profiles/r03_ab_rejected.txt: pulling the residual tile's 1024 lines into L2 during the K-loop with one
+        // 4-byte LDS-DMA per line — out_proj 301 -> 341 us, c_proj 854 -> 879 us: 1024 more requests per tile in the queue the operand
+        // DMAs wait in.)
 #if PCLIP_SR
         if (M16) pgemm::mainloop_sr<C, YOUNGER, !HAS_BIAS>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, tr);
 #else
@@ -676,6 +679,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
     }
 }
 
+// (Measured and rejected, profiles/r03_ab_rejected.txt: two rows per wave + gamma / beta hoisted into registers + non-temporal stores of h
+// — 152 vs 139 us on [201 728, 768] stand-alone, 123 vs 43 us on [65 792, 1024]: the 32 extra registers cost more occupancy than
+// the extra loads in flight bring.)
 // (mean, rstd) of a row for a LayerNorm folded into the consuming linear (ln_fold).  NOT layernorm_kernel's arithmetic: that one is
 // two-pass fp32 (mean, then the sum of squared deviations); these are ONE-pass sums (sum, sum of squares) in the canonical
 // association order of stats_chunk / stats_butterfly and var = E[x^2] - mean^2, clamped at 0 — so that the GEMM epilogue that writes
@@ -839,7 +845,7 @@ constexpr int ATT_DH = 64;
 constexpr int ATT_MAX_L = 288;
 // Softmax variants of attn_query_tile (bit mask VAR; same-process A/B of the seven combinations, tools/ab_multi.py attn,
 // profiles/r03_ab_attention_var.txt — ViT-B/16, B = 1024: 336 us -> 306 us with all four, each contributing):
-//   1  deferred maximum: the running maximum only moves when some row of the wave outgrew it by more than 2^kAttDefer; in between the
+//   1  deferred maximum: a row's running maximum only moves when the row outgrew it by more than 2^kAttDefer; in between the
 //      probabilities are taken against the OLD maximum (they reach 2^kAttDefer instead of 1: exact in fp32, and the fp16 rounding of
 //      P is relative) and the rescale of the 32 output accumulators (+ its v_exp) is skipped.  On N(0,1) data the maximum of a later
 //      key tile practically never exceeds the first tiles' by a factor 4, so the rescale runs once per query tile instead of 4 times.
@@ -987,9 +993,12 @@ __device__ __forceinline__ void attn_query_tile(const half_t* Ks, const half_t* 
             for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, st[u][e]);
         }
         tmax = half_wave_max(tmax) * kScale;                       // kScale > 0: max commutes with the scaling
-        // VAR & 1: deferred maximum (see above); -inf + kAttDefer = -inf, so the first tile always sets the maximum
-        const bool grow = (VAR & 1) ? __any(tmax > mrun + kAttDefer) : __any(fmaxf(mrun, tmax) != mrun);
-        const float mnew = ((VAR & 1) && !grow) ? mrun : fmaxf(mrun, tmax);     // finite from the first tile on: key 0 is never masked
+        // VAR & 1: deferred maximum (see above), decided PER ROW — a row's bits must not depend on the rows that share its wave (the
+        // one-query form of the last block == the full attention); -inf + kAttDefer = -inf, so the first tile always sets the maximum.
+        // The rescale below is skipped when no row of the wave moved (rows that did not move multiply by exp2(0) = 1 exactly).
+        const bool moved = (VAR & 1) ? tmax > mrun + kAttDefer : fmaxf(mrun, tmax) != mrun;
+        const float mnew = ((VAR & 1) && !moved) ? mrun : fmaxf(mrun, tmax);    // finite from the first tile on: key 0 is never masked
+        const bool grow = __any(moved);
         float psum = 0.f;
         if (VAR & 6) {
             float2_t ps2 = {0.f, 0.f};

@@ -41,6 +41,18 @@ if mode == "attn":
         base = next(iter(libs))
         print(f"{name:9s} " + " | ".join(f"{x} {med[x]:7.1f} us (d_base {(out[x].float() - out[base].float()).abs().max().item():.1e}, err {(out[x][:nb * L].float() - ref).abs().max().item():.1e})"
                                          for x in libs), flush=True)
+elif mode == "ln":
+    for l in libs.values():
+        l.pclip_layernorm_f16.argtypes = [P, ctypes.c_int, P, P, ctypes.c_float, P, ctypes.c_int, ctypes.c_int, P]
+    for R, D in ((201728, 768), (7000 * 77, 512), (257 * 256, 1024)):
+        x = (torch.randn(R, D, device="cuda") * 1.3 + 0.2).half()
+        g, b = 1 + 0.1 * torch.randn(D, device="cuda"), 0.1 * torch.randn(D, device="cuda")
+        out = {t: torch.zeros(R, D, device="cuda", dtype=torch.float16) for t in libs}
+        def call(t):
+            assert libs[t].pclip_layernorm_f16(P(x.data_ptr()), D, P(g.data_ptr()), P(b.data_ptr()), 1e-5, P(out[t].data_ptr()), R, D, st()) == 0
+        med = rounds(call, n=6, iters=10)
+        base = next(iter(libs))
+        print(f"layernorm [{R},{D}] " + " | ".join(f"{t} {med[t]:7.1f} us ({4.0 * R * D / med[t] / 1e6:5.2f} TB/s{'' if torch.equal(out[t], out[base]) else ' DIFF'})" for t in libs), flush=True)
 else:
     for l in libs.values():
         l.pclip_gemm_f16.argtypes = [P, ctypes.c_int, P, ctypes.c_int, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, P, ctypes.c_int, P, P]
