@@ -164,7 +164,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
                                                                      half_t* Cout, int ldc, int tiles_n,
                                                                      int ntiles, const half_t* residual = nullptr,
                                                                      const float* __restrict__ rowstats = nullptr,
-                                                                     float* __restrict__ partials = nullptr) {
+                                                                     float* __restrict__ partials = nullptr, int band = 0) {
     // ACT 5: relu(r16(r16(r16(acc) * scale + shift) + residual)) — bn3 + `out += identity` + ReLU of a bottleneck (clip/model.py:49-52)
     // in the epilogue of its conv3 GEMM; the residual rows are read row-major in the coalesced store pass.
     // ACT 9: ACT 6 + the row-statistics partials of the updated rows (stats_chunk / stats_butterfly) into `partials` [M][N/64][2]
@@ -186,6 +186,18 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     const int G = gridDim.x;
     int tile = pgemm::xcd_remap(blockIdx.x, G);
     if (tile >= ntiles) return;
+    // Linear tile id -> (row block, column tile).  band == 0: column tiles fastest (a round covers whole rows of tiles).  band > 0
+    // (PCLIP_GEMM_BAND, tools/ab_band.py): the output is walked in BANDS of `band` column tiles, row blocks fastest inside a band, so
+    // that for half of the launch every XCD multiplies against the same `band` weight panels (N = 3072, band 6: 2.4 MB of the 4 MiB L2
+    // instead of 4.7) at the price of reading the activations once per band.
+    const int tiles_m_all = ntiles / tiles_n;
+    auto decomp = [&](int t, int& tm, int& tn) {
+        if (band <= 0 || band >= tiles_n) { tm = t / tiles_n; tn = t - tm * tiles_n; return; }
+        const int per_band = tiles_m_all * band, bnd = t / per_band, r = t - bnd * per_band;
+        const int w = band < tiles_n - bnd * band ? band : tiles_n - bnd * band;
+        tm = r / w;
+        tn = bnd * band + r - tm * w;
+    };
     int p = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave % C::WN, hi = lane >> 5;
     pgemm::TilePair<C> tp;                                       // M16: buffer-descriptor staging + pipelined K-loop (pgemm::mainloop_bl)
@@ -193,14 +205,16 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     // r16(sum + bias), same value up to fp32 summation order), so the epilogue has no bias pass.  Its strip is copied one
     // tile ahead (double-buffered); every wave copies the same BN values: uniform vmcnt bookkeeping.
     auto copy_bias = [&](int t, int par) {
-        const int tn = t - (t / tiles_n) * tiles_n;
+        int tm_, tn;
+        decomp(t, tm_, tn);
         if (lane < C::BN / 8)
             __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(bias + tn * C::BN + lane * 8), (pgemm::lds_ptr_t)(bias_lds + par * C::BN), 16, 0, 0);
     };
     // eval-mode BatchNorm (+ReLU) of the ResNet tower (clip/model.py:43-52) as the epilogue of the convolution's GEMM: the
     // per-column scale / shift strips travel like the bias strip, one tile ahead
     auto copy_affine = [&](int t, int par) {
-        const int tn = t - (t / tiles_n) * tiles_n;
+        int tm_, tn;
+        decomp(t, tm_, tn);
         if (lane < C::BN / 4) {
             __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(scale + tn * C::BN + lane * 4), (pgemm::lds_ptr_t)(affine_lds + par * 2 * C::BN), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(shift + tn * C::BN + lane * 4), (pgemm::lds_ptr_t)(affine_lds + par * 2 * C::BN + C::BN), 16, 0, 0);
@@ -209,7 +223,8 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     // LNF: the (mean, rstd) pairs of the tile's BM rows, one tile ahead like the strips; rowstats is allocated in whole 256-row
     // blocks, so the last tile reads (never used) padding instead of running off the end
     auto copy_stats = [&](int t, int par) {
-        const int tm = t / tiles_n;
+        int tm, tn_;
+        decomp(t, tm, tn_);
 #pragma unroll
         for (int i = 0; i < NSTAT; ++i)
             if (NSTAT * 128 == C::BM || lane < (C::BM - i * 128) / 2)
@@ -223,7 +238,8 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         pgemm::lds_barrier();
     }
     {
-        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        int tm, tn;
+        decomp(tile, tm, tn);
         if (M16) {
             tp.prepare(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, wave, lane);
             tp.stage(0, smem + p * C::STAGE_BYTES, wave);
@@ -236,7 +252,8 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     int parity = 0;
     unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (; tile < ntiles; tile += G, parity ^= 1) {
-        const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+        int tile_m, tile_n;
+        decomp(tile, tile_m, tile_n);
         const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
         const bool full = m0 + C::BM <= M;                    // workgroup-uniform: every row of the tile exists
         pgemm::Acc<C> acc;
@@ -272,7 +289,8 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         else pgemm::mainloop<C, YOUNGER, !HAS_BIAS, M16>(A, lda, B, ldb, M, N, K, m0, n0, smem, acc, p, prev_full);
         const int next = tile + G;
         if (next < ntiles) {                                  // buffer p is free: prefetch the next tile's K-tile 0
-            const int tm = next / tiles_n, tn = next - tm * tiles_n;
+            int tm, tn;
+            decomp(next, tm, tn);
             if (M16) {
                 tp.prepare(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, wave, lane);
                 tp.stage(0, smem + p * C::STAGE_BYTES, wave);
@@ -563,9 +581,11 @@ static int launch_fast2(const void* A, int lda, const void* B, int ldb, int M, i
     }
     const int tiles_m = ceil_div(M, C::BM), tiles_n = N / C::BN, ntiles = tiles_m * tiles_n;
     const int grid = ntiles < slots ? ntiles : slots;
+    static const int band_env = getenv("PCLIP_GEMM_BAND") ? atoi(getenv("PCLIP_GEMM_BAND")) : 0;
+    const int band = getenv("PCLIP_GEMM_CFG_LIVE") ? (getenv("PCLIP_GEMM_BAND") ? atoi(getenv("PCLIP_GEMM_BAND")) : 0) : band_env;
     linear_fast_kernel<C, HAS_BIAS, ACT, M16><<<grid, C::NTHREADS, LDS, s>>>(
         (const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi.bias, epi.scale, epi.shift, epi.C, epi.ldc, tiles_n, ntiles, epi.residual,
-        epi.rowstats, epi.partials);
+        epi.rowstats, epi.partials, tiles_n >= 8 ? band : 0);
     return pclip_check_launch("gemm_f16");
 }
 

@@ -70,6 +70,22 @@ def test_gemm_row_split(ops, M, N, K):
         assert launches == 2                                # 2 full rounds of 256x256 tiles + the last 6912 rows
 
 
+def test_gemm_banded_tile_order_is_bit_identical(ops, monkeypatch):
+    """PCLIP_GEMM_BAND (tile order in bands of column tiles): a pure speed knob — same bits, including a
+    ragged last band (12 column tiles in bands of 5) and a partial last row block."""
+    M, N, K = 70001, 3072, 128
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = torch.randn(M, K, device="cuda", generator=g).half()
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).half()
+    b = torch.randn(N, device="cuda", generator=g).half()
+    monkeypatch.setenv("PCLIP_GEMM_CFG_LIVE", "1")
+    ref = ops.gemm(a, w, b, act=1)
+    for band in (6, 5, 1):
+        monkeypatch.setenv("PCLIP_GEMM_BAND", str(band))
+        assert torch.equal(ops.gemm(a, w, b, act=1), ref), band
+    monkeypatch.delenv("PCLIP_GEMM_BAND")
+
+
 @pytest.mark.parametrize("M,N,K,act", [(197, 768, 3072, 0), (1, 768, 3072, 0), (8, 3072, 3072, 1), (32, 512, 3072, 1), (257, 1024, 4096, 0),
                                         (130, 64, 2048, 1), (64, 1024, 4096, 0)])
 def test_gemm_splitk_small_M(ops, M, N, K, act):
@@ -182,16 +198,27 @@ def test_add_layernorm(ops, R, D, L):
 
 @pytest.mark.parametrize("M,N,K,act", [(197, 2304, 768, 0), (1000, 3072, 768, 1), (1, 1536, 512, 0), (3000, 4096, 1024, 1), (5000, 768, 768, 0),
                                        (50432, 768, 512, 1), (333, 64, 128, 0)])
-def test_gemm_ln_fold(ops, M, N, K, act):
+@pytest.mark.parametrize("stats", ["init", "trained"])
+def test_gemm_ln_fold(ops, M, N, K, act, stats):
     """LayerNorm folded into the consuming linear (pclip_row_stats_f16 + pclip_ln_fold_weights_f16 + pclip_gemm_ln_f16) against
     fp32 LayerNorm -> Linear (-> QuickGELU) on the same fp16 inputs, and against the unfolded kernels (LayerNorm pass + GEMM):
     the fold removes the fp16 rounding of h and rounds gamma.W instead, so the two GPU paths agree to a few fp16 ulp of the
     output scale, not bit for bit; a row alone gives exactly the row of the batch (persistent vs ring kernel, any tile)."""
-    x = (torch.from_numpy(synth.normal((M, K), 31, 0)).float() * 1.5 + 0.3 * torch.from_numpy(synth.normal((1, K), 31, 5)).float()).half()
+    x = torch.from_numpy(synth.normal((M, K), 31, 0)).float() * 1.5 + 0.3 * torch.from_numpy(synth.normal((1, K), 31, 5)).float()
     w = (torch.from_numpy(synth.normal((N, K), 31, 1)).float() * K ** -0.5).half()
     bias = (torch.from_numpy(synth.normal((N,), 31, 2)).float() * 0.1).half()
     g = 1.0 + 0.2 * torch.from_numpy(synth.normal((K,), 31, 3)).float()
     be = 0.1 * torch.from_numpy(synth.normal((K,), 31, 4)).float()
+    if stats == "trained":
+        # the statistics of a TRAINED tower (VERDICT r2 item 1b / ADVICE r2): LayerNorm gain log-uniform in [0.2, 5], bias N(0, 0.5),
+        # rows with a mean of up to +-3 sigma, four residual-stream outlier channels of ~50 sigma — where var = E[x^2] - mu^2 and
+        # acc - mu * colsum cancel hardest and r16(gamma * W) rounds weights of very different scales
+        g = torch.exp(torch.from_numpy(synth.uniform(K, 31, 13)).float() * (np.log(5.0) - np.log(0.2)) + np.log(0.2))
+        be = 0.5 * torch.from_numpy(synth.normal((K,), 31, 14)).float()
+        x = x + 3.0 * 1.5 * torch.from_numpy(synth.normal((M, 1), 31, 15)).float().clamp(-1, 1)
+        ch = synth.randint(4, K, 31, 16)
+        x[:, ch] += 50.0 * 1.5 * torch.tensor([1.0, -1.0, 1.0, -1.0])
+    x = x.half()
     xd, wd, bd, gd, bed = x.cuda(), w.cuda(), bias.cuda(), g.cuda(), be.cuda()
     wf, cs, bf = ops.ln_fold_weights(wd, bd, gd, bed)
     assert torch.equal(wf.cpu(), (g[None, :] * w.float()).half())
@@ -200,8 +227,8 @@ def test_gemm_ln_fold(ops, M, N, K, act):
     st = ops.row_stats(xd)
     mu = x.float().mean(1)
     rstd = 1.0 / torch.sqrt(x.float().var(1, unbiased=False) + 1e-5)
-    torch.testing.assert_close(st[:M, 0].cpu(), mu, rtol=1e-5, atol=1e-6)
-    torch.testing.assert_close(st[:M, 1].cpu(), rstd, rtol=1e-5, atol=0)
+    torch.testing.assert_close(st[:M, 0].cpu(), mu, rtol=1e-5, atol=1e-5 if stats == "trained" else 1e-6)
+    torch.testing.assert_close(st[:M, 1].cpu(), rstd, rtol=1e-5, atol=0)           # one-pass variance: holds with a 3 sigma row mean and 50 sigma outliers
     y = ops.gemm_ln(xd, st, wf, cs, bf, act=act)
     ref = torch.nn.functional.layer_norm(x.float(), [K], g, be) @ w.float().t() + bias.float()
     unf = ops.gemm(ops.layernorm(xd, gd, bed), wd, bd, act=act)
@@ -211,8 +238,8 @@ def test_gemm_ln_fold(ops, M, N, K, act):
     scale = ref.abs().max().item()
     e_fold = (y.float().cpu() - ref).abs().max().item() / scale
     e_unf = (unf.float().cpu() - ref).abs().max().item() / scale
-    observe(f"gemm_ln fold vs fp32 LN+linear (act {act}): max|d| / max|ref|", e_fold, 2e-3)
-    observe(f"unfolded LN pass + gemm vs fp32 LN+linear (act {act}): max|d| / max|ref| (yard-stick)", e_unf, 2e-3)
+    observe(f"gemm_ln fold vs fp32 LN+linear (act {act}, {stats} statistics): max|d| / max|ref|", e_fold, 2e-3)
+    observe(f"unfolded LN pass + gemm vs fp32 LN+linear (act {act}, {stats} statistics): max|d| / max|ref| (yard-stick)", e_unf, 2e-3)
     assert e_fold <= 2e-3 and e_fold <= 2.0 * e_unf + 2e-4
     # batch invariance: single rows / a small block through the ring kernel == the rows of the big call
     for r in sorted({0, M // 2, M - 1}):
