@@ -414,6 +414,9 @@ __device__ __forceinline__ void mainloop_bl(const TilePair<C>& tp, int nt, char*
 #ifndef PCLIP_TRACE
 #define PCLIP_TRACE 0            // debug build: s_memtime stamps around every wait of the K-loop (tools/trace_gemm.py)
 #endif
+#ifndef PCLIP_IGLP
+#define PCLIP_IGLP 1             // __builtin_amdgcn_iglp_opt strategy of the K-loop's first scheduling region (-1: none; 0 / 2 / 3 measured: no gain)
+#endif
 template <class C, int YOUNGER = 0, bool ZERO_ACC = true>
 __device__ __forceinline__ void mainloop_sr(const TilePair<C>& tp, int nt, char* smem, Acc<C>& acc, int& p, bool counted_first, int wave,
                                             int lane, unsigned long long* g_tr = nullptr) {
@@ -494,6 +497,9 @@ __device__ __forceinline__ void mainloop_sr(const TilePair<C>& tp, int nt, char*
                         }
         };
         const bool refill = t + 2 < nt;                               // workgroup-uniform
+#if PCLIP_IGLP >= 0 && defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_iglp_opt(PCLIP_IGLP);   // LLVM's DS-read / MFMA interleaving for the region behind the first barrier: +1.4 - 2.2 % on every bench shape (r03_ab_gemm_sched.txt), same bits
+#endif
         load_b(bcur, 0);
         load_a(acur, 0, 0);
         if (t == 0 && nt > 1 && !(PCLIP_ABL & 1)) tp.stage(1, smem + (p ^ 1) * C::STAGE_BYTES, wave);   // the other buffer was the previous tile's epilogue staging area until the barrier above
@@ -533,6 +539,12 @@ __device__ __forceinline__ void mainloop_sr(const TilePair<C>& tp, int nt, char*
     { PCLIP_STAMP(tr_end); g_tr[6] += tr_end - tr_begin; g_tr[7] += nt; }
 #endif
 }
+
+// (Measured and removed, profiles/r03_ab_gemm_sched.txt: the same loop software-pipelined ACROSS the K-tile boundary — the barrier that
+// publishes K-tile t + 1 moved in front of the last MFMA group of iteration t and the first fragments of t + 1 requested under that
+// group, so that an iteration starts issuing MFMAs at once.  Bit-identical and 4 - 6 % SLOWER: waiting for K-tile t + 1 a quarter of an
+// iteration earlier exposes the operand delivery itself — the LDS-DMA round trip of ~1.25 iterations is what this loop waits for, not
+// the fragment latency behind the first barrier.)
 
 // ---- implicit-GEMM gather for a 3x3 / stride 1 / pad 1 convolution on NHWC fp16 activations ------------------------------
 // Row m of the GEMM is output pixel (b, y, x); K-tile t covers tap = (t*64) / Cin and input channels c0 = (t*64) % Cin

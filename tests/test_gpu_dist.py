@@ -53,6 +53,15 @@ def _worker(rank, world, port, ret):
         proto = sharded_prototypes(rows[lo:hi], labels[lo:hi], N)
         ref = proto.clone()
         dist.broadcast(ref, 0)
+        # the side-stream exchange of bench.py's step (dist.PrototypeExchange): launched, other work on the main stream, joined
+        from proto_clip_amd.dist import PrototypeExchange
+        ex = PrototypeExchange()
+        side_ok = True
+        for _ in range(3):
+            ex.launch(rows[lo:hi], labels[lo:hi], N)
+            busy = ops.l2norm_rows(rows)                    # main-stream work while the all-gather is in flight
+            side_ok = side_ok and torch.equal(ex.result(), proto)
+        del busy
         tot, n = allreduce_counts(torch.tensor([[rank + 1, 2]], dtype=torch.int32, device="cuda"), 10 + rank)
         tr, l_dist = train()
         v = tr.visual.clone()
@@ -61,12 +70,12 @@ def _worker(rank, world, port, ret):
         f0 = flat.clone()
         dist.broadcast(f0, 0)
         ok = torch.tensor([int(torch.equal(ref, proto)), int(torch.equal(proto, proto_single)), int(torch.equal(v, tr.visual)),
-                           int(torch.equal(f0, flat))], device="cuda")
+                           int(torch.equal(f0, flat)), int(side_ok)], device="cuda")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if rank == 0:
             ret["world"] = dist.get_world_size()
             ret["backend"] = dist.get_backend()
-            ret["ranks_identical_protos"], ret["equal_single_gpu"], ret["ranks_identical_bank"], ret["ranks_identical_adapter"] = [bool(x) for x in ok.tolist()]
+            ret["ranks_identical_protos"], ret["equal_single_gpu"], ret["ranks_identical_bank"], ret["ranks_identical_adapter"], ret["side_stream_exchange"] = [bool(x) for x in ok.tolist()]
             ret["counts"], ret["n"] = tot.tolist(), n
             ret["losses"] = (l_single, l_dist)
             ret["bank_diff"] = (tr.visual.float() - single.visual.float()).abs().max().item()
@@ -85,6 +94,7 @@ def test_sharded_prototypes_and_dp_step_over_rccl(world):
     assert ret["world"] == world and ret["backend"] == "nccl"
     assert ret["ranks_identical_protos"] and ret["equal_single_gpu"], "sharded prototypes differ between ranks / from the one-GPU kernel"
     assert ret["ranks_identical_bank"] and ret["ranks_identical_adapter"], "data-parallel step left the ranks with different parameters"
+    assert ret["side_stream_exchange"], "PrototypeExchange (all-gather on the side stream) != the in-line exchange"
     s = sum(range(1, world + 1))
     assert ret["counts"] == [[s, 2 * world]] and ret["n"] == sum(10 + r for r in range(world))
     l_single, l_dist = ret["losses"]
