@@ -200,7 +200,9 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     };
     int p = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave % C::WN, hi = lane >> 5;
-    pgemm::TilePair<C> tp;                                       // M16: buffer-descriptor staging + pipelined K-loop (pgemm::mainloop_bl)
+    // M16: buffer-descriptor staging + pipelined K-loop; eight-wave tiles split the DMA issue by wave role (pgemm::TilePairR)
+    using TP = std::conditional_t<(PCLIP_DMA_ROLES && PCLIP_SR && C::NWAVES == 8), pgemm::TilePairR<C>, pgemm::TilePair<C>>;
+    TP tp;
     // The bias enters as the INITIAL VALUE of the accumulators (fp32 copy of the fp16 bias: r16(bias + sum) instead of
     // r16(sum + bias), same value up to fp32 summation order), so the epilogue has no bias pass.  Its strip is copied one
     // tile ahead (double-buffered); every wave copies the same BN values: uniform vmcnt bookkeeping.
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         // 4-byte LDS-DMA per line — out_proj 301 -> 341 us, c_proj 854 -> 879 us: 1024 more requests per tile in the queue the operand
         // DMAs wait in.)
 #if PCLIP_SR
-        if (M16) pgemm::mainloop_sr<C, YOUNGER, !HAS_BIAS>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, tr);
+        if (M16) pgemm::mainloop_sr<C, YOUNGER, !HAS_BIAS, TP>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, tr);
 #else
         if (M16) pgemm::mainloop_bl<C, YOUNGER, !HAS_BIAS, PCLIP_PF>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, smem + C::LDS_BYTES + STRIP_BYTES);
 #endif
@@ -298,7 +300,11 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
                 pgemm::stage_first<C>(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, smem, p);
         }
         char* stg = smem + (p ^ 1) * C::STAGE_BYTES;          // buffer of the last K-tile, reused after a barrier
-        const int col = n0 + 8 * (tid % C::CPR);
+        int etid = tid;                                       // opaque copy: the epilogue's lane constants are recomputed per tile (pgemm::epilogue_f16)
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(etid));
+#endif
+        const int col = n0 + 8 * (etid % C::CPR);
         // LNF: the lane's column strips (colsum | folded bias for its 4 columns of every (j, g & 1)) and row statistics ((mean, rstd)
         // of its row in every (i, g >> 1)) are read from LDS ONCE per tile into registers (the K-loop's fragment registers are free
         // here): read inside `pre` they were 96 LDS reads per lane and slab, re-issued behind every staging write, and the epilogue
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             if (!RES) return;
 #pragma unroll
             for (int ps = 0; ps < C::NPASS; ++ps) {
-                const int r = h * C::HR + tid / C::CPR + ps * C::ROWS_PER_PASS;
+                const int r = h * C::HR + etid / C::CPR + ps * C::ROWS_PER_PASS;
                 if (full || m0 + r < M) rr[ps] = ld_half8(residual + (size_t)(m0 + r) * ldc + col);
             }
         };

@@ -267,6 +267,8 @@ struct TileSrc {
 
 template <class C>
 struct TilePair {
+    static constexpr bool ROLES = false;
+    static constexpr int NA = TileSrc<C::BM, C::NWAVES>::NL, NB = TileSrc<C::BN, C::NWAVES>::NL;
     TileSrc<C::BM, C::NWAVES> a;
     TileSrc<C::BN, C::NWAVES> b;
     int pf_voff;                  // L2 prefetch (below): byte offset of this lane's row in the operand wave `wave` touches
@@ -297,6 +299,68 @@ struct TilePair {
     __device__ __forceinline__ void stage(int t, char* stage_buf, int wave) const {
         a.template stage<PCLIP_NT_A>(t * (BK * 2), stage_buf, wave);
         b.template stage<0>(t * (BK * 2), stage_buf + C::A_BYTES, wave);
+    }
+};
+
+// ---- role split of the LDS-DMA issue (eight-wave tiles) ---------------------------------------------------------------------
+// An LDS-DMA instruction costs its wave 60 - 185 issue cycles (guide, microarch table) during which the wave issues no MFMA, and in
+// TilePair every wave issues four pieces at each refill point — i.e. BOTH waves of every SIMD (w and w + 4) stall on DMA issue at the
+// same moment, right behind the same barrier, and the matrix pipe of that SIMD idles.  Here waves 0 - 3 stage the whole B tile (at the B
+// refill point) and waves 4 - 7 the whole A tile (at the A refill point): each wave still issues (BM or BN) / 32 pieces per K-tile, but in
+// one burst while its SIMD partner feeds the matrix pipe.  Same LDS image, same fragment order: bit-identical results.
+#ifndef PCLIP_DMA_ROLES
+#define PCLIP_DMA_ROLES 1
+#endif
+template <class C>
+struct TilePairR {
+    static constexpr bool ROLES = true;
+    static_assert(C::NWAVES == 8, "role split: waves w and w + 4 share a SIMD");
+    static constexpr int NA = C::BM / 32, NB = C::BN / 32;             // pieces per A wave / per B wave and K-tile
+    static_assert(C::BM % 64 == 0 && C::BN % 64 == 0, "a wave stages ROWS / 4 rows, a multiple of 16");
+    // Per-lane state: TWO byte offsets.  Piece i of a wave covers rows w4 * ROWS/4 + 8 i + (lane >> 3); the swizzle key (row >> 1) & 7
+    // only depends on the parity of i, so piece i = piece (i & 1) + (i >> 1) * 16 rows, and those 16 rows travel in the instruction's
+    // SCALAR offset together with the K-tile.  Rows beyond the operand are not clamped but cut off by the descriptor's size (a buffer
+    // load past num_records returns zeros; such rows are never stored).
+    rsrc_t rs;
+    int voff[2];
+    int row16;                                                        // bytes of 16 operand rows (wave-uniform)
+    bool is_b;                                                        // wave-uniform
+    __device__ __forceinline__ void prepare(const half_t* __restrict__ A, int lda, const half_t* __restrict__ B, int ldb, int M, int N,
+                                            int m0, int n0, int wave, int lane) {
+        is_b = wave < 4;
+        const half_t* g = is_b ? B : A;
+        const int ld = is_b ? ldb : lda, row0 = is_b ? n0 : m0, nrows = is_b ? N : M, rpw = (is_b ? C::BN : C::BM) / 4, w4 = wave & 3;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint64_t addr = (uint64_t)(g + (size_t)row0 * ld);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)addr), hi = __builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
+        const long left = (long)(nrows - row0) * ld * 2;               // bytes from the tile's first row to the end of the operand
+        const uint32_t size = __builtin_amdgcn_readfirstlane((uint32_t)(left < 0x7fffffffL ? left : 0x7fffffffL));
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, size, 0x00020000);
+#endif
+        row16 = 16 * ld * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = w4 * rpw + i * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ swz_key(r);
+            voff[i] = (r * ld + c * 8) * 2;
+        }
+    }
+    // this wave's share of K-tile t into stage buffer `stage_buf` (A image at +0, B image at +A_BYTES)
+    __device__ __forceinline__ void stage(int t, char* stage_buf, int wave) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int w4 = wave & 3, k = t * (BK * 2);
+        if (is_b) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(stage_buf + C::A_BYTES + (w4 * (C::BN / 4) + i * 8) * ROW_BYTES), 16, voff[i & 1],
+                                                         k + (i >> 1) * row16, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(stage_buf + (w4 * (C::BM / 4) + i * 8) * ROW_BYTES), 16, voff[i & 1],
+                                                         k + (i >> 1) * row16, 0, PCLIP_NT_A);
+        }
+#endif
     }
 };
 
@@ -417,12 +481,18 @@ __device__ __forceinline__ void mainloop_bl(const TilePair<C>& tp, int nt, char*
 #ifndef PCLIP_IGLP
 #define PCLIP_IGLP 1             // __builtin_amdgcn_iglp_opt strategy of the K-loop's first scheduling region (-1: none; 0 / 2 / 3 measured: no gain)
 #endif
-template <class C, int YOUNGER = 0, bool ZERO_ACC = true>
-__device__ __forceinline__ void mainloop_sr(const TilePair<C>& tp, int nt, char* smem, Acc<C>& acc, int& p, bool counted_first, int wave,
+template <class C, int YOUNGER = 0, bool ZERO_ACC = true, class TP = TilePair<C>>
+__device__ __forceinline__ void mainloop_sr(const TP& tp, int nt, char* smem, Acc<C>& acc, int& p, bool counted_first, int wave,
                                             int lane, unsigned long long* g_tr = nullptr) {
     static_assert(C::TM >= 2 && C::TM % 2 == 0, "group pipeline splits the wave's A rows in two halves");
     constexpr int HM = C::TM / 2;
-    constexpr int NA = TileSrc<C::BM, C::NWAVES>::NL, NB = TileSrc<C::BN, C::NWAVES>::NL;
+    constexpr int NA = TP::NA, NB = TP::NB;
+    // requests of ONE K-tile this wave leaves in flight across the top barrier: every wave NA + NB pieces (TilePair), or the pieces
+    // of its own operand (TilePairR)
+    auto wait_ahead = [&]() {
+        if constexpr (TP::ROLES) { if (wave < 4) wait_vm<NB>(); else wait_vm<NA>(); }
+        else wait_vm<NA + NB>();
+    };
     const int wm = wave / C::WN, wn = wave % C::WN;
     if (ZERO_ACC) {
 #pragma unroll
@@ -448,7 +518,7 @@ __device__ __forceinline__ void mainloop_sr(const TilePair<C>& tp, int nt, char*
     for (int t = 0; t < nt; ++t) {
         PCLIP_STAMP(tr0);
         if (t == 0) { if (counted_first) wait_vm<YOUNGER>(); else wait_vm<0>(); }
-        else if (t + 1 < nt) wait_vm<NA + NB>();
+        else if (t + 1 < nt) wait_ahead();
         else wait_vm<0>();
         PCLIP_STAMP(tr1);
         lds_barrier();
@@ -517,7 +587,8 @@ __device__ __forceinline__ void mainloop_sr(const TilePair<C>& tp, int nt, char*
 #if PCLIP_TRACE && defined(__HIP_DEVICE_COMPILE__)
             g_tr[2] += tr4 - tr3; g_tr[3] += tr5 - tr4;
 #endif
-            if (!(PCLIP_ABL & 1)) tp.b.template stage<0>((t + 2) * (BK * 2), cur + C::A_BYTES, wave);
+            if constexpr (TP::ROLES) { if (wave < 4) tp.stage(t + 2, cur, wave); }
+            else if (!(PCLIP_ABL & 1)) tp.b.template stage<0>((t + 2) * (BK * 2), cur + C::A_BYTES, wave);
         }
         load_a(anext, 1, 1);
         group(acur, bnext, 0);                   // ks 1, rows half 0
@@ -530,7 +601,8 @@ __device__ __forceinline__ void mainloop_sr(const TilePair<C>& tp, int nt, char*
 #if PCLIP_TRACE && defined(__HIP_DEVICE_COMPILE__)
             g_tr[4] += tr7 - tr6; g_tr[5] += tr8 - tr7;
 #endif
-            if (!(PCLIP_ABL & 1)) tp.a.template stage<PCLIP_NT_A>((t + 2) * (BK * 2), cur, wave);
+            if constexpr (TP::ROLES) { if (wave >= 4) tp.stage(t + 2, cur, wave); }
+            else if (!(PCLIP_ABL & 1)) tp.a.template stage<PCLIP_NT_A>((t + 2) * (BK * 2), cur, wave);
         }
         group(anext, bnext, 1);                  // ks 1, rows half 1
         p ^= 1;
@@ -687,7 +759,14 @@ __device__ __forceinline__ void mainloop_ring(const half_t* __restrict__ A, int 
 //          512-byte / 256-byte row segments: 16-byte fully coalesced global stores.
 template <class C, bool M16 = false, class Slab, class Pre, class Post>
 __device__ __forceinline__ void epilogue_f16(const Acc<C>& acc, char* stg, const Slab& slab, const Pre& pre, const Post& post) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // The lane-constant addressing of the epilogue is recomputed per tile from an OPAQUE copy of the thread id: hipcc otherwise hoists
+    // it out of the persistent tile loop and keeps ~10 registers live across the K-loop — spilled around it in the residual kernels
+    // (scratch reloads beside LDS-DMA drain the vector-memory counter, guide: "recompute per block").
+    int tid = threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(tid));
+#endif
+    const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / C::WN, wn = wave % C::WN, hi = lane >> 5;
     constexpr int RB = C::BN * 2;                                    // bytes per staged row
     constexpr int WROWS = C::BM / C::WM;                             // rows per wave
