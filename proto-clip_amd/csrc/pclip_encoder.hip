@@ -705,7 +705,70 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
     }
 }
 
-// (Measured and rejected, profiles/r03_ab_rejected.txt: two rows per wave + gamma / beta hoisted into registers + non-temporal stores of h
+// The whole-batch LayerNorm pass of the towers (MODE 0, fp32 affine) with the NEXT row's loads requested before the current row's two
+// wave reductions (each a chain of six ds_bpermute round trips): one more 16 / 24 bytes per lane in flight, 8 registers.  Same arithmetic
+// and summation order per row as layernorm_kernel.
+#ifndef PCLIP_LN_PF
+#define PCLIP_LN_PF 1
+#endif
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_pf_kernel(const half_t* __restrict__ x, int ld_x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, half_t* __restrict__ y, int R, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, stride = gridDim.x * 4;
+    int row = blockIdx.x * 4 + wave;
+    half8_t cur[NCH], nxt[NCH];
+    auto load = [&](half8_t (&h)[NCH], int r) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            if (c * 512 + lane * 8 < D) h[c] = ld_half8(x + (size_t)r * ld_x + c * 512 + lane * 8);
+    };
+    if (row < R) load(cur, row);
+    for (; row < R; row += stride) {
+        if (row + stride < R) load(nxt, row + stride);
+        float v[NCH][8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (c * 512 + lane * 8 < D) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { v[c][j] = (float)cur[c][j]; s += v[c][j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+            }
+        }
+        const float mean = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            if (c * 512 + lane * 8 < D) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float t = v[c][j] - mean; q += t * t; }
+            }
+        const float rstd = 1.f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int d = c * 512 + lane * 8;
+            if (d < D) {
+                half8_t o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float t = (v[c][j] - mean) * rstd * (float)gamma[d + j] + (float)beta[d + j];
+                    t = r16(t);
+                    o[j] = (half_t)t;
+                }
+                st_half8(y + (size_t)row * D + d, o);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) cur[c] = nxt[c];
+    }
+}
+
+// (Measured and rejected, profiles/r03_ab_rejected.txt: TWO ADJACENT rows of D = 768 as three full wave loads, row B brought into this
+// kernel's lane layout with v_permlane32_swap — the half-empty second load of a 1.5 KiB row is NOT what holds the pass at 4.5 TB/s
+// stand-alone: 136.7 vs 137.0 us; the 6.5 TB/s of [65 792, 1024] is the Infinity Cache (270 MB footprint).  Also:
+// two rows per wave + gamma / beta hoisted into registers + non-temporal stores of h
 // — 152 vs 139 us on [201 728, 768] stand-alone, 123 vs 43 us on [65 792, 1024]: the 32 extra registers cost more occupancy than
 // the extra loads in flight bring.)
 // (mean, rstd) of a row for a LayerNorm folded into the consuming linear (ln_fold).  NOT layernorm_kernel's arithmetic: that one is
@@ -2044,6 +2107,10 @@ extern "C" int pclip_layernorm_f16(const void* x, int ld_x, const float* gamma, 
     PCLIP_REQUIRE(D > 0 && D % 8 == 0 && D <= 4096 && ld_x >= D && ld_x % 8 == 0 && R >= 0,
                   "pclip_layernorm_f16: bad shape R=%d D=%d ld=%d", R, D, ld_x);
     if (R == 0) return PCLIP_OK;
+    if (PCLIP_LN_PF && R > 4 * 16384) {                      // more rows than waves in the grid: the row loop iterates, prefetch pays
+        DISPATCH_NCH(D, (layernorm_pf_kernel<NCH><<<row_grid(R), 256, 0, (hipStream_t)stream>>>((const half_t*)x, ld_x, gamma, beta, eps, (half_t*)y, R, D)));
+        return pclip_check_launch("layernorm");
+    }
     DISPATCH_NCH(D, (layernorm_kernel<NCH, float, 0><<<row_grid(R), 256, 0, (hipStream_t)stream>>>(
                         (const half_t*)x, ld_x, gamma, beta, eps, (half_t*)y, R, D, nullptr, 0.f, 0.f, 0, nullptr)));
     return pclip_check_launch("layernorm");

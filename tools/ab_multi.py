@@ -44,7 +44,7 @@ if mode == "attn":
 elif mode == "ln":
     for l in libs.values():
         l.pclip_layernorm_f16.argtypes = [P, ctypes.c_int, P, P, ctypes.c_float, P, ctypes.c_int, ctypes.c_int, P]
-    for R, D in ((201728, 768), (7000 * 77, 512), (257 * 256, 1024)):
+    for R, D in ((201728, 768), (70001, 768), (7000 * 77, 512), (257 * 256, 1024)):
         x = (torch.randn(R, D, device="cuda") * 1.3 + 0.2).half()
         g, b = 1 + 0.1 * torch.randn(D, device="cuda"), 0.1 * torch.randn(D, device="cuda")
         out = {t: torch.zeros(R, D, device="cuda", dtype=torch.float16) for t in libs}
