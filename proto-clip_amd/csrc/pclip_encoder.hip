@@ -1072,14 +1072,22 @@ __device__ __forceinline__ void attn_query_tile(const half_t* Ks, const half_t* 
         for (int u = 0; u < NTILE; ++u) {
             const int t = t0 + u;
             if ((t * 32 + 32 > L) || (causal && t == qb)) {        // wave-uniform: only edge tiles pay for the mask
+                // key k = t*32 + c_e + 4*hi is valid iff k < L and (causal) k <= q, i.e. k < min(L, q + 1): ONE per-lane limit
+                // against the compile-time c_e — a compare + select per element (the two-condition form was 12 instructions each)
+                const int kend = causal ? (q + 1 < L ? q + 1 : L) : L;
+                const int lim = kend - t * 32 - 4 * hi;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int k = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                    if (!(k < L && (!causal || k <= q))) st[u][e] = -__builtin_inff();
-                }
+                for (int e = 0; e < 16; ++e)
+                    if (!((e & 3) + 8 * (e >> 2) < lim)) st[u][e] = -__builtin_inff();
             }
+        }
+        {   // four independent maximum chains instead of one 32-deep dependent one (max is exact: same value)
+            float m4[4] = {tmax, tmax, tmax, tmax};
 #pragma unroll
-            for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, st[u][e]);
+            for (int u = 0; u < NTILE; ++u)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) m4[e & 3] = fmaxf(m4[e & 3], st[u][e]);
+            tmax = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
         }
         tmax = half_wave_max(tmax) * kScale;                       // kScale > 0: max commutes with the scaling
         // VAR & 1: deferred maximum (see above), decided PER ROW — a row's bits must not depend on the rows that share its wave (the
