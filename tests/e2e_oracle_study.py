@@ -1,5 +1,5 @@
 """Study (CPU; `python tests/e2e_oracle_study.py`): how far is the ORACLE — the per-operation restatement of the reference with its
-fp16 rounding points, pinned to the reference's fp32 towers at 5e-6 — from the reference's own fp16 chain on the six image -> logits
+fp16 rounding points, pinned to the reference's fp32 towers at 5e-6 — from the reference's own fp16 chain on the seven image -> logits
 fixtures?  The reference ran its fp16 towers on the CPU (torch's CPU half kernels: their own accumulation order and intermediate
 rounding); any restatement, the HIP path included, lands one draw of fp16 noise away from them.  Prints, per fixture, max|p - p_ref16|
 and max|p - p_ref32| of the oracle's fp16 and fp32 chains next to the fixture's own fp16 <-> fp32 gap -> profiles/r03_e2e_oracle_study.json;
@@ -30,16 +30,17 @@ def oracle_chain(name, half):
     classnames, templates = [str(x) for x in g["classnames"]], [str(x) for x in g["templates"]]
     tok = pclip.tokenize([t.format(cn.replace("_", " ")) for cn in classnames for t in templates])
     ad_sd = {str(k): torch.from_numpy(g["adapter__" + str(k)]) for k in g["adapter_keys"]}
+    enc = co.encode_image_resnet if E2E_VARIANTS[name].get("arch") == "rn" else co.encode_image
     order = torch.from_numpy(np.argsort(np.asarray(sup_y), kind="stable"))
     T = len(templates)
     if half:        # fp16 towers: every normalisation / mean is fp16 arithmetic on fp16 tensors (the reference's GPU precision)
-        keys = po.l2norm_rows(co.encode_image(sd, sup_x, half=True).half())[order]
-        tf = po.l2norm_rows(co.encode_image(sd, test_x, half=True).half())
+        keys = po.l2norm_rows(enc(sd, sup_x, half=True).half())[order]
+        tf = po.l2norm_rows(enc(sd, test_x, half=True).half())
         txt = co.encode_text(sd, tok, half=True).half()
     else:           # fp32 towers (the reference CPU path): normalised in fp32, cast to fp16 where the reference casts (`.half()` of the banks)
         n32 = lambda x: x / x.norm(dim=-1, keepdim=True)
-        keys = n32(n32(co.encode_image(sd, sup_x, half=False).float()))[order].half()          # utils.py:305-311: per-epoch normalise, mean, normalise
-        tf = n32(co.encode_image(sd, test_x, half=False).float()).half()                       # utils.py:349-351
+        keys = n32(n32(enc(sd, sup_x, half=False).float()))[order].half()          # utils.py:305-311: per-epoch normalise, mean, normalise
+        tf = n32(enc(sd, test_x, half=False).float()).half()                       # utils.py:349-351
         e = n32(co.encode_text(sd, tok, half=False).float()).view(N, T, -1).mean(dim=1)       # utils.py:266-270
         txt = None
         text_bank = n32(e).half()                                                              # [N, D] = clip_weights.t()

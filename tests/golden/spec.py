@@ -36,6 +36,8 @@ E2E_VARIANTS = {
     "e2e_s3": dict(sd_seed=20, case=dict(E2E_CASE, seed=52), adapter_seed=12, trained=False),
     "e2e_trained": dict(sd_seed=21, case=dict(E2E_CASE, seed=59), adapter_seed=13, trained=True),
     "e2e_trained2": dict(sd_seed=22, case=dict(E2E_CASE, seed=66), adapter_seed=14, trained=True),
+    # the same chain behind the ModifiedResNet tower (RN50's channel widths, one bottleneck per stage, attention pool; RESNET below)
+    "e2e_rn": dict(sd_seed=23, case=dict(E2E_CASE, seed=73), adapter_seed=15, trained=False, arch="rn"),
 }
 
 
@@ -76,8 +78,13 @@ def e2e_state_dict(variant):
     """Seeded weights of an image -> logits fixture (shared by make_golden.py and the tests)."""
     from proto_clip_amd.clip.model import random_state_dict
     v = E2E_VARIANTS[variant]
-    sd = random_state_dict(seed=v["sd_seed"], **E2E)
+    sd = random_state_dict(seed=v["sd_seed"], **e2e_arch(variant))
     return trained_like_(sd, v["sd_seed"]) if v["trained"] else sd
+
+
+def e2e_arch(variant):
+    """Tower hyper-parameters of an image -> logits fixture (embed_dim 128 and 64 x 64 images either way)."""
+    return dict(RESNET, vocab_size=49408) if E2E_VARIANTS[variant].get("arch") == "rn" else E2E
 
 
 def e2e_images(case=E2E_CASE, res=64):

@@ -17,7 +17,7 @@ implementation d > 2 x gap happens on roughly one fixture in six — measured: `
 (1.72e-3 vs 1.19e-3: the reference's rounding points) and folded (1.23e-3) alike, and the CPU oracle, which is pinned to the
 reference's fp32 towers at 5e-6, sits at 0.98e-3 on it (tests/fold_cpu_study.py); the deviation is the textual bank's (18 prompts,
 shared by every query: tests/golden/make_golden.py decomposition in DESIGN section 4).  The suite therefore asserts per fixture the
-hard cap 1.5 x tol and over the six fixtures AT MOST ONE excursion above tol (test_suite_allows_one_excursion) — a calibrated
+hard cap 1.5 x tol and over the fixtures (seven: six ViT draws + one ModifiedResNet) AT MOST ONE excursion above tol (test_suite_allows_one_excursion) — a calibrated
 statement instead of a lucky set of seeds.  With the LayerNorms unfolded (the default) the trained-like fixtures additionally hold
 p to max(2 x the reference's jitter self-noise, 2e-4): there the HIP chain is as close to the reference as the reference is to
 itself."""
@@ -77,7 +77,7 @@ def test_images_to_logits_against_reference_chain(name, tmp_path):
 
 
 def test_suite_allows_one_excursion():
-    """Over the six fixtures at most ONE may exceed tol = max(2 x gap, 1e-3) (module docstring); runs after the per-fixture tests."""
+    """Over the fixtures at most ONE may exceed tol = max(2 x gap, 1e-3) (module docstring); runs after the per-fixture tests."""
     if len(_RESULTS) < len(E2E_VARIANTS):
         pytest.skip("needs the per-fixture results of this run")
     over = [n for n, r in _RESULTS.items() if max(r["d16"], r["d32"]) > r["tol"]]
