@@ -18,10 +18,14 @@ namespace {
 #ifndef PCLIP_SR
 #define PCLIP_SR 1               // K-loop with staggered refill of the buffer being consumed (pgemm::mainloop_sr); 0: mainloop_bl
 #endif
+#ifndef PCLIP_PP
+#define PCLIP_PP 0               // 1: 256 x 256 tiles take the ping-pong K-loop (pgemm::mainloop_pp) — bit-identical, measured 4 - 10 % slower than mainloop_sr (profiles/r03_ab_pingpong.txt)
+#endif
 #ifndef PCLIP_PF
 #define PCLIP_PF false           // L2 prefetch two K-tiles ahead inside the persistent linear kernels: measured no gain, off
 #endif
 
+using CfgBigT = pgemm::Cfg<256, 256, 2, 4>;
 // ---- nn.Linear on MFMA ------------------------------------------------------------------------
 // Rounding points follow the reference's fp16 tensors: r16(acc + bias); QuickGELU as three fp16
 // elementwise ops (clip/model.py:166); residual add rounds once more (clip/model.py:188-189).
@@ -201,7 +205,9 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     int p = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave % C::WN, hi = lane >> 5;
     // M16: buffer-descriptor staging + pipelined K-loop; eight-wave tiles split the DMA issue by wave role (pgemm::TilePairR)
-    using TP = std::conditional_t<(PCLIP_DMA_ROLES && PCLIP_SR && C::NWAVES == 8), pgemm::TilePairR<C>, pgemm::TilePair<C>>;
+    constexpr bool PP = PCLIP_PP && M16 && C::BM == 256 && C::BN == 256 && C::WM == 2 && C::WN == 4;
+    using TPO = std::conditional_t<(PCLIP_DMA_ROLES && PCLIP_SR && C::NWAVES == 8), pgemm::TilePairR<C>, pgemm::TilePair<C>>;
+    using TP = std::conditional_t<PP, pgemm::TilePairP<std::conditional_t<PP, C, CfgBigT>>, TPO>;
     TP tp;
     // The bias enters as the INITIAL VALUE of the accumulators (fp32 copy of the fp16 bias: r16(bias + sum) instead of
     // r16(sum + bias), same value up to fp32 summation order), so the epilogue has no bias pass.  Its strip is copied one
@@ -242,7 +248,11 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     {
         int tm, tn;
         decomp(tile, tm, tn);
-        if (M16) {
+        if constexpr (PP) {
+            tp.prepare(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, wave, lane);
+            tp.stage(0, 0, smem);
+            if (K > 32) tp.stage(1, 1, smem);
+        } else if constexpr (M16) {
             tp.prepare(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, wave, lane);
             tp.stage(0, smem + p * C::STAGE_BYTES, wave);
         } else
@@ -283,17 +293,31 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         // (Measured and rejected, profiles/r03_ab_rejected.txt: pulling the residual tile's 1024 lines into L2 during the K-loop with one
         // 4-byte LDS-DMA per line — out_proj 301 -> 341 us, c_proj 854 -> 879 us: 1024 more requests per tile in the queue the operand
         // DMAs wait in.)
+        const int next = tile + G;
+        if constexpr (PP) {
+            // the next tile's K-steps 0 and 1 are requested from inside the loop's last phase (group 0 before, group 1 behind its last barrier)
+            pgemm::mainloop_pp<C, YOUNGER, !HAS_BIAS>(tp, K / 32, smem, acc, p, prev_full, wave, lane, [&](int pair) {
+                if (next < ntiles) {
+                    int tm, tn;
+                    decomp(next, tm, tn);
+                    tp.prepare(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, wave, lane);
+                    tp.stage(0, 2 * pair, smem);
+                    if (K > 32) tp.stage(1, 2 * pair + 1, smem);
+                }
+            }, tr);
+        } else {
 #if PCLIP_SR
-        if (M16) pgemm::mainloop_sr<C, YOUNGER, !HAS_BIAS, TP>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, tr);
+        if constexpr (M16) pgemm::mainloop_sr<C, YOUNGER, !HAS_BIAS, TP>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, tr);
 #else
-        if (M16) pgemm::mainloop_bl<C, YOUNGER, !HAS_BIAS, PCLIP_PF>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, smem + C::LDS_BYTES + STRIP_BYTES);
+        if constexpr (M16) pgemm::mainloop_bl<C, YOUNGER, !HAS_BIAS, PCLIP_PF>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, smem + C::LDS_BYTES + STRIP_BYTES);
 #endif
         else pgemm::mainloop<C, YOUNGER, !HAS_BIAS, M16>(A, lda, B, ldb, M, N, K, m0, n0, smem, acc, p, prev_full);
-        const int next = tile + G;
-        if (next < ntiles) {                                  // buffer p is free: prefetch the next tile's K-tile 0
+        }
+        if (!PP && next < ntiles) {                           // buffer p is free: prefetch the next tile's K-tile 0
             int tm, tn;
             decomp(next, tm, tn);
-            if (M16) {
+            if constexpr (PP) {
+            } else if constexpr (M16) {
                 tp.prepare(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, wave, lane);
                 tp.stage(0, smem + p * C::STAGE_BYTES, wave);
             } else
