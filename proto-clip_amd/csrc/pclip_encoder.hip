@@ -735,11 +735,28 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
 #ifndef PCLIP_LN_PF
 #define PCLIP_LN_PF 1
 #endif
-template <int NCH>
+#ifndef PCLIP_LN_LDS
+#define PCLIP_LN_LDS 1
+#endif
+#ifndef PCLIP_LN_BPC
+#define PCLIP_LN_BPC 32
+#endif
+template <int NCH, bool GB_LDS = false>
 __global__ __launch_bounds__(256) void layernorm_pf_kernel(const half_t* __restrict__ x, int ld_x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, half_t* __restrict__ y, int R, int D) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, stride = gridDim.x * 4;
     int row = blockIdx.x * 4 + wave;
+    // GB_LDS (the whole-batch pass of the towers): gamma / beta once per workgroup into LDS.  Per row they are 4 x the bytes of the row
+    // itself through the vector-memory path (8 dwordx4 loads per lane against 2 for x); as ds_read_b128 they use the LDS pipe instead
+    // (256 B/clk against 64): [201 728, 768] 129 -> 111 us, same bits (profiles/r03_ab_ln_lds.txt)
+    __shared__ __attribute__((aligned(16))) float gb_s[2][GB_LDS ? NCH * 512 : 4];
+    if (GB_LDS) {
+        for (int i = threadIdx.x; i < NCH * 512; i += 256) {
+            gb_s[0][i] = i < D ? gamma[i] : 0.f;
+            gb_s[1][i] = i < D ? beta[i] : 0.f;
+        }
+        __syncthreads();
+    }
     half8_t cur[NCH], nxt[NCH];
     auto load = [&](half8_t (&h)[NCH], int r) {
 #pragma unroll
@@ -777,7 +794,7 @@ __global__ __launch_bounds__(256) void layernorm_pf_kernel(const half_t* __restr
                 half8_t o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    float t = (v[c][j] - mean) * rstd * (float)gamma[d + j] + (float)beta[d + j];
+                    float t = (v[c][j] - mean) * rstd * (GB_LDS ? gb_s[0][d + j] : gamma[d + j]) + (GB_LDS ? gb_s[1][d + j] : beta[d + j]);
                     t = r16(t);
                     o[j] = (half_t)t;
                 }
@@ -1614,7 +1631,10 @@ thread_local int g_min_bn = 0;               // act 9 (statistics partials per 6
 inline double tile_cost(const TileCfg& c, long M, int N, int cus) {
     if (N % c.bn || c.bn < g_min_bn) return 1e30;
     const long slots = (long)c.wg_per_cu * cus, nt = ((M + c.bm - 1) / c.bm) * (N / c.bn);
-    return (double)((nt + slots - 1) / slots) * (c.bm / 128.0) * (c.bn / 128.0) * c.wg_per_cu / c.eff;
+    // two workgroups per CU share its matrix pipe — unless the launch has no more tiles than CUs: then every workgroup has a CU to itself
+    // (the 60-tile tail of the N = 768 GEMMs as 240 tiles of 128 x 128: 10.6 / 28.8 us against 11.7 / 33.1 us as 256 x 64, K = 768 / 3072)
+    const double share = nt <= cus ? 1.0 : (double)c.wg_per_cu;
+    return (double)((nt + slots - 1) / slots) * (c.bm / 128.0) * (c.bn / 128.0) * share / c.eff;
 }
 inline int best_cfg(long M, int N, int cus, double* cost_out) {
     int pick = -1;
@@ -2139,8 +2159,14 @@ extern "C" int pclip_layernorm_f16(const void* x, int ld_x, const float* gamma, 
     PCLIP_REQUIRE(D > 0 && D % 8 == 0 && D <= 4096 && ld_x >= D && ld_x % 8 == 0 && R >= 0,
                   "pclip_layernorm_f16: bad shape R=%d D=%d ld=%d", R, D, ld_x);
     if (R == 0) return PCLIP_OK;
+    // whole-batch pass (>= 16 rows per workgroup of a PCLIP_LN_BPC-per-CU grid): gamma / beta from the workgroup's LDS copy
+    const int ln_grid = pclip_device_cus() * PCLIP_LN_BPC;
+    if (PCLIP_LN_PF && PCLIP_LN_LDS && R >= 16 * ln_grid) {
+        DISPATCH_NCH(D, (layernorm_pf_kernel<NCH, true><<<ln_grid, 256, 0, (hipStream_t)stream>>>((const half_t*)x, ld_x, gamma, beta, eps, (half_t*)y, R, D)));
+        return pclip_check_launch("layernorm");
+    }
     if (PCLIP_LN_PF && R > 4 * 16384) {                      // more rows than waves in the grid: the row loop iterates, prefetch pays
-        DISPATCH_NCH(D, (layernorm_pf_kernel<NCH><<<row_grid(R), 256, 0, (hipStream_t)stream>>>((const half_t*)x, ld_x, gamma, beta, eps, (half_t*)y, R, D)));
+        DISPATCH_NCH(D, (layernorm_pf_kernel<NCH, false><<<row_grid(R), 256, 0, (hipStream_t)stream>>>((const half_t*)x, ld_x, gamma, beta, eps, (half_t*)y, R, D)));
         return pclip_check_launch("layernorm");
     }
     DISPATCH_NCH(D, (layernorm_kernel<NCH, float, 0><<<row_grid(R), 256, 0, (hipStream_t)stream>>>(
