@@ -21,6 +21,9 @@ namespace {
 #ifndef PCLIP_PP
 #define PCLIP_PP 0               // 1: 256 x 256 tiles take the ping-pong K-loop (pgemm::mainloop_pp) — bit-identical, measured 4 - 10 % slower than mainloop_sr (profiles/r03_ab_pingpong.txt)
 #endif
+#ifndef PCLIP_EPI_DIRECT
+#define PCLIP_EPI_DIRECT 0       // 1: 256 x 256 tiles, bias / bias + QuickGELU: 8-byte stores straight from the accumulator layout (pgemm::epilogue_direct), K-tiles 0 and 1 of the next tile in flight meanwhile — bit-identical, in_proj 18 % / c_fc 4 % slower (profiles/r03_ab_rejected.txt)
+#endif
 #ifndef PCLIP_PF
 #define PCLIP_PF false           // L2 prefetch two K-tiles ahead inside the persistent linear kernels: measured no gain, off
 #endif
@@ -206,6 +209,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave % C::WN, hi = lane >> 5;
     // M16: buffer-descriptor staging + pipelined K-loop; eight-wave tiles split the DMA issue by wave role (pgemm::TilePairR)
     constexpr bool PP = PCLIP_PP && M16 && C::BM == 256 && C::BN == 256 && C::WM == 2 && C::WN == 4;
+    constexpr bool DIRECT = PCLIP_EPI_DIRECT && !PP && PCLIP_SR && M16 && ACT <= 1 && C::BM == 256 && C::BN == 256 && C::WM == 2 && C::WN == 4;
     using TPO = std::conditional_t<(PCLIP_DMA_ROLES && PCLIP_SR && C::NWAVES == 8), pgemm::TilePairR<C>, pgemm::TilePair<C>>;
     using TP = std::conditional_t<PP, pgemm::TilePairP<std::conditional_t<PP, C, CfgBigT>>, TPO>;
     TP tp;
@@ -255,11 +259,14 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         } else if constexpr (M16) {
             tp.prepare(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, wave, lane);
             tp.stage(0, smem + p * C::STAGE_BYTES, wave);
+            if (DIRECT && K > pgemm::BK) tp.stage(1, smem + (p ^ 1) * C::STAGE_BYTES, wave);
         } else
             pgemm::stage_first<C>(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, smem, p);
     }
     constexpr int PST = ACT == 9 ? 1 : 0;                                     // act 9: one store of statistics partials per pass
-    constexpr int YOUNGER = C::NH * C::NPASS * (1 + PST) + (AFFINE ? 2 : (HAS_BIAS ? 1 : 0)) + NSTAT;
+    // vector-memory operations a wave issues between a tile's K-tile 0 pieces and the first wait of its K-loop: the previous tile's stores + the
+    // strip copies (DIRECT: the TM * TN * 4 direct stores, and the wave's 8 pieces of K-tile 1 in front of them)
+    constexpr int YOUNGER = DIRECT ? C::TM * C::TN * 4 + (HAS_BIAS ? 1 : 0) + 8 : C::NH * C::NPASS * (1 + PST) + (AFFINE ? 2 : (HAS_BIAS ? 1 : 0)) + NSTAT;
     bool prev_full = false;
     int parity = 0;
     unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             }, tr);
         } else {
 #if PCLIP_SR
-        if constexpr (M16) pgemm::mainloop_sr<C, YOUNGER, !HAS_BIAS, TP>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, tr);
+        if constexpr (M16) pgemm::mainloop_sr<C, YOUNGER, !HAS_BIAS, TP, DIRECT>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, tr);
 #else
         if constexpr (M16) pgemm::mainloop_bl<C, YOUNGER, !HAS_BIAS, PCLIP_PF>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, smem + C::LDS_BYTES + STRIP_BYTES);
 #endif
@@ -320,6 +327,10 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             } else if constexpr (M16) {
                 tp.prepare(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, wave, lane);
                 tp.stage(0, smem + p * C::STAGE_BYTES, wave);
+                if constexpr (DIRECT) {
+                    pgemm::lds_barrier();                      // every wave holds its last fragments: the buffer of the last K-tile is free too
+                    if (K > pgemm::BK) tp.stage(1, smem + (p ^ 1) * C::STAGE_BYTES, wave);
+                }
             } else
                 pgemm::stage_first<C>(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, smem, p);
         }
@@ -425,6 +436,12 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             if (valid && (c & 7) == 0)
                 *reinterpret_cast<float2_t*>(partials + ((size_t)(m0 + r) * (N >> 6) + (n0 >> 6) + (c >> 3)) * 2) = float2_t{ps, pq};
         };
+        if constexpr (DIRECT) {
+            if (full) pgemm::epilogue_direct<C>(acc, Cout, ldc, m0, n0, pre, [](int) { return true; });
+            else pgemm::epilogue_direct<C>(acc, Cout, ldc, m0, n0, pre, [&](int m) { return m < M; });
+            prev_full = full;
+            continue;
+        }
 #if (PCLIP_ABL & 4) && defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
         for (int i = 0; i < C::TM; ++i)

@@ -484,7 +484,9 @@ __device__ __forceinline__ void mainloop_bl(const TilePair<C>& tp, int nt, char*
 #ifndef PCLIP_IGLP
 #define PCLIP_IGLP 1             // __builtin_amdgcn_iglp_opt strategy of the K-loop's first scheduling region (-1: none; 0 / 2 / 3 measured: no gain)
 #endif
-template <class C, int YOUNGER = 0, bool ZERO_ACC = true, class TP = TilePair<C>>
+// TWO: K-tiles 0 AND 1 were requested by the caller (direct-store epilogue: no LDS staging area between tiles); `counted_first` then
+// also covers the wait for K-tile 1, whose pieces sit in front of the previous tile's YOUNGER - NA|NB stores and strip copies.
+template <class C, int YOUNGER = 0, bool ZERO_ACC = true, class TP = TilePair<C>, bool TWO = false>
 __device__ __forceinline__ void mainloop_sr(const TP& tp, int nt, char* smem, Acc<C>& acc, int& p, bool counted_first, int wave,
                                             int lane, unsigned long long* g_tr = nullptr) {
     static_assert(C::TM >= 2 && C::TM % 2 == 0, "group pipeline splits the wave's A rows in two halves");
@@ -521,6 +523,7 @@ __device__ __forceinline__ void mainloop_sr(const TP& tp, int nt, char* smem, Ac
     for (int t = 0; t < nt; ++t) {
         PCLIP_STAMP(tr0);
         if (t == 0) { if (counted_first) wait_vm<YOUNGER>(); else wait_vm<0>(); }
+        else if (TWO && t == 1 && counted_first && nt > 2) wait_vm<YOUNGER>();   // behind K-tile 1: the stores / strips and K-tile 2's pieces = as many as behind K-tile 0
         else if (t + 1 < nt) wait_ahead();
         else wait_vm<0>();
         PCLIP_STAMP(tr1);
@@ -575,7 +578,7 @@ __device__ __forceinline__ void mainloop_sr(const TP& tp, int nt, char* smem, Ac
 #endif
         load_b(bcur, 0);
         load_a(acur, 0, 0);
-        if (t == 0 && nt > 1 && !(PCLIP_ABL & 1)) tp.stage(1, smem + (p ^ 1) * C::STAGE_BYTES, wave);   // the other buffer was the previous tile's epilogue staging area until the barrier above
+        if (!TWO && t == 0 && nt > 1 && !(PCLIP_ABL & 1)) tp.stage(1, smem + (p ^ 1) * C::STAGE_BYTES, wave);   // the other buffer was the previous tile's epilogue staging area until the barrier above
         load_a(anext, 0, 1);
         group(acur, bcur, 0);                    // ks 0, rows half 0
         load_b(bnext, 1);
@@ -1044,6 +1047,35 @@ __device__ __forceinline__ void epilogue_f16(const Acc<C>& acc, char* stg, const
             post(h * C::HR + r, c, h * C::NPASS + ps, hv);
         }
     }
+}
+
+// ---- fp16 output straight from the accumulator layout (no LDS staging, no barrier) -----------------------------------------------
+// A lane owns, per accumulator quad, four consecutive columns of one row: one 8-byte store.  A wave instruction then covers 16 rows x
+// 32 bytes — a quarter of the coalescing of the LDS-staged pass, but the epilogue needs no LDS (the next tile's K-tiles 0 AND 1 fly
+// during it) and no barrier.  `pre` as in epilogue_f16; `row_ok(m)` predicates the rows of a partial tile.  TM * TN * 4 stores per wave.
+template <class C, class Pre, class RowOk>
+__device__ __forceinline__ void epilogue_direct(const Acc<C>& acc, half_t* __restrict__ Cout, int ldc, int m0, int n0, const Pre& pre, const RowOk& row_ok) {
+    int tid = threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(tid));
+#endif
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    half_t* base = Cout + (size_t)(m0 + wm * (C::BM / C::WM) + (lane & 15)) * ldc + n0 + wn * (C::BN / C::WN) + 4 * (lane >> 4);
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int rl = (g >> 1) * 16 + (lane & 15);
+            const bool ok = row_ok(m0 + wm * (C::BM / C::WM) + i * 32 + rl);
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j) {
+                const int coff = (g & 1) * 16 + 4 * (lane >> 4);
+                const float4_t v = {acc.v[i][j][4 * g], acc.v[i][j][4 * g + 1], acc.v[i][j][4 * g + 2], acc.v[i][j][4 * g + 3]};
+                const half4_t hv = pre(i, j, coff, v, rl, g);
+                if (ok) *reinterpret_cast<half4_t*>(base + (size_t)(i * 32 + (g >> 1) * 16) * ldc + j * 32 + (g & 1) * 16) = hv;
+            }
+        }
 }
 
 }  // namespace pgemm
