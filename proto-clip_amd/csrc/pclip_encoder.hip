@@ -8,6 +8,12 @@
 
 #if PCLIP_TRACE
 __device__ unsigned long long g_pclip_trace[18];
+__device__ unsigned long long g_pclip_trace2[16];     // tile-level: [0..3] epilogue (slab barrier, staging writes, barrier, row-major reads + stores), [4] K-loop, [5] next-tile requests, [6] epilogue, [7] tiles; wave 7 at +8
+extern "C" int pclip_debug_trace2(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pclip_trace2), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pclip_trace2), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
 extern "C" int pclip_debug_trace(unsigned long long* out, int reset) {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pclip_trace), sizeof(unsigned long long) * 18) != hipSuccess) return 1;
     if (reset) { unsigned long long z[18] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pclip_trace), z, sizeof(z)) != hipSuccess) return 1; }
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     constexpr int YOUNGER = DIRECT ? C::TM * C::TN * 4 + (HAS_BIAS ? 1 : 0) + 8 : C::NH * C::NPASS * (1 + PST) + (AFFINE ? 2 : (HAS_BIAS ? 1 : 0)) + NSTAT;
     bool prev_full = false;
     int parity = 0;
-    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, te[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (; tile < ntiles; tile += G, parity ^= 1) {
         int tile_m, tile_n;
         decomp(tile, tile_m, tile_n);
@@ -301,6 +307,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         // 4-byte LDS-DMA per line — out_proj 301 -> 341 us, c_proj 854 -> 879 us: 1024 more requests per tile in the queue the operand
         // DMAs wait in.)
         const int next = tile + G;
+        PCLIP_STAMP(tt0);
         if constexpr (PP) {
             // the next tile's K-steps 0 and 1 are requested from inside the loop's last phase (group 0 before, group 1 behind its last barrier)
             pgemm::mainloop_pp<C, YOUNGER, !HAS_BIAS>(tp, K / 32, smem, acc, p, prev_full, wave, lane, [&](int pair) {
@@ -320,6 +327,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
 #endif
         else pgemm::mainloop<C, YOUNGER, !HAS_BIAS, M16>(A, lda, B, ldb, M, N, K, m0, n0, smem, acc, p, prev_full);
         }
+        PCLIP_STAMP(tt1);
         if (!PP && next < ntiles) {                           // buffer p is free: prefetch the next tile's K-tile 0
             int tm, tn;
             decomp(next, tm, tn);
@@ -334,6 +342,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             } else
                 pgemm::stage_first<C>(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, smem, p);
         }
+        PCLIP_STAMP(tt2);
         char* stg = smem + (p ^ 1) * C::STAGE_BYTES;          // buffer of the last K-tile, reused after a barrier
         int etid = tid;                                       // opaque copy: the epilogue's lane constants are recomputed per tile (pgemm::epilogue_f16)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -437,6 +446,14 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
                 *reinterpret_cast<float2_t*>(partials + ((size_t)(m0 + r) * (N >> 6) + (n0 >> 6) + (c >> 3)) * 2) = float2_t{ps, pq};
         };
         if constexpr (DIRECT) {
+#if (PCLIP_ABL & 4) && defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j) asm volatile("" ::"v"(acc.v[i][j]));
+            prev_full = false;
+            continue;
+#endif
             if (full) pgemm::epilogue_direct<C>(acc, Cout, ldc, m0, n0, pre, [](int) { return true; });
             else pgemm::epilogue_direct<C>(acc, Cout, ldc, m0, n0, pre, [&](int m) { return m < M; });
             prev_full = full;
@@ -456,7 +473,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
                 if (RES) h = add_res(pass, h);
                 st_out(Cout + o, h);
                 if (ACT == 9) put_partials(r, c, h, true);
-            });
+            }, te);
         else
             pgemm::epilogue_f16<C, M16>(acc, stg, slab, pre, [&](int r, int c, int pass, half8_t h) {
                 const size_t o = (size_t)(m0 + r) * ldc + col;
@@ -465,10 +482,13 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
                 if (ACT == 9) put_partials(r, c, h, m0 + r < M);
             });
         prev_full = full;
+#if PCLIP_TRACE && defined(__HIP_DEVICE_COMPILE__)
+        { PCLIP_STAMP(tt3); te[4] += tt1 - tt0; te[5] += tt2 - tt1; te[6] += tt3 - tt2; te[7] += 1; }
+#endif
     }
 #if PCLIP_TRACE
     if (lane == 0 && (wave == 0 || wave == 7))
-        for (int i = 0; i < 8; ++i) atomicAdd(&g_pclip_trace[(wave ? 8 : 0) + i], tr[i]);
+        for (int i = 0; i < 8; ++i) { atomicAdd(&g_pclip_trace[(wave ? 8 : 0) + i], tr[i]); atomicAdd(&g_pclip_trace2[(wave ? 8 : 0) + i], te[i]); }
 #if defined(__HIP_DEVICE_COMPILE__)
     if (tid == 0) {                                            // kernel span in s_memtime ticks: [16] = min entry stamp, [17] = max exit stamp
         unsigned long long t_exit;

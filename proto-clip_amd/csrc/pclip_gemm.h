@@ -1000,7 +1000,7 @@ __device__ __forceinline__ void mainloop_ring(const half_t* __restrict__ A, int 
 //          row (one ds_read_b128; the XOR may swap the two 8-byte halves) — a wave instruction covers whole
 //          512-byte / 256-byte row segments: 16-byte fully coalesced global stores.
 template <class C, bool M16 = false, class Slab, class Pre, class Post>
-__device__ __forceinline__ void epilogue_f16(const Acc<C>& acc, char* stg, const Slab& slab, const Pre& pre, const Post& post) {
+__device__ __forceinline__ void epilogue_f16(const Acc<C>& acc, char* stg, const Slab& slab, const Pre& pre, const Post& post, unsigned long long* e_tr = nullptr) {
     // The lane-constant addressing of the epilogue is recomputed per tile from an OPAQUE copy of the thread id: hipcc otherwise hoists
     // it out of the persistent tile loop and keeps ~10 registers live across the K-loop — spilled around it in the residual kernels
     // (scratch reloads beside LDS-DMA drain the vector-memory counter, guide: "recompute per block").
@@ -1015,8 +1015,10 @@ __device__ __forceinline__ void epilogue_f16(const Acc<C>& acc, char* stg, const
     constexpr int SWZ = C::BN / 4 >= 16 ? 15 : C::BN / 4 - 1;         // XOR mask of the 8-byte units (a row has BN / 4 of them)
 #pragma unroll
     for (int h = 0; h < C::NH; ++h) {
+        PCLIP_STAMP(te0);
         slab(h);           // caller hook: e.g. issue this slab's residual loads so they fly during the staging
         lds_barrier();     // slab buffer free: K-loop reads (h = 0) / previous slab's row-major reads are done
+        PCLIP_STAMP(te1);
         if ((wm * WROWS) / C::HR == h) {
 #pragma unroll
             for (int i = 0; i < C::TM; ++i) {
@@ -1036,7 +1038,9 @@ __device__ __forceinline__ void epilogue_f16(const Acc<C>& acc, char* stg, const
                     }
             }
         }
+        PCLIP_STAMP(te2);
         lds_barrier();
+        PCLIP_STAMP(te3);
         const int c = tid % C::CPR;
 #pragma unroll
         for (int ps = 0; ps < C::NPASS; ++ps) {
@@ -1046,6 +1050,10 @@ __device__ __forceinline__ void epilogue_f16(const Acc<C>& acc, char* stg, const
             if (r & 1) hv = half8_t{hv[4], hv[5], hv[6], hv[7], hv[0], hv[1], hv[2], hv[3]};
             post(h * C::HR + r, c, h * C::NPASS + ps, hv);
         }
+        PCLIP_STAMP(te4);
+#if PCLIP_TRACE && defined(__HIP_DEVICE_COMPILE__)
+        if (e_tr) { e_tr[0] += te1 - te0; e_tr[1] += te2 - te1; e_tr[2] += te3 - te2; e_tr[3] += te4 - te3; }
+#endif
     }
 }
 
