@@ -27,6 +27,9 @@ namespace {
 #ifndef PCLIP_PP
 #define PCLIP_PP 0               // 1: 256 x 256 tiles take the ping-pong K-loop (pgemm::mainloop_pp) — bit-identical, measured 4 - 10 % slower than mainloop_sr (profiles/r03_ab_pingpong.txt)
 #endif
+#ifndef PCLIP_EPI_PIPE
+#define PCLIP_EPI_PIPE 1         // 256 x 256 tiles: the LDS-staged epilogue as a four-slab pipeline (pgemm::epilogue_pipe)
+#endif
 #ifndef PCLIP_EPI_DIRECT
 #define PCLIP_EPI_DIRECT 0       // 1: 256 x 256 tiles, bias / bias + QuickGELU: 8-byte stores straight from the accumulator layout (pgemm::epilogue_direct), K-tiles 0 and 1 of the next tile in flight meanwhile — bit-identical, in_proj 18 % / c_fc 4 % slower (profiles/r03_ab_rejected.txt)
 #endif
@@ -417,7 +420,19 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         // compiler cannot hoist a later pass's load above an earlier pass's store by itself: load -> wait -> store per pass was
         // 16 dependent round trips per tile.
         constexpr bool RES = ACT == 5 || ACT == 6 || ACT == 9;
+        // (measured, profiles/r03_ab_epilogue_pipe.txt: c_fc + QuickGELU 1001 -> 972 us; the bias-only and residual epilogues do not profit — their phases
+        // are bound by the LDS write rate / the stores' address path / the residual loads' latency one after the other either way — and keep epilogue_f16)
+        constexpr bool PIPE = PCLIP_EPI_PIPE && M16 && !DIRECT && (ACT == 1 || ACT == 8 || PCLIP_EPI_PIPE == 2) && C::BM == 256 && C::BN == 256 && C::WM == 2 && C::WN == 4;
         half8_t rr[RES ? C::NPASS : 1];
+        // PIPE: slab k = 32-row block k of both wave rows, four passes of 16 rows; its residual chunks go to rr[(k & 1) * 4 + ps], requested one interval ahead
+        auto ahead = [&](int k) {
+            if (!RES) return;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int rs = etid / C::CPR + ps * 16, r = (rs >> 5) * 128 + k * 32 + (rs & 31);
+                if (full || m0 + r < M) rr[RES ? (k & 1) * 4 + ps : 0] = ld_half8(residual + (size_t)(m0 + r) * ldc + col);
+            }
+        };
         auto slab = [&](int h) {
             if (!RES) return;
 #pragma unroll
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             }
         };
         auto add_res = [&](int pass, half8_t h) {
-            const half8_t x = rr[RES ? pass % C::NPASS : 0];
+            const half8_t x = rr[RES ? pass % C::NPASS : 0];     // (PIPE: pass = 4 k + ps -> (k & 1) * 4 + ps = pass % 8, NPASS = 8)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float y = r16((float)x[j] + (float)h[j]);
@@ -457,6 +472,28 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             if (full) pgemm::epilogue_direct<C>(acc, Cout, ldc, m0, n0, pre, [](int) { return true; });
             else pgemm::epilogue_direct<C>(acc, Cout, ldc, m0, n0, pre, [&](int m) { return m < M; });
             prev_full = full;
+            continue;
+        }
+        if constexpr (PIPE) {
+            static_assert(C::NPASS == 8, "rr[pass % NPASS] pairs slab parity and pass");
+            if (full)
+                pgemm::epilogue_pipe<C>(acc, stg, ahead, pre, [&](int r, int c, int pass, half8_t h) {
+                    const size_t o = (size_t)(m0 + r) * ldc + col;
+                    if (RES) h = add_res(pass, h);
+                    st_out(Cout + o, h);
+                    if (ACT == 9) put_partials(r, c, h, true);
+                });
+            else
+                pgemm::epilogue_pipe<C>(acc, stg, ahead, pre, [&](int r, int c, int pass, half8_t h) {
+                    const size_t o = (size_t)(m0 + r) * ldc + col;
+                    if (RES) h = add_res(pass, h);
+                    if (m0 + r < M) st_out(Cout + o, h);
+                    if (ACT == 9) put_partials(r, c, h, m0 + r < M);
+                });
+            prev_full = full;
+#if PCLIP_TRACE && defined(__HIP_DEVICE_COMPILE__)
+            { PCLIP_STAMP(tt3); te[4] += tt1 - tt0; te[5] += tt2 - tt1; te[6] += tt3 - tt2; te[7] += 1; }
+#endif
             continue;
         }
 #if (PCLIP_ABL & 4) && defined(__HIP_DEVICE_COMPILE__)

@@ -1057,6 +1057,75 @@ __device__ __forceinline__ void epilogue_f16(const Acc<C>& acc, char* stg, const
     }
 }
 
+// ---- the same LDS-staged epilogue as a four-slab pipeline (256-row tiles, 16x16x32 accumulator layout) --------------------------------
+// tools/trace_tile.py: epilogue_f16 is a chain of phases — barrier, staging writes (half of the waves), barrier, row-major reads + stores (bound by
+// the CU's one address path: 19 cycles per 1 KB store) — twice per tile, 15 % of a K = 768 tile with bias only and 30 % with QuickGELU (whose
+// arithmetic is VALU-bound and ran on four waves at a time).  Here slab k (k = 0 .. 3) holds 32-row block k of EVERY wave (64 rows; every wave converts /
+// activates 8 quads per slab), the 64 KB staging buffer is two 32 KB halves, and in interval k every wave first stages its share of slab k + 1 into the
+// other half and then reads + stores slab k: the VALU / LDS-write work of one slab overlaps the stores of the previous one, five barriers per tile.
+// `ahead(k)`: caller hook at the top of interval k - 1 (k = 0: before the first barrier) — e.g. request slab k's residual chunks one interval early.
+// `post(row_in_tile, chunk, pass = 4 k + ps, half8)` as in epilogue_f16; 16 stores per thread and tile as there.
+#ifndef PCLIP_EPI_PIPE_ALT
+#define PCLIP_EPI_PIPE_ALT 1
+#endif
+template <class C, class Ahead, class Pre, class Post>
+__device__ __forceinline__ void epilogue_pipe(const Acc<C>& acc, char* stg, const Ahead& ahead, const Pre& pre, const Post& post) {
+    static_assert(C::TM == 4 && C::BM == 256 && C::BN % 64 == 0, "four 32-row blocks per wave");
+    int tid = threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(tid));
+#endif
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    constexpr int RB = C::BN * 2, SLAB = 64 * RB;                    // bytes per staged row / per slab (BN = 256: 32 KB)
+    constexpr int SWZ = 15;
+    constexpr int SR = 256 / C::WM / 4 * C::WM;                       // rows of a slab = 32-row block k of each of the WM wave rows ... (WM = 2: 64)
+    static_assert(SR == 32 * C::WM && 2 * SR * RB <= C::STAGE_BYTES, "two slabs must fit one stage buffer");
+    constexpr int RPP = C::NTHREADS / C::CPR, NP4 = SR / RPP;          // rows per pass, passes per slab
+    auto stage = [&](int k) {
+        char* buf = stg + (k & 1) * SLAB;
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int rl = (g >> 1) * 16 + (lane & 15), coff = (g & 1) * 16 + 4 * (lane >> 4);
+                const int ml = wm * 32 + rl, nl = wn * (C::BN / C::WN) + j * 32 + coff;
+                float4_t v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // acc.v[k] with a compile-time k after unrolling (the caller's loop over k is unrolled)
+                    v[e] = acc.v[k][j][4 * g + e];
+                }
+                const half4_t hv = pre(k, j, coff, v, rl, g);
+                const int unit = (nl >> 2) ^ (ml & SWZ);
+                *reinterpret_cast<half4_t*>(buf + ml * RB + unit * 8) = hv;
+            }
+    };
+    ahead(0);
+    lds_barrier();                                                     // staging buffer free (the K-loop's reads of the last K-tile are done)
+    stage(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k + 1 < 4) ahead(k + 1);
+        lds_barrier();                                                 // slab k staged; the other half's readers (slab k - 1) are done
+        // half of the waves stage slab k + 1 first and store slab k afterwards, the other half the other way round: the LDS-write path and the
+        // address path of the stores are busy at the same time instead of one after the other
+        const bool stage_first = PCLIP_EPI_PIPE_ALT ? (wave & 1) == 0 : true;
+        if (k + 1 < 4 && stage_first) stage(k + 1);
+        const char* buf = stg + (k & 1) * SLAB;
+        const int c = tid % C::CPR;
+#pragma unroll
+        for (int ps = 0; ps < NP4; ++ps) {
+            const int r = tid / C::CPR + ps * RPP;                     // row inside the slab: wave-row block r >> 5, row r & 31 of its block k
+            const int pair = c ^ ((r & SWZ) >> 1);
+            half8_t hv = *reinterpret_cast<const half8_t*>(buf + r * RB + pair * 16);
+            if (r & 1) hv = half8_t{hv[4], hv[5], hv[6], hv[7], hv[0], hv[1], hv[2], hv[3]};
+            post((r >> 5) * (C::BM / C::WM) + k * 32 + (r & 31), c, k * NP4 + ps, hv);
+        }
+        if (k + 1 < 4 && !stage_first) stage(k + 1);
+    }
+}
+
 // ---- fp16 output straight from the accumulator layout (no LDS staging, no barrier) -----------------------------------------------
 // A lane owns, per accumulator quad, four consecutive columns of one row: one 8-byte store.  A wave instruction then covers 16 rows x
 // 32 bytes — a quarter of the coalescing of the LDS-staged pass, but the epilogue needs no LDS (the next tile's K-tiles 0 AND 1 fly
