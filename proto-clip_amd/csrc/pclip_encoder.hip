@@ -31,7 +31,7 @@ namespace {
 #define PCLIP_EPI_PIPE 1         // 256 x 256 tiles: the LDS-staged epilogue as a four-slab pipeline (pgemm::epilogue_pipe)
 #endif
 #ifndef PCLIP_EPI_DIRECT
-#define PCLIP_EPI_DIRECT 0       // 1: 256 x 256 tiles, bias / bias + QuickGELU: 8-byte stores straight from the accumulator layout (pgemm::epilogue_direct), K-tiles 0 and 1 of the next tile in flight meanwhile — bit-identical, in_proj 18 % / c_fc 4 % slower (profiles/r03_ab_rejected.txt)
+#define PCLIP_EPI_DIRECT 0       // epilogue without LDS staging, K-tiles 0 and 1 of the next tile in flight meanwhile (256 x 256 tiles, bias / bias + QuickGELU): 1 = 8-byte stores from the accumulator layout (pgemm::epilogue_direct: in_proj 18 % / c_fc 4 % slower), 2 = column-permuted B tile + DPP / ds_bpermute transposition + 16-byte stores (pgemm::epilogue_lane: in_proj 2.4 % slower, c_fc as the pipelined staged form); all bit-identical (profiles/r03_ab_rejected.txt)
 #endif
 #ifndef PCLIP_PF
 #define PCLIP_PF false           // L2 prefetch two K-tiles ahead inside the persistent linear kernels: measured no gain, off
@@ -224,8 +224,9 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave % C::WN, hi = lane >> 5;
     // M16: buffer-descriptor staging + pipelined K-loop; eight-wave tiles split the DMA issue by wave role (pgemm::TilePairR)
     constexpr bool PP = PCLIP_PP && M16 && C::BM == 256 && C::BN == 256 && C::WM == 2 && C::WN == 4;
-    constexpr bool DIRECT = PCLIP_EPI_DIRECT && !PP && PCLIP_SR && M16 && ACT <= 1 && C::BM == 256 && C::BN == 256 && C::WM == 2 && C::WN == 4;
-    using TPO = std::conditional_t<(PCLIP_DMA_ROLES && PCLIP_SR && C::NWAVES == 8), pgemm::TilePairR<C>, pgemm::TilePair<C>>;
+    constexpr bool DIRECT = PCLIP_EPI_DIRECT && !PP && PCLIP_SR && PCLIP_DMA_ROLES && M16 && ACT <= 1 && C::BM == 256 && C::BN == 256 && C::WM == 2 && C::WN == 4;
+    constexpr bool LANE = DIRECT && PCLIP_EPI_DIRECT == 2;       // 16-byte stores from the column-permuted accumulator layout (pgemm::epilogue_lane)
+    using TPO = std::conditional_t<(PCLIP_DMA_ROLES && PCLIP_SR && C::NWAVES == 8), pgemm::TilePairR<C, LANE>, pgemm::TilePair<C>>;
     using TP = std::conditional_t<PP, pgemm::TilePairP<std::conditional_t<PP, C, CfgBigT>>, TPO>;
     TP tp;
     // The bias enters as the INITIAL VALUE of the accumulators (fp32 copy of the fp16 bias: r16(bias + sum) instead of
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     constexpr int PST = ACT == 9 ? 1 : 0;                                     // act 9: one store of statistics partials per pass
     // vector-memory operations a wave issues between a tile's K-tile 0 pieces and the first wait of its K-loop: the previous tile's stores + the
     // strip copies (DIRECT: the TM * TN * 4 direct stores, and the wave's 8 pieces of K-tile 1 in front of them)
-    constexpr int YOUNGER = DIRECT ? C::TM * C::TN * 4 + (HAS_BIAS ? 1 : 0) + 8 : C::NH * C::NPASS * (1 + PST) + (AFFINE ? 2 : (HAS_BIAS ? 1 : 0)) + NSTAT;
+    constexpr int YOUNGER = DIRECT ? (LANE ? C::TM * 4 : C::TM * C::TN * 4) + (HAS_BIAS ? 1 : 0) + 8 : C::NH * C::NPASS * (1 + PST) + (AFFINE ? 2 : (HAS_BIAS ? 1 : 0)) + NSTAT;
     bool prev_full = false;
     int parity = 0;
     unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, te[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -301,7 +302,8 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int coff = M16 ? (g & 1) * 16 + 4 * (lane >> 4) : 8 * g + 4 * hi;      // columns of elements 4g .. 4g+3
-                    const half4_t b = *reinterpret_cast<const half4_t*>(bl + j * 32 + coff);
+                    const half4_t b = LANE ? *reinterpret_cast<const half4_t*>(bl + 16 * (lane >> 4) + 4 * (2 * j + (g & 1)))   // column-permuted accumulators
+                                           : *reinterpret_cast<const half4_t*>(bl + j * 32 + coff);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             }, tr);
         } else {
 #if PCLIP_SR
-        if constexpr (M16) pgemm::mainloop_sr<C, YOUNGER, !HAS_BIAS, TP, DIRECT>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, tr);
+        if constexpr (M16) pgemm::mainloop_sr<C, YOUNGER, !HAS_BIAS, TP, DIRECT, LANE>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, tr);
 #else
         if constexpr (M16) pgemm::mainloop_bl<C, YOUNGER, !HAS_BIAS, PCLIP_PF>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, smem + C::LDS_BYTES + STRIP_BYTES);
 #endif
@@ -475,7 +477,10 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             prev_full = false;
             continue;
 #endif
-            if (full) pgemm::epilogue_direct<C>(acc, Cout, ldc, m0, n0, pre, [](int) { return true; });
+            auto nofin = [](pgemm::uint4v_t x, int, int, int) { return x; };
+            if (LANE && full) pgemm::epilogue_lane<C>(acc, Cout, ldc, m0, n0, pre, nofin, [](int) { return true; });
+            else if (LANE) pgemm::epilogue_lane<C>(acc, Cout, ldc, m0, n0, pre, nofin, [&](int m) { return m < M; });
+            else if (full) pgemm::epilogue_direct<C>(acc, Cout, ldc, m0, n0, pre, [](int) { return true; });
             else pgemm::epilogue_direct<C>(acc, Cout, ldc, m0, n0, pre, [&](int m) { return m < M; });
             prev_full = full;
             continue;

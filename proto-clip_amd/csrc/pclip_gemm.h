@@ -314,7 +314,11 @@ struct TilePair {
 #ifndef PCLIP_DMA_ROLES
 #define PCLIP_DMA_ROLES 1
 #endif
-template <class C>
+// PERM (column-permuted B tile, for pgemm::epilogue_lane): the B fragment of MFMA block blk = 2 j + b takes, for MFMA column c = lane & 15, the tile row
+// wn * 64 + 16 (c >> 2) + 4 blk + (c & 3) instead of wn * 64 + 16 blk + c — a lane's accumulator quads of the four blocks then are 16 CONSECUTIVE output
+// columns.  Those 16 rows of a fragment read differ in row bits 0, 1, 4, 5, so the B image's swizzle key becomes ((row >> 1) & 1) | (((row >> 4) & 3) << 1)
+// (conflict-free under ds_read_b128's lane groups like the default key); on the staging side it depends on the 16-row group of a piece: four offsets.
+template <class C, bool PERM = false>
 struct TilePairR {
     static constexpr bool ROLES = true;
     static_assert(C::NWAVES == 8, "role split: waves w and w + 4 share a SIMD");
@@ -324,8 +328,9 @@ struct TilePairR {
     // only depends on the parity of i, so piece i = piece (i & 1) + (i >> 1) * 16 rows, and those 16 rows travel in the instruction's
     // SCALAR offset together with the K-tile.  Rows beyond the operand are not clamped but cut off by the descriptor's size (a buffer
     // load past num_records returns zeros; such rows are never stored).
+    static_assert(!PERM || C::BN == 256, "permuted B tile: four 16-row groups per staging wave");
     rsrc_t rs;
-    int voff[2];
+    int voff[PERM ? 4 : 2];
     int row16;                                                        // bytes of 16 operand rows (wave-uniform)
     bool is_b;                                                        // wave-uniform
     __device__ __forceinline__ void prepare(const half_t* __restrict__ A, int lda, const half_t* __restrict__ B, int ldb, int M, int N,
@@ -341,6 +346,15 @@ struct TilePairR {
         rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, size, 0x00020000);
 #endif
         row16 = 16 * ld * 2;
+        if (PERM && is_b) {
+#pragma unroll
+            for (int v = 0; v < (PERM ? 4 : 0); ++v) {             // 16-row group v of the wave's 64 rows: rows 16 v + (lane >> 3) (+ 8 in the scalar offset)
+                const int r = w4 * rpw + 16 * v + (lane >> 3);
+                const int c = (lane & 7) ^ (((lane >> 4) & 1) | (v << 1));
+                voff[v] = (r * ld + c * 8) * 2;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = w4 * rpw + i * 8 + (lane >> 3);
@@ -352,7 +366,12 @@ struct TilePairR {
     __device__ __forceinline__ void stage(int t, char* stage_buf, int wave) const {
 #if defined(__HIP_DEVICE_COMPILE__)
         const int w4 = wave & 3, k = t * (BK * 2);
-        if (is_b) {
+        if (is_b && PERM) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i)                               // piece i = rows 16 (i >> 1) + 8 (i & 1) + (lane >> 3) of the wave's share
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(stage_buf + C::A_BYTES + (w4 * (C::BN / 4) + i * 8) * ROW_BYTES), 16, voff[PERM ? i >> 1 : 0],
+                                                         k + (i & 1) * (row16 >> 1), 0, 0);
+        } else if (is_b) {
 #pragma unroll
             for (int i = 0; i < NB; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(stage_buf + C::A_BYTES + (w4 * (C::BN / 4) + i * 8) * ROW_BYTES), 16, voff[i & 1],
@@ -486,7 +505,9 @@ __device__ __forceinline__ void mainloop_bl(const TilePair<C>& tp, int nt, char*
 #endif
 // TWO: K-tiles 0 AND 1 were requested by the caller (direct-store epilogue: no LDS staging area between tiles); `counted_first` then
 // also covers the wait for K-tile 1, whose pieces sit in front of the previous tile's YOUNGER - NA|NB stores and strip copies.
-template <class C, int YOUNGER = 0, bool ZERO_ACC = true, class TP = TilePair<C>, bool TWO = false>
+// PERM: the B image is column-permuted (TilePairR<C, true>): accumulator element (a * 2 + b) * 4 + e of acc.v[i][j] is then output column
+// wn * (BN / WN) + 16 (lane >> 4) + 4 (2 j + b) + e (row i * 32 + a * 16 + (lane & 15) as before).
+template <class C, int YOUNGER = 0, bool ZERO_ACC = true, class TP = TilePair<C>, bool TWO = false, bool PERM = false>
 __device__ __forceinline__ void mainloop_sr(const TP& tp, int nt, char* smem, Acc<C>& acc, int& p, bool counted_first, int wave,
                                             int lane, unsigned long long* g_tr = nullptr) {
     static_assert(C::TM >= 2 && C::TM % 2 == 0, "group pipeline splits the wave's A rows in two halves");
@@ -510,7 +531,9 @@ __device__ __forceinline__ void mainloop_sr(const TP& tp, int nt, char* smem, Ac
     const int key = (lane & 15) >> 1, q = lane >> 4;
     const int col0 = (q ^ key) << 4;
     const int offa = (wm * (C::BM / C::WM) + (lane & 15)) * ROW_BYTES + col0;
-    const int offb = C::A_BYTES + (wn * (C::BN / C::WN) + (lane & 15)) * ROW_BYTES + col0;
+    const int cb = lane & 15;
+    const int offb = PERM ? C::A_BYTES + (wn * (C::BN / C::WN) + 16 * (cb >> 2) + (cb & 3)) * ROW_BYTES + ((q ^ (((cb >> 1) & 1) | ((cb >> 2) << 1))) << 4)
+                          : C::A_BYTES + (wn * (C::BN / C::WN) + (lane & 15)) * ROW_BYTES + col0;
     // (s_setprio measured on this loop, tools/ab_multi.py gemm, profiles/r03_ab_gemm_prio.txt: priority 1 around every MFMA group
     // is neutral at N = 3072 and 5 - 32 % SLOWER at N = 768 / 2304; a static priority for the younger half of the waves is +-0.5 %.)
 
@@ -535,7 +558,7 @@ __device__ __forceinline__ void mainloop_sr(const TP& tp, int nt, char* smem, Ac
         char* cur = smem + p * C::STAGE_BYTES;
         const char* base = cur;
         auto fa = [&](int ks, int i, int a) { return *reinterpret_cast<const half8_t*>(base + (offa ^ (ks << 6)) + (i * 32 + a * 16) * ROW_BYTES); };
-        auto fb = [&](int ks, int j, int b) { return *reinterpret_cast<const half8_t*>(base + (offb ^ (ks << 6)) + (j * 32 + b * 16) * ROW_BYTES); };
+        auto fb = [&](int ks, int j, int b) { return *reinterpret_cast<const half8_t*>(base + (offb ^ (ks << 6)) + (PERM ? (2 * j + b) * 4 : j * 32 + b * 16) * ROW_BYTES); };
         half8_t bcur[C::TN][2], acur[HM][2], anext[HM][2], bnext[C::TN][2];
         auto load_a = [&](half8_t (&dst)[HM][2], int ks, int half) {
 #pragma unroll
@@ -1152,6 +1175,78 @@ __device__ __forceinline__ void epilogue_direct(const Acc<C>& acc, half_t* __res
                 const half4_t hv = pre(i, j, coff, v, rl, g);
                 if (ok) *reinterpret_cast<half4_t*>(base + (size_t)(i * 32 + (g >> 1) * 16) * ldc + j * 32 + (g & 1) * 16) = hv;
             }
+        }
+}
+
+// ---- fp16 output in 16-byte pieces straight from the (column-permuted) accumulator layout -------------------------------------------
+// With the PERM layout a lane holds, for every 16-row half (i, a) of its rows, the 16 consecutive columns 16 q .. 16 q + 15 of row a * 16 + r
+// (r = lane & 15, q = lane >> 4): two 16-byte pieces P0 | P1.  Lanes r and r ^ 8 exchange one piece each (DPP row_ror:8), after which lane r < 8 holds
+// P0 of rows r and r + 8 and lane r >= 8 holds P1 of rows r - 8 and r: a wave store instruction then covers 8 rows x 128 contiguous bytes — the same
+// 1 KB / 8 lines per instruction as the LDS-staged pass, with no LDS, no barrier, and every wave on its own.  TM * 2 * 2 = 16 stores per wave and tile.
+// `fin(piece, row_in_tile, col_in_tile, k)`: last touch of a 16-byte piece before its store (residual add), k = 2 (2 i + a) + {0, 1} its index.
+typedef unsigned uint4v_t __attribute__((ext_vector_type(4)));
+#ifndef PCLIP_LANE_BPERM
+#define PCLIP_LANE_BPERM 1
+#endif
+template <class C, class Pre, class Fin, class RowOk>
+__device__ __forceinline__ void epilogue_lane(const Acc<C>& acc, half_t* __restrict__ Cout, int ldc, int m0, int n0, const Pre& pre, const Fin& fin, const RowOk& row_ok) {
+    static_assert(C::TN == 2 && C::BN / C::WN == 64, "a wave owns 64 output columns");
+    int tid = threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(tid));
+#endif
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / C::WN, wn = wave % C::WN, r = lane & 15, q = lane >> 4;
+    const bool lo = r < 8;
+    const int row_l = wm * (C::BM / C::WM) + (r & 7), col_l = wn * 64 + 16 * q + (lo ? 0 : 8);      // piece X0 of (i, a): row row_l + i * 32 + a * 16, X1: + 8
+    const int src_lane4 = (16 * ((lane >> 1) & 3) + (lane >> 3) + 8 * (lane & 1)) * 4;              // byte address of the ds_bpermute source lane (see below)
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            unsigned pk[8];                                                      // the lane's 16 halves of row i * 32 + a * 16 + r: P0 = pk[0..3], P1 = pk[4..7]
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+                const int j = blk >> 1, b = blk & 1, g = a * 2 + b;
+                const float4_t v = {acc.v[i][j][4 * g], acc.v[i][j][4 * g + 1], acc.v[i][j][4 * g + 2], acc.v[i][j][4 * g + 3]};
+                const half4_t hv = pre(i, j, 16 * q + 4 * blk, v, a * 16 + r, g);
+                const half2_t h01 = {hv[0], hv[1]}, h23 = {hv[2], hv[3]};
+                pk[2 * blk] = __builtin_bit_cast(unsigned, h01);
+                pk[2 * blk + 1] = __builtin_bit_cast(unsigned, h23);
+            }
+            uint4v_t x0, x1;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const unsigned send = lo ? pk[4 + d] : pk[d];
+#if defined(__HIP_DEVICE_COMPILE__)
+                const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp((int)send, (int)send, 0x128, 0xF, 0xF, false);   // row_ror:8 = lane r ^ 8 of the 16-lane row
+#else
+                const unsigned recv = send;
+#endif
+                x0[d] = lo ? pk[d] : recv;
+                x1[d] = lo ? recv : pk[4 + d];
+            }
+#if PCLIP_LANE_BPERM && defined(__HIP_DEVICE_COMPILE__)
+            // The address path coalesces CONSECUTIVE lanes: with lane = (q, r) consecutive lanes are consecutive ROWS and a store instruction touches 64 lines a
+            // quad at a time (measured: 95 cycles per store instead of 19).  One ds_bpermute per dword (the LDS crossbar: no LDS memory, no barrier) brings the
+            // pieces into store order: lane l' takes row l' >> 3, 16-byte chunk l' & 7 of the wave's 128-byte row segment = the piece of lane (r = (l' >> 3) + 8 (l' & 1), q = (l' >> 1) & 3).
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                x0[d] = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane4, (int)x0[d]);
+                x1[d] = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane4, (int)x1[d]);
+            }
+            const int row0 = wm * (C::BM / C::WM) + i * 32 + a * 16 + (lane >> 3), col_s = wn * 64 + 8 * (lane & 7);
+            x0 = fin(x0, row0, col_s, 2 * (2 * i + a));
+            x1 = fin(x1, row0 + 8, col_s, 2 * (2 * i + a) + 1);
+            if (row_ok(m0 + row0)) *reinterpret_cast<uint4v_t*>(Cout + (size_t)(m0 + row0) * ldc + n0 + col_s) = x0;
+            if (row_ok(m0 + row0 + 8)) *reinterpret_cast<uint4v_t*>(Cout + (size_t)(m0 + row0 + 8) * ldc + n0 + col_s) = x1;
+#else
+            const int row0 = row_l + i * 32 + a * 16;
+            x0 = fin(x0, row0, col_l, 2 * (2 * i + a));
+            x1 = fin(x1, row0 + 8, col_l, 2 * (2 * i + a) + 1);
+            if (row_ok(m0 + row0)) *reinterpret_cast<uint4v_t*>(Cout + (size_t)(m0 + row0) * ldc + n0 + col_l) = x0;
+            if (row_ok(m0 + row0 + 8)) *reinterpret_cast<uint4v_t*>(Cout + (size_t)(m0 + row0 + 8) * ldc + n0 + col_l) = x1;
+#endif
         }
 }
 
