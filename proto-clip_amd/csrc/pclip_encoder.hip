@@ -27,6 +27,9 @@ namespace {
 #ifndef PCLIP_PP
 #define PCLIP_PP 0               // 1: 256 x 256 tiles take the ping-pong K-loop (pgemm::mainloop_pp) — bit-identical, measured 4 - 10 % slower than mainloop_sr (profiles/r03_ab_pingpong.txt)
 #endif
+#ifndef PCLIP_RES_PF
+#define PCLIP_RES_PF 0           // 1: residual epilogues touch their tile of the residual stream into L2 from inside the K-loop (pgemm::mainloop_sr PFN / touch) — out_proj 7.6 % / c_proj 4 % SLOWER (profiles/r03_ab_rejected.txt)
+#endif
 #ifndef PCLIP_EPI_PIPE
 #define PCLIP_EPI_PIPE 1         // 256 x 256 tiles: the LDS-staged epilogue as a four-slab pipeline (pgemm::epilogue_pipe)
 #endif
@@ -332,7 +335,16 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             }, tr);
         } else {
 #if PCLIP_SR
-        if constexpr (M16) pgemm::mainloop_sr<C, YOUNGER, !HAS_BIAS, TP, DIRECT, LANE>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, tr);
+        // residual epilogues: the tile of the residual stream is pulled into L2 from inside the K-loop (1024 lines = two 64-line touches per wave, by 4-byte LDS-DMA
+        // into a scrap area: no registers), so that the epilogue's residual chunks are L2 hits instead of two HBM round trips per tile
+        constexpr int PFN = (PCLIP_RES_PF && (ACT == 6 || ACT == 9) && C::BM == 256 && C::BN == 256 && C::NWAVES == 8) ? 2 : 0;
+        auto touch = [&](int k) {
+            const int line = (2 * wave + k) * 64 + lane, row = line >> 2, seg = line & 3;
+            int gm = m0 + row;
+            gm = gm < M ? gm : M - 1;
+            __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(residual + (size_t)gm * ldc + n0 + seg * 64), (pgemm::lds_ptr_t)(smem + C::LDS_BYTES + STRIP_BYTES), 4, 0, 0);
+        };
+        if constexpr (M16) pgemm::mainloop_sr<C, YOUNGER, !HAS_BIAS, TP, DIRECT, LANE, PFN>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, tr, touch);
 #else
         if constexpr (M16) pgemm::mainloop_bl<C, YOUNGER, !HAS_BIAS, PCLIP_PF>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, smem + C::LDS_BYTES + STRIP_BYTES);
 #endif

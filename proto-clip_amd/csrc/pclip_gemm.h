@@ -507,9 +507,14 @@ __device__ __forceinline__ void mainloop_bl(const TilePair<C>& tp, int nt, char*
 // also covers the wait for K-tile 1, whose pieces sit in front of the previous tile's YOUNGER - NA|NB stores and strip copies.
 // PERM: the B image is column-permuted (TilePairR<C, true>): accumulator element (a * 2 + b) * 4 + e of acc.v[i][j] is then output column
 // wn * (BN / WN) + 16 (lane >> 4) + 4 (2 j + b) + e (row i * 32 + a * 16 + (lane & 15) as before).
-template <class C, int YOUNGER = 0, bool ZERO_ACC = true, class TP = TilePair<C>, bool TWO = false, bool PERM = false>
+// PFN / touch(k): in iteration nt - 5 every wave issues PFN extra vector-memory operations `touch(0 .. PFN - 1)` right behind its own pieces of that iteration
+// (the residual epilogues pull their tile of the residual stream into L2 this way, ~3 iterations before the epilogue asks for it).  They are YOUNGER than the
+// pieces the next two top-of-iteration waits are for, so those two waits leave PFN more operations outstanding — an in-order wait that did not would sit out
+// the touches' whole HBM round trip in the middle of the K-loop.
+struct NoTouch { __device__ __forceinline__ void operator()(int) const {} };
+template <class C, int YOUNGER = 0, bool ZERO_ACC = true, class TP = TilePair<C>, bool TWO = false, bool PERM = false, int PFN = 0, class Touch = NoTouch>
 __device__ __forceinline__ void mainloop_sr(const TP& tp, int nt, char* smem, Acc<C>& acc, int& p, bool counted_first, int wave,
-                                            int lane, unsigned long long* g_tr = nullptr) {
+                                            int lane, unsigned long long* g_tr = nullptr, const Touch& touch = Touch()) {
     static_assert(C::TM >= 2 && C::TM % 2 == 0, "group pipeline splits the wave's A rows in two halves");
     constexpr int HM = C::TM / 2;
     constexpr int NA = TP::NA, NB = TP::NB;
@@ -519,6 +524,11 @@ __device__ __forceinline__ void mainloop_sr(const TP& tp, int nt, char* smem, Ac
         if constexpr (TP::ROLES) { if (wave < 4) wait_vm<NB>(); else wait_vm<NA>(); }
         else wait_vm<NA + NB>();
     };
+    auto wait_ahead_pf = [&]() {
+        if constexpr (TP::ROLES) { if (wave < 4) wait_vm<NB + PFN>(); else wait_vm<NA + PFN>(); }
+        else wait_vm<NA + NB + PFN>();
+    };
+    const int t_pf = (PFN > 0 && nt >= 6) ? nt - 5 : -1;                // iteration that issues the touches (it refills: t_pf + 2 < nt)
     const int wm = wave / C::WN, wn = wave % C::WN;
     if (ZERO_ACC) {
 #pragma unroll
@@ -547,6 +557,7 @@ __device__ __forceinline__ void mainloop_sr(const TP& tp, int nt, char* smem, Ac
         PCLIP_STAMP(tr0);
         if (t == 0) { if (counted_first) wait_vm<YOUNGER>(); else wait_vm<0>(); }
         else if (TWO && t == 1 && counted_first && nt > 2) wait_vm<YOUNGER>();   // behind K-tile 1: the stores / strips and K-tile 2's pieces = as many as behind K-tile 0
+        else if (PFN > 0 && (t == t_pf + 1 || t == t_pf + 2) && t_pf >= 0) wait_ahead_pf();
         else if (t + 1 < nt) wait_ahead();
         else wait_vm<0>();
         PCLIP_STAMP(tr1);
@@ -618,6 +629,12 @@ __device__ __forceinline__ void mainloop_sr(const TP& tp, int nt, char* smem, Ac
 #endif
             if constexpr (TP::ROLES) { if (wave < 4) tp.stage(t + 2, cur, wave); }
             else if (!(PCLIP_ABL & 1)) tp.b.template stage<0>((t + 2) * (BK * 2), cur + C::A_BYTES, wave);
+            if constexpr (PFN > 0 && TP::ROLES) {
+                if (t == t_pf && wave < 4) {
+#pragma unroll
+                    for (int k = 0; k < PFN; ++k) touch(k);
+                }
+            }
         }
         load_a(anext, 1, 1);
         group(acur, bnext, 0);                   // ks 1, rows half 0
@@ -632,6 +649,12 @@ __device__ __forceinline__ void mainloop_sr(const TP& tp, int nt, char* smem, Ac
 #endif
             if constexpr (TP::ROLES) { if (wave >= 4) tp.stage(t + 2, cur, wave); }
             else if (!(PCLIP_ABL & 1)) tp.a.template stage<PCLIP_NT_A>((t + 2) * (BK * 2), cur, wave);
+            if constexpr (PFN > 0) {
+                if (t == t_pf && (!TP::ROLES || wave >= 4)) {
+#pragma unroll
+                    for (int k = 0; k < PFN; ++k) touch(k);
+                }
+            }
         }
         group(anext, bnext, 1);                  // ks 1, rows half 1
         p ^= 1;
