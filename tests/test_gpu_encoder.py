@@ -86,6 +86,27 @@ def test_gemm_banded_tile_order_is_bit_identical(ops, monkeypatch):
     monkeypatch.delenv("PCLIP_GEMM_BAND")
 
 
+def test_gemm_quickgelu_pipelined_epilogue_is_the_two_slab_epilogue(ops, monkeypatch):
+    """256 x 256 tiles stage a QuickGELU epilogue as a four-slab pipeline (pgemm::epilogue_pipe: slab k = 32-row block k of every wave, two halves of the
+    staging buffer, the activation arithmetic of slab k + 1 under the stores of slab k); every other tile shape keeps the two-slab pass.  Same bits —
+    on a shape with a partial last row block — and within 3 fp16 ulp of the fp32 reference with the reference's three roundings."""
+    M, N, K = 70001, 3072, 128
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a = torch.randn(M, K, device="cuda", generator=g).half()
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).half()
+    b = torch.randn(N, device="cuda", generator=g).half()
+    monkeypatch.setenv("PCLIP_GEMM_CFG_LIVE", "1")
+    monkeypatch.setenv("PCLIP_GEMM_CFG", "2")               # 256 x 256 tiles
+    big = ops.gemm(a, w, b, act=1)
+    monkeypatch.setenv("PCLIP_GEMM_CFG", "0")               # 128 x 128 tiles: epilogue_f16
+    assert torch.equal(ops.gemm(a, w, b, act=1), big)
+    monkeypatch.delenv("PCLIP_GEMM_CFG")
+    rows = torch.cat([torch.arange(0, 600), torch.arange(M - 300, M)]).cuda()
+    h = po.r16((a[rows].float() @ w.float().t() + b.float()).cpu())
+    ref = po.r16(h * po.r16(torch.sigmoid(po.r16(1.702 * h))))
+    assert ulp_diff(big[rows].cpu(), ref.half()) <= 3
+
+
 @pytest.mark.parametrize("M,N,K,act", [(197, 768, 3072, 0), (1, 768, 3072, 0), (8, 3072, 3072, 1), (32, 512, 3072, 1), (257, 1024, 4096, 0),
                                         (130, 64, 2048, 1), (64, 1024, 4096, 0)])
 def test_gemm_splitk_small_M(ops, M, N, K, act):
@@ -182,13 +203,13 @@ def test_layernorm_big_batch_kernel_is_the_small_batch_kernel(ops, D):
     """More than 65 536 rows take layernorm_pf_kernel (next row's loads ahead of the reductions), fewer layernorm_kernel: same source
     arithmetic, but two compilations — hipcc's contraction / SLP choices can move a rounding between them (seen once while editing a
     shared header: one fp16 ulp on 0.4 % of the rows).  "A row alone == the row in a batch" needs them equal bit for bit."""
-    R = 70000
-    g = torch.Generator(device="cuda").manual_seed(D)
-    x = (torch.randn(R, D, device="cuda", generator=g) * 1.3 + 0.2).half()
-    gam, bet = 1 + 0.3 * torch.randn(D, device="cuda", generator=g), 0.2 * torch.randn(D, device="cuda", generator=g)
-    big = ops.layernorm(x, gam, bet)
-    small = torch.cat([ops.layernorm(x[i:i + 5000].contiguous(), gam, bet) for i in range(0, R, 5000)])
-    assert torch.equal(big, small)
+    for R in (70000, 140001):       # 140 001 rows: the whole-batch form (>= 16 rows per workgroup of the 32-per-CU grid) with gamma / beta from the workgroup's LDS copy
+        g = torch.Generator(device="cuda").manual_seed(D)
+        x = (torch.randn(R, D, device="cuda", generator=g) * 1.3 + 0.2).half()
+        gam, bet = 1 + 0.3 * torch.randn(D, device="cuda", generator=g), 0.2 * torch.randn(D, device="cuda", generator=g)
+        big = ops.layernorm(x, gam, bet)
+        small = torch.cat([ops.layernorm(x[i:i + 5000].contiguous(), gam, bet) for i in range(0, R, 5000)])
+        assert torch.equal(big, small), R
 
 
 @pytest.mark.parametrize("R,D,L", [(12, 64, 3), (394, 768, 197), (77, 512, 7)])
