@@ -1617,7 +1617,7 @@ __device__ __forceinline__ void ln_row_inplace(float (&v)[NCH][8], int D, int la
     }
 }
 
-template <int NCH>
+template <int NCH, bool GB_LDS = false>
 __global__ __launch_bounds__(256) void vit_embed_ln_kernel(const half_t* __restrict__ patch, const half_t* __restrict__ cls,
                                                            const half_t* __restrict__ pos, int B, int G2, int W,
                                                            const float* __restrict__ g0, const float* __restrict__ b0,
@@ -1626,6 +1626,19 @@ __global__ __launch_bounds__(256) void vit_embed_ln_kernel(const half_t* __restr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int L = G2 + 1;
     const size_t R = (size_t)B * L;
+    // GB_LDS (whole batches): the four affine vectors once per workgroup into LDS, as in layernorm_pf_kernel — per 1.5 KB row they were 12 KB through the
+    // vector-memory path
+    __shared__ __attribute__((aligned(16))) float gb_s[4][GB_LDS ? NCH * 512 : 4];
+    if (GB_LDS) {
+        for (int i = threadIdx.x; i < NCH * 512; i += 256) {
+            gb_s[0][i] = i < W ? g0[i] : 0.f;
+            gb_s[1][i] = i < W ? b0[i] : 0.f;
+            gb_s[2][i] = (h && i < W) ? g1[i] : 0.f;
+            gb_s[3][i] = (h && i < W) ? b1[i] : 0.f;
+        }
+        __syncthreads();
+        g0 = gb_s[0]; b0 = gb_s[1]; g1 = gb_s[2]; b1 = gb_s[3];
+    }
     for (size_t row = (size_t)blockIdx.x * 4 + wave; row < R; row += (size_t)gridDim.x * 4) {
         const int l = (int)(row % L);
         const size_t bb = row / L;
@@ -2461,7 +2474,16 @@ extern "C" int pclip_vit_embed_ln_f16(const void* patch_emb, const void* class_e
     PCLIP_REQUIRE(B >= 0 && G2 > 0 && W > 0 && W % 8 == 0 && W <= 4096, "pclip_vit_embed_ln_f16: bad shape B=%d G2=%d W=%d", B, G2, W);
     if (B == 0) return PCLIP_OK;
     const size_t R = (size_t)B * (G2 + 1);
-    const int grid = (int)((R + 3) / 4 > 16384 ? 16384 : (R + 3) / 4);
+    int grid = (int)((R + 3) / 4 > 16384 ? 16384 : (R + 3) / 4);
+    const int ln_grid = pclip_device_cus() * PCLIP_LN_BPC;
+    if (PCLIP_LN_LDS && W <= 1024 && R >= (size_t)16 * ln_grid) {     // whole batch: resident-size grid, affine vectors from LDS (<= 16 KB per workgroup)
+        grid = ln_grid;
+        if (W <= 512) vit_embed_ln_kernel<1, true><<<grid, 256, 0, (hipStream_t)stream>>>((const half_t*)patch_emb, (const half_t*)class_emb, (const half_t*)pos_emb, B, G2, W, gamma_pre,
+                                                                                          beta_pre, gamma_1, beta_1, eps, (half_t*)x0, (half_t*)h, stats);
+        else vit_embed_ln_kernel<2, true><<<grid, 256, 0, (hipStream_t)stream>>>((const half_t*)patch_emb, (const half_t*)class_emb, (const half_t*)pos_emb, B, G2, W, gamma_pre,
+                                                                                 beta_pre, gamma_1, beta_1, eps, (half_t*)x0, (half_t*)h, stats);
+        return pclip_check_launch("vit_embed_ln");
+    }
 #define PCLIP_VEL(NCH) vit_embed_ln_kernel<NCH><<<grid, 256, 0, (hipStream_t)stream>>>((const half_t*)patch_emb, (const half_t*)class_emb, \
         (const half_t*)pos_emb, B, G2, W, gamma_pre, beta_pre, gamma_1, beta_1, eps, (half_t*)x0, (half_t*)h, stats)
     if (W <= 512) PCLIP_VEL(1);
