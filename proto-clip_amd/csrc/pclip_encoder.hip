@@ -27,6 +27,9 @@ namespace {
 #ifndef PCLIP_PP
 #define PCLIP_PP 0               // 1: 256 x 256 tiles take the ping-pong K-loop (pgemm::mainloop_pp) — bit-identical, measured 4 - 10 % slower than mainloop_sr (profiles/r03_ab_pingpong.txt)
 #endif
+#ifndef PCLIP_CFG_BIG4
+#define PCLIP_CFG_BIG4 0         // 1: also build the four-wave 256 x 256 configuration (Cfg<256,256,2,2>; PCLIP_GEMM_CFG=5 selects it)
+#endif
 #ifndef PCLIP_RES_PF
 #define PCLIP_RES_PF 0           // 1: residual epilogues touch their tile of the residual stream into L2 from inside the K-loop (pgemm::mainloop_sr PFN / touch) — out_proj 7.6 % / c_proj 4 % SLOWER (profiles/r03_ab_rejected.txt)
 #endif
@@ -181,7 +184,7 @@ __device__ __forceinline__ void st_out(half_t* p, half8_t v) {
 // travels by global_load_lds into a small double-buffered LDS strip), because hipcc answers any ordinary
 // VGPR load issued beside an LDS-DMA with a full vmcnt(0) drain at its use (guide §5, trap (b)).
 template <class C, bool HAS_BIAS, int ACT, bool M16 = false>
-__global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_t* __restrict__ A, int lda,
+__global__ __launch_bounds__(C::NTHREADS, (C::NWAVES == 4 && C::BM * C::BN == 65536) ? 1 : 2) void linear_fast_kernel(const half_t* __restrict__ A, int lda,
                                                                      const half_t* __restrict__ B, int ldb, int M, int N,
                                                                      int K, const half_t* __restrict__ bias,
                                                                      const float* __restrict__ scale,
@@ -689,6 +692,7 @@ using CfgBig = pgemm::Cfg<256, 256, 2, 4>;
 using CfgWide = pgemm::Cfg<256, 128, 4, 2>;
 using CfgNarrow = pgemm::Cfg<256, 64, 4, 2>;          // 64-channel convolutions of the ResNet tower
 using CfgThin = pgemm::Cfg<256, 32, 4, 1>;            // its 32-channel stem (4 waves, two workgroups per CU)
+using CfgBig4 = pgemm::Cfg<256, 256, 2, 2>;           // the 256 x 256 tile on FOUR waves (one per SIMD, 128 x 128 each: 256 accumulator registers of the 512 a lone wave may use) — experiment, PCLIP_GEMM_CFG=5
 using CfgSmall = pgemm::CfgSmall;
 
 template <class C, bool HAS_BIAS, int ACT, bool M16 = false>
@@ -1733,8 +1737,8 @@ extern "C" long pclip_gemm_kernel_launches(void) { return g_gemm_launches; }
 
 namespace {
 struct TileCfg { int bm, bn, wg_per_cu; double eff; };
-constexpr int kNumCfgs = 5;
-constexpr TileCfg kTileCfgs[kNumCfgs] = {{128, 128, 2, 0.85}, {256, 128, 1, 0.85}, {256, 256, 1, 1.0}, {256, 64, 1, 0.6}, {256, 32, 2, 0.4}};
+constexpr int kNumCfgs = 5;                  // configurations the cost model chooses from; index 5 (CfgBig4) only by PCLIP_GEMM_CFG=5
+constexpr TileCfg kTileCfgs[kNumCfgs + 1] = {{128, 128, 2, 0.85}, {256, 128, 1, 0.85}, {256, 256, 1, 1.0}, {256, 64, 1, 0.6}, {256, 32, 2, 0.4}, {256, 256, 1, 1.0}};
 constexpr double kLaunchCost = 0.5;          // extra launch of a split, in the same units
 
 thread_local int g_min_bn = 0;               // act 9 (statistics partials per 64 columns): tiles narrower than 64 columns are excluded
@@ -1777,7 +1781,7 @@ int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int
     if (epi.act >= 7 && pick < 0) { pclip_set_error("pclip_gemm_ln_f16: N=%d / alignment not supported by the fused epilogue", N); return PCLIP_E_INVALID; }
     if (forced >= 0) {
         may_split = false;
-        if (aligned && forced < kNumCfgs && N % kTileCfgs[forced].bn == 0) pick = forced;
+        if (aligned && forced <= kNumCfgs && N % kTileCfgs[forced].bn == 0) pick = forced;
     }
     if (pick >= 0 && may_split) {
         long split_rows = 0;                                   // rows given to the full rounds of configuration split_cfg
@@ -1811,6 +1815,9 @@ int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int
     if (pick == 0) return launch_fast<CfgSmall>(A, lda, B, ldb, M, N, K, epi, 2 * cus, s);
     if (pick == 3) return launch_fast<CfgNarrow>(A, lda, B, ldb, M, N, K, epi, cus, s);
     if (pick == 4) return launch_fast<CfgThin>(A, lda, B, ldb, M, N, K, epi, 2 * cus, s);
+#if PCLIP_CFG_BIG4
+    if (pick == 5) return launch_fast<CfgBig4>(A, lda, B, ldb, M, N, K, epi, cus, s);
+#endif
     const int tiles_m = ceil_div(M, 128), tiles_n = ceil_div(N, 128);
     linear_generic_kernel<<<tiles_m * tiles_n, 256, CfgSmall::LDS_BYTES, s>>>(A, lda, B, ldb, M, N, K, epi, tiles_n);
     return pclip_check_launch("gemm_f16 (generic)");
@@ -1837,6 +1844,7 @@ extern "C" int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, vo
         forced = f ? atoi(f) : -1;
         if (forced == 3) forced = -2;                       // generic kernel
         else if (forced == 4) forced = 3;                   // index of the 256x64 configuration
+        else if (forced == 5 && !PCLIP_CFG_BIG4) forced = -1;
         live = getenv("PCLIP_GEMM_CFG_LIVE") != nullptr;   // tools/ab_cfg.py: re-read the overrides on every call
         nosplit = getenv("PCLIP_GEMM_NOSPLIT") != nullptr;
         g_m16 = !(getenv("PCLIP_GEMM_M16") != nullptr && getenv("PCLIP_GEMM_M16")[0] == '0');
