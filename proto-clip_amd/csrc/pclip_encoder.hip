@@ -2278,8 +2278,8 @@ extern "C" int pclip_layernorm_f16(const void* x, int ld_x, const float* gamma, 
                   "pclip_layernorm_f16: bad shape R=%d D=%d ld=%d", R, D, ld_x);
     if (R == 0) return PCLIP_OK;
     // whole-batch pass (>= 16 rows per workgroup of a PCLIP_LN_BPC-per-CU grid): gamma / beta from the workgroup's LDS copy
-    const int ln_grid = pclip_device_cus() * PCLIP_LN_BPC;
-    if (PCLIP_LN_PF && PCLIP_LN_LDS && R >= 16 * ln_grid) {
+    const int ln_grid = pclip_device_cus() * PCLIP_LN_BPC;          // (0 if the CU count is unknown: the old paths)
+    if (PCLIP_LN_PF && PCLIP_LN_LDS && ln_grid > 0 && R >= 16 * ln_grid) {
         DISPATCH_NCH(D, (layernorm_pf_kernel<NCH, true><<<ln_grid, 256, 0, (hipStream_t)stream>>>((const half_t*)x, ld_x, gamma, beta, eps, (half_t*)y, R, D)));
         return pclip_check_launch("layernorm");
     }
@@ -2484,7 +2484,7 @@ extern "C" int pclip_vit_embed_ln_f16(const void* patch_emb, const void* class_e
     const size_t R = (size_t)B * (G2 + 1);
     int grid = (int)((R + 3) / 4 > 16384 ? 16384 : (R + 3) / 4);
     const int ln_grid = pclip_device_cus() * PCLIP_LN_BPC;
-    if (PCLIP_LN_LDS && W <= 1024 && R >= (size_t)16 * ln_grid) {     // whole batch: resident-size grid, affine vectors from LDS (<= 16 KB per workgroup)
+    if (PCLIP_LN_LDS && W <= 1024 && ln_grid > 0 && R >= (size_t)16 * ln_grid) {     // whole batch: resident-size grid, affine vectors from LDS (<= 16 KB per workgroup)
         grid = ln_grid;
         if (W <= 512) vit_embed_ln_kernel<1, true><<<grid, 256, 0, (hipStream_t)stream>>>((const half_t*)patch_emb, (const half_t*)class_emb, (const half_t*)pos_emb, B, G2, W, gamma_pre,
                                                                                           beta_pre, gamma_1, beta_1, eps, (half_t*)x0, (half_t*)h, stats);
