@@ -220,6 +220,7 @@ __global__ __launch_bounds__(C::NTHREADS, (C::NWAVES == 4 && C::BM * C::BN == 65
     // instead of 4.7) at the price of reading the activations once per band.
     const int tiles_m_all = ntiles / tiles_n;
     auto decomp = [&](int t, int& tm, int& tn) {
+        if (band < 0) t = ntiles - 1 - t;                   // band == -1: the tiles in DESCENDING order (PCLIP_GEMM_REV: the rows the producer wrote last are read first)
         if (band <= 0 || band >= tiles_n) { tm = t / tiles_n; tn = t - tm * tiles_n; return; }
         const int per_band = tiles_m_all * band, bnd = t / per_band, r = t - bnd * per_band;
         const int w = band < tiles_n - bnd * band ? band : tiles_n - bnd * band;
@@ -714,9 +715,16 @@ static int launch_fast2(const void* A, int lda, const void* B, int ldb, int M, i
     const int grid = ntiles < slots ? ntiles : slots;
     static const int band_env = getenv("PCLIP_GEMM_BAND") ? atoi(getenv("PCLIP_GEMM_BAND")) : 0;
     const int band = getenv("PCLIP_GEMM_CFG_LIVE") ? (getenv("PCLIP_GEMM_BAND") ? atoi(getenv("PCLIP_GEMM_BAND")) : 0) : band_env;
+    // Tile order against the Infinity Cache (256 MiB, memory-side): a LayerNorm / attention pass writes its 310 MB output in ascending row order, so what is still
+    // cached when the consuming GEMM starts are its LAST rows — walking the tiles in descending order reads those first (and leaves the GEMM's own first-written, high
+    // rows to be evicted, its low rows fresh for the ascending pass behind it).  Same bits (tile order only); bench +0.4 % (profiles/r03_bench_rev.txt).  Default 2.
+    static const int rev_env = getenv("PCLIP_GEMM_REV") ? atoi(getenv("PCLIP_GEMM_REV")) : 2;
+    const int rev_mode = getenv("PCLIP_GEMM_CFG_LIVE") ? (getenv("PCLIP_GEMM_REV") ? atoi(getenv("PCLIP_GEMM_REV")) : 2) : rev_env;
+    // 1: every launch descending; 2: only the launches that read a LayerNorm / attention output (K <= 1024: in_proj, c_fc, out_proj), c_proj ascending behind the descending c_fc
+    const bool rev = rev_mode == 1 || (rev_mode == 2 && K <= 1024);
     linear_fast_kernel<C, HAS_BIAS, ACT, M16><<<grid, C::NTHREADS, LDS, s>>>(
         (const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi.bias, epi.scale, epi.shift, epi.C, epi.ldc, tiles_n, ntiles, epi.residual,
-        epi.rowstats, epi.partials, tiles_n >= 8 ? band : 0);
+        epi.rowstats, epi.partials, rev ? -1 : (tiles_n >= 8 ? band : 0));
     return pclip_check_launch("gemm_f16");
 }
 

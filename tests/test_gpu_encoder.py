@@ -84,6 +84,10 @@ def test_gemm_banded_tile_order_is_bit_identical(ops, monkeypatch):
         monkeypatch.setenv("PCLIP_GEMM_BAND", str(band))
         assert torch.equal(ops.gemm(a, w, b, act=1), ref), band
     monkeypatch.delenv("PCLIP_GEMM_BAND")
+    for rev in (0, 1, 2):                                   # PCLIP_GEMM_REV: tiles in descending order (default 2: launches with K <= 1024) — same bits
+        monkeypatch.setenv("PCLIP_GEMM_REV", str(rev))
+        assert torch.equal(ops.gemm(a, w, b, act=1), ref), rev
+    monkeypatch.delenv("PCLIP_GEMM_REV")
 
 
 def test_gemm_quickgelu_pipelined_epilogue_is_the_two_slab_epilogue(ops, monkeypatch):
