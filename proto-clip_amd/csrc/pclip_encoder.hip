@@ -858,11 +858,14 @@ __global__ __launch_bounds__(256) void layernorm_pf_kernel(const half_t* __restr
     // GB_LDS (the whole-batch pass of the towers): gamma / beta once per workgroup into LDS.  Per row they are 4 x the bytes of the row
     // itself through the vector-memory path (8 dwordx4 loads per lane against 2 for x); as ds_read_b128 they use the LDS pipe instead
     // (256 B/clk against 64): [201 728, 768] 129 -> 111 us, same bits (profiles/r03_ab_ln_lds.txt)
-    __shared__ __attribute__((aligned(16))) float gb_s[2][GB_LDS ? NCH * 512 : 4];
+    // (layout: the lane's eight values of a chunk as two 16-byte halves in two PLANES, [plane][chunk * 256 + lane * 4 ..]: a ds_read_b128 of the wave is 1 KB
+    // contiguous — with the eight values adjacent (32-byte lane stride) the PMC pass counted 22 % of the LDS cycles as bank conflicts)
+    __shared__ __attribute__((aligned(16))) float gb_s[2][2][GB_LDS ? NCH * 256 : 4];
     if (GB_LDS) {
         for (int i = threadIdx.x; i < NCH * 512; i += 256) {
-            gb_s[0][i] = i < D ? gamma[i] : 0.f;
-            gb_s[1][i] = i < D ? beta[i] : 0.f;
+            const int pos = (i >> 9) * 256 + ((i & 511) >> 3) * 4 + (i & 3), plane = (i >> 2) & 1;
+            gb_s[0][plane][pos] = i < D ? gamma[i] : 0.f;
+            gb_s[1][plane][pos] = i < D ? beta[i] : 0.f;
         }
         __syncthreads();
     }
@@ -903,7 +906,8 @@ __global__ __launch_bounds__(256) void layernorm_pf_kernel(const half_t* __restr
                 half8_t o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    float t = (v[c][j] - mean) * rstd * (GB_LDS ? gb_s[0][d + j] : gamma[d + j]) + (GB_LDS ? gb_s[1][d + j] : beta[d + j]);
+                    float t = (v[c][j] - mean) * rstd * (GB_LDS ? gb_s[0][j >> 2][c * 256 + lane * 4 + (j & 3)] : gamma[d + j]) +
+                              (GB_LDS ? gb_s[1][j >> 2][c * 256 + lane * 4 + (j & 3)] : beta[d + j]);
                     t = r16(t);
                     o[j] = (half_t)t;
                 }
