@@ -339,8 +339,9 @@ __global__ __launch_bounds__(C::NTHREADS, (C::NWAVES == 4 && C::BM * C::BN == 65
             }, tr);
         } else {
 #if PCLIP_SR
-        // residual epilogues: the tile of the residual stream is pulled into L2 from inside the K-loop (1024 lines = two 64-line touches per wave, by 4-byte LDS-DMA
-        // into a scrap area: no registers), so that the epilogue's residual chunks are L2 hits instead of two HBM round trips per tile
+        // (experiment, -DPCLIP_RES_PF=1, OFF: the residual epilogues pull their tile of the residual stream into L2 from inside the K-loop — 1024 lines = two 64-line
+        // touches per wave by 4-byte LDS-DMA into a scrap area, no registers — so that the epilogue's residual chunks would be L2 hits instead of two HBM round trips
+        // per tile; measured 4 - 8 % SLOWER: a 64-line touch costs the address path more than it saves)
         constexpr int PFN = (PCLIP_RES_PF && (ACT == 6 || ACT == 9) && C::BM == 256 && C::BN == 256 && C::NWAVES == 8) ? 2 : 0;
         auto touch = [&](int k) {
             const int line = (2 * wave + k) * 64 + lane, row = line >> 2, seg = line & 3;
