@@ -6,41 +6,12 @@
 #include <stdlib.h>
 #include <type_traits>
 
-#if PCLIP_TRACE
-__device__ unsigned long long g_pclip_trace[18];
-__device__ unsigned long long g_pclip_trace2[16];     // tile-level: [0..3] epilogue (slab barrier, staging writes, barrier, row-major reads + stores), [4] K-loop, [5] next-tile requests, [6] epilogue, [7] tiles; wave 7 at +8
-extern "C" int pclip_debug_trace2(unsigned long long* out, int reset) {
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pclip_trace2), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pclip_trace2), z, sizeof(z)) != hipSuccess) return 1; }
-    return 0;
-}
-extern "C" int pclip_debug_trace(unsigned long long* out, int reset) {
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pclip_trace), sizeof(unsigned long long) * 18) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[18] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pclip_trace), z, sizeof(z)) != hipSuccess) return 1; }
-    return 0;
-}
-#endif
 namespace {
-#ifndef PCLIP_SR
-#define PCLIP_SR 1               // K-loop with staggered refill of the buffer being consumed (pgemm::mainloop_sr); 0: mainloop_bl
-#endif
-#ifndef PCLIP_PP
-#define PCLIP_PP 0               // 1: 256 x 256 tiles take the ping-pong K-loop (pgemm::mainloop_pp) — bit-identical, measured 4 - 10 % slower than mainloop_sr (profiles/r03_ab_pingpong.txt)
-#endif
-#ifndef PCLIP_CFG_BIG4
-#define PCLIP_CFG_BIG4 0         // 1: also build the four-wave 256 x 256 configuration (Cfg<256,256,2,2>; PCLIP_GEMM_CFG=5 selects it)
-#endif
-#ifndef PCLIP_RES_PF
-#define PCLIP_RES_PF 0           // 1: residual epilogues touch their tile of the residual stream into L2 from inside the K-loop (pgemm::mainloop_sr PFN / touch) — out_proj 7.6 % / c_proj 4 % SLOWER (profiles/r03_ab_rejected.txt)
-#endif
 #ifndef PCLIP_EPI_PIPE
 #define PCLIP_EPI_PIPE 1         // 256 x 256 tiles: the LDS-staged epilogue as a four-slab pipeline (pgemm::epilogue_pipe)
 #endif
-#ifndef PCLIP_EPI_DIRECT
-#define PCLIP_EPI_DIRECT 0       // epilogue without LDS staging, K-tiles 0 and 1 of the next tile in flight meanwhile (256 x 256 tiles, bias / bias + QuickGELU): 1 = 8-byte stores from the accumulator layout (pgemm::epilogue_direct: in_proj 18 % / c_fc 4 % slower), 2 = column-permuted B tile + DPP / ds_bpermute transposition + 16-byte stores (pgemm::epilogue_lane: in_proj 2.4 % slower, c_fc as the pipelined staged form); all bit-identical (profiles/r03_ab_rejected.txt)
-#endif
-#ifndef PCLIP_PF
-#define PCLIP_PF false           // L2 prefetch two K-tiles ahead inside the persistent linear kernels: measured no gain, off
+#ifndef PCLIP_DRAIN
+#define PCLIP_DRAIN 0            // 256 x 256 tiles: the last K-tile block-major with the four-slab epilogue pipeline running under its MFMAs (pgemm::last_tile_drain)
 #endif
 
 using CfgBigT = pgemm::Cfg<256, 256, 2, 4>;
@@ -183,8 +154,8 @@ __device__ __forceinline__ void st_out(half_t* p, half8_t v) {
 // Every vector-memory operation of this kernel is an LDS-DMA or a store (the bias row of the tile also
 // travels by global_load_lds into a small double-buffered LDS strip), because hipcc answers any ordinary
 // VGPR load issued beside an LDS-DMA with a full vmcnt(0) drain at its use (guide §5, trap (b)).
-template <class C, bool HAS_BIAS, int ACT, bool M16 = false>
-__global__ __launch_bounds__(C::NTHREADS, (C::NWAVES == 4 && C::BM * C::BN == 65536) ? 1 : 2) void linear_fast_kernel(const half_t* __restrict__ A, int lda,
+template <class C, bool HAS_BIAS, int ACT>
+__global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_t* __restrict__ A, int lda,
                                                                      const half_t* __restrict__ B, int ldb, int M, int N,
                                                                      int K, const half_t* __restrict__ bias,
                                                                      const float* __restrict__ scale,
@@ -200,10 +171,7 @@ __global__ __launch_bounds__(C::NTHREADS, (C::NWAVES == 4 && C::BM * C::BN == 65
     // in the epilogue of out_proj / c_proj; Cout may BE residual (the residual stream is updated in place: every 16-byte chunk is
     // read and then written by the same thread)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-#if PCLIP_TRACE && defined(__HIP_DEVICE_COMPILE__)
-    unsigned long long t_entry;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry)::"memory");
-#endif
+    constexpr bool M16 = true;                                               // 16x16x32 MFMAs (accumulator layout of pgemm::mainloop_sr)
     half_t* bias_lds = reinterpret_cast<half_t*>(smem + C::LDS_BYTES);       // [2][BN] fp16
     float* affine_lds = reinterpret_cast<float*>(smem + C::LDS_BYTES);       // ACT >= 2: [2][ scale BN | shift BN ] fp32
     constexpr bool LNF = ACT == 7 || ACT == 8;                                // LayerNorm folded into this linear (ln_fold)
@@ -228,13 +196,9 @@ __global__ __launch_bounds__(C::NTHREADS, (C::NWAVES == 4 && C::BM * C::BN == 65
         tn = bnd * band + r - tm * w;
     };
     int p = 0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave % C::WN, hi = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave % C::WN;
     // M16: buffer-descriptor staging + pipelined K-loop; eight-wave tiles split the DMA issue by wave role (pgemm::TilePairR)
-    constexpr bool PP = PCLIP_PP && M16 && C::BM == 256 && C::BN == 256 && C::WM == 2 && C::WN == 4;
-    constexpr bool DIRECT = PCLIP_EPI_DIRECT && !PP && PCLIP_SR && PCLIP_DMA_ROLES && M16 && ACT <= 1 && C::BM == 256 && C::BN == 256 && C::WM == 2 && C::WN == 4;
-    constexpr bool LANE = DIRECT && PCLIP_EPI_DIRECT == 2;       // 16-byte stores from the column-permuted accumulator layout (pgemm::epilogue_lane)
-    using TPO = std::conditional_t<(PCLIP_DMA_ROLES && PCLIP_SR && C::NWAVES == 8), pgemm::TilePairR<C, LANE>, pgemm::TilePair<C>>;
-    using TP = std::conditional_t<PP, pgemm::TilePairP<std::conditional_t<PP, C, CfgBigT>>, TPO>;
+    using TP = std::conditional_t<(PCLIP_DMA_ROLES && C::NWAVES == 8), pgemm::TilePairR<C>, pgemm::TilePair<C>>;
     TP tp;
     // The bias enters as the INITIAL VALUE of the accumulators (fp32 copy of the fp16 bias: r16(bias + sum) instead of
     // r16(sum + bias), same value up to fp32 summation order), so the epilogue has no bias pass.  Its strip is copied one
@@ -275,24 +239,14 @@ __global__ __launch_bounds__(C::NTHREADS, (C::NWAVES == 4 && C::BM * C::BN == 65
     {
         int tm, tn;
         decomp(tile, tm, tn);
-        if constexpr (PP) {
-            tp.prepare(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, wave, lane);
-            tp.stage(0, 0, smem);
-            if (K > 32) tp.stage(1, 1, smem);
-        } else if constexpr (M16) {
-            tp.prepare(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, wave, lane);
-            tp.stage(0, smem + p * C::STAGE_BYTES, wave);
-            if (DIRECT && K > pgemm::BK) tp.stage(1, smem + (p ^ 1) * C::STAGE_BYTES, wave);
-        } else
-            pgemm::stage_first<C>(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, smem, p);
+        tp.prepare(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, wave, lane);
+        tp.stage(0, smem + p * C::STAGE_BYTES, wave);
     }
     constexpr int PST = ACT == 9 ? 1 : 0;                                     // act 9: one store of statistics partials per pass
-    // vector-memory operations a wave issues between a tile's K-tile 0 pieces and the first wait of its K-loop: the previous tile's stores + the
-    // strip copies (DIRECT: the TM * TN * 4 direct stores, and the wave's 8 pieces of K-tile 1 in front of them)
-    constexpr int YOUNGER = DIRECT ? (LANE ? C::TM * 4 : C::TM * C::TN * 4) + (HAS_BIAS ? 1 : 0) + 8 : C::NH * C::NPASS * (1 + PST) + (AFFINE ? 2 : (HAS_BIAS ? 1 : 0)) + NSTAT;
+    // vector-memory operations a wave issues between a tile's K-tile 0 pieces and the first wait of its K-loop: the previous tile's stores + the strip copies
+    constexpr int YOUNGER = C::NH * C::NPASS * (1 + PST) + (AFFINE ? 2 : (HAS_BIAS ? 1 : 0)) + NSTAT;
     bool prev_full = false;
     int parity = 0;
-    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, te[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (; tile < ntiles; tile += G, parity ^= 1) {
         int tile_m, tile_n;
         decomp(tile, tile_m, tile_n);
@@ -308,9 +262,8 @@ __global__ __launch_bounds__(C::NTHREADS, (C::NWAVES == 4 && C::BM * C::BN == 65
             for (int j = 0; j < C::TN; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int coff = M16 ? (g & 1) * 16 + 4 * (lane >> 4) : 8 * g + 4 * hi;      // columns of elements 4g .. 4g+3
-                    const half4_t b = LANE ? *reinterpret_cast<const half4_t*>(bl + 16 * (lane >> 4) + 4 * (2 * j + (g & 1)))   // column-permuted accumulators
-                                           : *reinterpret_cast<const half4_t*>(bl + j * 32 + coff);
+                    const int coff = (g & 1) * 16 + 4 * (lane >> 4);                               // columns of elements 4g .. 4g+3
+                    const half4_t b = *reinterpret_cast<const half4_t*>(bl + j * 32 + coff);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -325,52 +278,19 @@ __global__ __launch_bounds__(C::NTHREADS, (C::NWAVES == 4 && C::BM * C::BN == 65
         // 4-byte LDS-DMA per line — out_proj 301 -> 341 us, c_proj 854 -> 879 us: 1024 more requests per tile in the queue the operand
         // DMAs wait in.)
         const int next = tile + G;
-        PCLIP_STAMP(tt0);
-        if constexpr (PP) {
-            // the next tile's K-steps 0 and 1 are requested from inside the loop's last phase (group 0 before, group 1 behind its last barrier)
-            pgemm::mainloop_pp<C, YOUNGER, !HAS_BIAS>(tp, K / 32, smem, acc, p, prev_full, wave, lane, [&](int pair) {
-                if (next < ntiles) {
-                    int tm, tn;
-                    decomp(next, tm, tn);
-                    tp.prepare(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, wave, lane);
-                    tp.stage(0, 2 * pair, smem);
-                    if (K > 32) tp.stage(1, 2 * pair + 1, smem);
-                }
-            }, tr);
-        } else {
-#if PCLIP_SR
-        // (experiment, -DPCLIP_RES_PF=1, OFF: the residual epilogues pull their tile of the residual stream into L2 from inside the K-loop — 1024 lines = two 64-line
-        // touches per wave by 4-byte LDS-DMA into a scrap area, no registers — so that the epilogue's residual chunks would be L2 hits instead of two HBM round trips
-        // per tile; measured 4 - 8 % SLOWER: a 64-line touch costs the address path more than it saves)
-        constexpr int PFN = (PCLIP_RES_PF && (ACT == 6 || ACT == 9) && C::BM == 256 && C::BN == 256 && C::NWAVES == 8) ? 2 : 0;
-        auto touch = [&](int k) {
-            const int line = (2 * wave + k) * 64 + lane, row = line >> 2, seg = line & 3;
-            int gm = m0 + row;
-            gm = gm < M ? gm : M - 1;
-            __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(residual + (size_t)gm * ldc + n0 + seg * 64), (pgemm::lds_ptr_t)(smem + C::LDS_BYTES + STRIP_BYTES), 4, 0, 0);
-        };
-        if constexpr (M16) pgemm::mainloop_sr<C, YOUNGER, !HAS_BIAS, TP, DIRECT, LANE, PFN>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, tr, touch);
-#else
-        if constexpr (M16) pgemm::mainloop_bl<C, YOUNGER, !HAS_BIAS, PCLIP_PF>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane, smem + C::LDS_BYTES + STRIP_BYTES);
-#endif
-        else pgemm::mainloop<C, YOUNGER, !HAS_BIAS, M16>(A, lda, B, ldb, M, N, K, m0, n0, smem, acc, p, prev_full);
-        }
-        PCLIP_STAMP(tt1);
-        if (!PP && next < ntiles) {                           // buffer p is free: prefetch the next tile's K-tile 0
-            int tm, tn;
-            decomp(next, tm, tn);
-            if constexpr (PP) {
-            } else if constexpr (M16) {
+        constexpr bool BIGT = C::BM == 256 && C::BN == 256 && C::WM == 2 && C::WN == 4;
+        constexpr bool DRAIN = PCLIP_DRAIN && BIGT && !LNF;    // (the folded-LayerNorm epilogues keep 48 strip / statistics registers per lane: no room beside a K-tile's fragments)
+        const int nt = K / pgemm::BK;
+        pgemm::mainloop_sr<C, YOUNGER, !HAS_BIAS, TP>(tp, nt, smem, acc, p, prev_full, wave, lane, DRAIN ? nt - 1 : nt);
+        auto next_k0 = [&]() {                                // buffer p is free: prefetch the next tile's K-tile 0
+            if (next < ntiles) {
+                int tm, tn;
+                decomp(next, tm, tn);
                 tp.prepare(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, wave, lane);
                 tp.stage(0, smem + p * C::STAGE_BYTES, wave);
-                if constexpr (DIRECT) {
-                    pgemm::lds_barrier();                      // every wave holds its last fragments: the buffer of the last K-tile is free too
-                    if (K > pgemm::BK) tp.stage(1, smem + (p ^ 1) * C::STAGE_BYTES, wave);
-                }
-            } else
-                pgemm::stage_first<C>(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, smem, p);
-        }
-        PCLIP_STAMP(tt2);
+            }
+        };
+        if constexpr (!DRAIN) next_k0();
         char* stg = smem + (p ^ 1) * C::STAGE_BYTES;          // buffer of the last K-tile, reused after a barrier
         int etid = tid;                                       // opaque copy: the epilogue's lane constants are recomputed per tile (pgemm::epilogue_f16)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -384,12 +304,12 @@ __global__ __launch_bounds__(C::NTHREADS, (C::NWAVES == 4 && C::BM * C::BN == 65
         float4_t lcs[LNF ? C::TN : 1][2], lbf[LNF ? C::TN : 1][2];
         float2_t lms[LNF ? C::TM : 1][2];
         if (LNF) {
-            const int cq = M16 ? 4 * (lane >> 4) : 4 * hi, rq = M16 ? (lane & 15) : (lane & 31);
+            const int cq = 4 * (lane >> 4), rq = lane & 15;
 #pragma unroll
             for (int j = 0; j < C::TN; ++j)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    const float* st = affine_lds + parity * 2 * C::BN + wn * (C::BN / C::WN) + j * 32 + (M16 ? b * 16 : b * 8) + cq;
+                    const float* st = affine_lds + parity * 2 * C::BN + wn * (C::BN / C::WN) + j * 32 + b * 16 + cq;
                     lcs[j][b] = *reinterpret_cast<const float4_t*>(st);
                     lbf[j][b] = *reinterpret_cast<const float4_t*>(st + C::BN);
                 }
@@ -397,26 +317,14 @@ __global__ __launch_bounds__(C::NTHREADS, (C::NWAVES == 4 && C::BM * C::BN == 65
             for (int i = 0; i < C::TM; ++i)
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
-                    lms[i][a] = *reinterpret_cast<const float2_t*>(stats_lds + (parity * C::BM + (wave / C::WN) * (C::BM / C::WM) + i * 32 + (M16 ? a * 16 : 0) + rq) * 2);
+                    lms[i][a] = *reinterpret_cast<const float2_t*>(stats_lds + (parity * C::BM + (wave / C::WN) * (C::BM / C::WM) + i * 32 + a * 16 + rq) * 2);
         }
         auto pre = [&](int i, int j, int coff, float4_t v, int rl, int g) {
             if (ACT == 1) return quick_gelu16x4(v);
             half4_t h;
-            if (LNF && M16) {
+            if (LNF) {
                 const float4_t cs = lcs[j][g & 1], bf = lbf[j][g & 1];
                 const float2_t ms = lms[i][g >> 1];
-                float4_t y;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = ln_fold(v[e], ms[0], ms[1], cs[e], bf[e]);
-                if (ACT == 8) return quick_gelu16x4(y);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = (half_t)y[e];
-                return h;
-            }
-            if (LNF) {                                     // 32x32x16 fallback (PCLIP_GEMM_M16=0): columns 8g + 4hi, one row per lane
-                const float* st = affine_lds + parity * 2 * C::BN + wn * (C::BN / C::WN) + j * 32 + coff;
-                const float4_t cs = *reinterpret_cast<const float4_t*>(st), bf = *reinterpret_cast<const float4_t*>(st + C::BN);
-                const float2_t ms = lms[i][0];
                 float4_t y;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = ln_fold(v[e], ms[0], ms[1], cs[e], bf[e]);
@@ -447,7 +355,7 @@ __global__ __launch_bounds__(C::NTHREADS, (C::NWAVES == 4 && C::BM * C::BN == 65
         constexpr bool RES = ACT == 5 || ACT == 6 || ACT == 9;
         // (measured, profiles/r03_ab_epilogue_pipe.txt: c_fc + QuickGELU 1001 -> 972 us; the bias-only and residual epilogues do not profit — their phases
         // are bound by the LDS write rate / the stores' address path / the residual loads' latency one after the other either way — and keep epilogue_f16)
-        constexpr bool PIPE = PCLIP_EPI_PIPE && M16 && !DIRECT && (ACT == 1 || ACT == 8 || PCLIP_EPI_PIPE == 2) && C::BM == 256 && C::BN == 256 && C::WM == 2 && C::WN == 4;
+        constexpr bool PIPE = (PCLIP_EPI_PIPE && (ACT == 1 || ACT == 8 || PCLIP_EPI_PIPE == 2) && BIGT) || DRAIN;
         half8_t rr[RES ? C::NPASS : 1];
         // PIPE: slab k = 32-row block k of both wave rows, four passes of 16 rows; its residual chunks go to rr[(k & 1) * 4 + ps], requested one interval ahead
         auto ahead = [&](int k) {
@@ -485,20 +393,30 @@ __global__ __launch_bounds__(C::NTHREADS, (C::NWAVES == 4 && C::BM * C::BN == 65
             if (valid && (c & 7) == 0)
                 *reinterpret_cast<float2_t*>(partials + ((size_t)(m0 + r) * (N >> 6) + (n0 >> 6) + (c >> 3)) * 2) = float2_t{ps, pq};
         };
-        if constexpr (DIRECT) {
-#if (PCLIP_ABL & 4) && defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-            for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-                for (int j = 0; j < C::TN; ++j) asm volatile("" ::"v"(acc.v[i][j]));
-            prev_full = false;
-            continue;
-#endif
-            auto nofin = [](pgemm::uint4v_t x, int, int, int) { return x; };
-            if (LANE && full) pgemm::epilogue_lane<C>(acc, Cout, ldc, m0, n0, pre, nofin, [](int) { return true; });
-            else if (LANE) pgemm::epilogue_lane<C>(acc, Cout, ldc, m0, n0, pre, nofin, [&](int m) { return m < M; });
-            else if (full) pgemm::epilogue_direct<C>(acc, Cout, ldc, m0, n0, pre, [](int) { return true; });
-            else pgemm::epilogue_direct<C>(acc, Cout, ldc, m0, n0, pre, [&](int m) { return m < M; });
+        if constexpr (DRAIN) {
+            static_assert(C::NPASS == 8, "rr[pass % NPASS] pairs slab parity and pass");
+            // (DRAIN: mainloop_sr stopped in front of the last K-tile, which sits in buffer p; the staging area is buffer p ^ 1)
+            if (full) {
+                auto post = [&](int r, int c, int pass, half8_t h) {
+                    const size_t o = (size_t)(m0 + r) * ldc + col;
+                    if (RES) h = add_res(pass, h);
+                    st_out(Cout + o, h);
+                    if (ACT == 9) put_partials(r, c, h, true);
+                };
+                pgemm::drain_phases<C, YOUNGER>(smem, acc, p, nt == 1, prev_full, wave, lane, etid, ahead, pre, post);
+                next_k0();
+                pgemm::drain_tails<C>(smem, acc, p, etid, pre, post);
+            } else {
+                auto post = [&](int r, int c, int pass, half8_t h) {
+                    const size_t o = (size_t)(m0 + r) * ldc + col;
+                    if (RES) h = add_res(pass, h);
+                    if (m0 + r < M) st_out(Cout + o, h);
+                    if (ACT == 9) put_partials(r, c, h, m0 + r < M);
+                };
+                pgemm::drain_phases<C, YOUNGER>(smem, acc, p, nt == 1, prev_full, wave, lane, etid, ahead, pre, post);
+                next_k0();
+                pgemm::drain_tails<C>(smem, acc, p, etid, pre, post);
+            }
             prev_full = full;
             continue;
         }
@@ -519,26 +437,15 @@ __global__ __launch_bounds__(C::NTHREADS, (C::NWAVES == 4 && C::BM * C::BN == 65
                     if (ACT == 9) put_partials(r, c, h, m0 + r < M);
                 });
             prev_full = full;
-#if PCLIP_TRACE && defined(__HIP_DEVICE_COMPILE__)
-            { PCLIP_STAMP(tt3); te[4] += tt1 - tt0; te[5] += tt2 - tt1; te[6] += tt3 - tt2; te[7] += 1; }
-#endif
             continue;
         }
-#if (PCLIP_ABL & 4) && defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-        for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-            for (int j = 0; j < C::TN; ++j) asm volatile("" ::"v"(acc.v[i][j]));
-        if (false)
-#else
         if (full)
-#endif
             pgemm::epilogue_f16<C, M16>(acc, stg, slab, pre, [&](int r, int c, int pass, half8_t h) {
                 const size_t o = (size_t)(m0 + r) * ldc + col;
                 if (RES) h = add_res(pass, h);
                 st_out(Cout + o, h);
                 if (ACT == 9) put_partials(r, c, h, true);
-            }, te);
+            });
         else
             pgemm::epilogue_f16<C, M16>(acc, stg, slab, pre, [&](int r, int c, int pass, half8_t h) {
                 const size_t o = (size_t)(m0 + r) * ldc + col;
@@ -547,21 +454,7 @@ __global__ __launch_bounds__(C::NTHREADS, (C::NWAVES == 4 && C::BM * C::BN == 65
                 if (ACT == 9) put_partials(r, c, h, m0 + r < M);
             });
         prev_full = full;
-#if PCLIP_TRACE && defined(__HIP_DEVICE_COMPILE__)
-        { PCLIP_STAMP(tt3); te[4] += tt1 - tt0; te[5] += tt2 - tt1; te[6] += tt3 - tt2; te[7] += 1; }
-#endif
     }
-#if PCLIP_TRACE
-    if (lane == 0 && (wave == 0 || wave == 7))
-        for (int i = 0; i < 8; ++i) { atomicAdd(&g_pclip_trace[(wave ? 8 : 0) + i], tr[i]); atomicAdd(&g_pclip_trace2[(wave ? 8 : 0) + i], te[i]); }
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (tid == 0) {                                            // kernel span in s_memtime ticks: [16] = min entry stamp, [17] = max exit stamp
-        unsigned long long t_exit;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_exit)::"memory");
-        atomicMax(&g_pclip_trace[17], t_exit - t_entry);        // (the counters of different XCDs are not aligned: per-workgroup spans only)
-    }
-#endif
-#endif
 }
 
 // ---- 3x3 convolution (stride 1, pad 1, NHWC) + eval BatchNorm (+ReLU) as an implicit GEMM -----------------------------------
@@ -694,10 +587,24 @@ using CfgBig = pgemm::Cfg<256, 256, 2, 4>;
 using CfgWide = pgemm::Cfg<256, 128, 4, 2>;
 using CfgNarrow = pgemm::Cfg<256, 64, 4, 2>;          // 64-channel convolutions of the ResNet tower
 using CfgThin = pgemm::Cfg<256, 32, 4, 1>;            // its 32-channel stem (4 waves, two workgroups per CU)
-using CfgBig4 = pgemm::Cfg<256, 256, 2, 2>;           // the 256 x 256 tile on FOUR waves (one per SIMD, 128 x 128 each: 256 accumulator registers of the 512 a lone wave may use) — experiment, PCLIP_GEMM_CFG=5
 using CfgSmall = pgemm::CfgSmall;
 
-template <class C, bool HAS_BIAS, int ACT, bool M16 = false>
+// Tile-order switches (PCLIP_GEMM_BAND, PCLIP_GEMM_REV): read from the environment ONCE; only under PCLIP_GEMM_CFG_LIVE (the A/B tools flip
+// them between calls of one process) are they re-read per launch — no getenv on the product's launch path.
+struct TileOrder { int band, rev; };
+static TileOrder read_tile_order() {
+    const char* b = getenv("PCLIP_GEMM_BAND");
+    const char* r = getenv("PCLIP_GEMM_REV");
+    return TileOrder{b ? atoi(b) : 0, r ? atoi(r) : 2};
+}
+static const TileOrder& tile_order() {
+    static const bool live = getenv("PCLIP_GEMM_CFG_LIVE") != nullptr;
+    static TileOrder order = read_tile_order();
+    if (live) order = read_tile_order();
+    return order;
+}
+
+template <class C, bool HAS_BIAS, int ACT>
 static int launch_fast2(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const LinearEpi& epi,
                         int slots, hipStream_t s) {
     static DevOnce attr;
@@ -705,7 +612,7 @@ static int launch_fast2(const void* A, int lda, const void* B, int ldb, int M, i
     constexpr int LDS = C::LDS_BYTES + ((ACT == 2 || ACT == 3 || ACT == 5 || LNF) ? 2 * 2 * C::BN * 4 : 2 * C::BN * 2) + 256 +
                         (LNF ? 2 * C::BM * 8 : 0);   // K-tile ring + double-buffered bias / affine strips + prefetch scrap + (mean, rstd) rows
     if (!attr.done()) {
-        if (hipFuncSetAttribute((const void*)linear_fast_kernel<C, HAS_BIAS, ACT, M16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)linear_fast_kernel<C, HAS_BIAS, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS) != hipSuccess) {
             pclip_set_error("pclip_gemm_f16: cannot raise the dynamic LDS limit to %d", LDS);
             return PCLIP_E_LAUNCH;
@@ -714,48 +621,36 @@ static int launch_fast2(const void* A, int lda, const void* B, int ldb, int M, i
     }
     const int tiles_m = ceil_div(M, C::BM), tiles_n = N / C::BN, ntiles = tiles_m * tiles_n;
     const int grid = ntiles < slots ? ntiles : slots;
-    static const int band_env = getenv("PCLIP_GEMM_BAND") ? atoi(getenv("PCLIP_GEMM_BAND")) : 0;
-    const int band = getenv("PCLIP_GEMM_CFG_LIVE") ? (getenv("PCLIP_GEMM_BAND") ? atoi(getenv("PCLIP_GEMM_BAND")) : 0) : band_env;
+    const TileOrder& order = tile_order();
+    const int band = order.band;
     // Tile order against the Infinity Cache (256 MiB, memory-side): a LayerNorm / attention pass writes its 310 MB output in ascending row order, so what is still
     // cached when the consuming GEMM starts are its LAST rows — walking the tiles in descending order reads those first (and leaves the GEMM's own first-written, high
     // rows to be evicted, its low rows fresh for the ascending pass behind it).  Same bits (tile order only); bench +0.4 % (profiles/r03_bench_rev.txt).  Default 2.
-    static const int rev_env = getenv("PCLIP_GEMM_REV") ? atoi(getenv("PCLIP_GEMM_REV")) : 2;
-    const int rev_mode = getenv("PCLIP_GEMM_CFG_LIVE") ? (getenv("PCLIP_GEMM_REV") ? atoi(getenv("PCLIP_GEMM_REV")) : 2) : rev_env;
+    const int rev_mode = order.rev;
     // 1: every launch descending; 2: only the launches that read a LayerNorm / attention output (K <= 1024: in_proj, c_fc, out_proj), c_proj ascending behind the descending c_fc
     const bool rev = rev_mode == 1 || (rev_mode == 2 && K <= 1024);
-    linear_fast_kernel<C, HAS_BIAS, ACT, M16><<<grid, C::NTHREADS, LDS, s>>>(
+    linear_fast_kernel<C, HAS_BIAS, ACT><<<grid, C::NTHREADS, LDS, s>>>(
         (const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi.bias, epi.scale, epi.shift, epi.C, epi.ldc, tiles_n, ntiles, epi.residual,
         epi.rowstats, epi.partials, rev ? -1 : (tiles_n >= 8 ? band : 0));
     return pclip_check_launch("gemm_f16");
 }
 
-static bool g_m16 = true;                                     // PCLIP_GEMM_M16=0: fall back to 32x32x16 MFMAs (A/B switch)
-
-template <class C, bool M16>
-static int launch_fast_m(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const LinearEpi& epi,
-                         int slots, hipStream_t s) {
-    if (epi.act == 2) return launch_fast2<C, false, 2, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
-    if (epi.act == 3) return launch_fast2<C, false, 3, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
-    if (epi.act == 5) return launch_fast2<C, false, 5, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
-    if (epi.act == 6) return launch_fast2<C, true, 6, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
-    if (epi.act == 9) return launch_fast2<C, true, 9, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
-    if (epi.act == 7) return launch_fast2<C, false, 7, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
-    if (epi.act == 8) return launch_fast2<C, false, 8, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
-    if (epi.bias) {
-        if (epi.act == 1) return launch_fast2<C, true, 1, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
-        return launch_fast2<C, true, 0, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
-    }
-    if (epi.act == 1) return launch_fast2<C, false, 1, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
-    return launch_fast2<C, false, 0, M16>(A, lda, B, ldb, M, N, K, epi, slots, s);
-}
-
-// 16x16x32 MFMAs by default: same FLOPs per cycle as 32x32x16 but a quarter of the accumulator-register traffic per FLOP, and
-// the kernel sits at the socket power cap — 8192^3: 1060 -> 1165 TFLOP/s, bench 46.5 -> 45.8 ms/step (same-box A/B).
 template <class C>
 static int launch_fast(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const LinearEpi& epi,
                        int slots, hipStream_t s) {
-    return g_m16 ? launch_fast_m<C, true>(A, lda, B, ldb, M, N, K, epi, slots, s)
-                 : launch_fast_m<C, false>(A, lda, B, ldb, M, N, K, epi, slots, s);
+    if (epi.act == 2) return launch_fast2<C, false, 2>(A, lda, B, ldb, M, N, K, epi, slots, s);
+    if (epi.act == 3) return launch_fast2<C, false, 3>(A, lda, B, ldb, M, N, K, epi, slots, s);
+    if (epi.act == 5) return launch_fast2<C, false, 5>(A, lda, B, ldb, M, N, K, epi, slots, s);
+    if (epi.act == 6) return launch_fast2<C, true, 6>(A, lda, B, ldb, M, N, K, epi, slots, s);
+    if (epi.act == 9) return launch_fast2<C, true, 9>(A, lda, B, ldb, M, N, K, epi, slots, s);
+    if (epi.act == 7) return launch_fast2<C, false, 7>(A, lda, B, ldb, M, N, K, epi, slots, s);
+    if (epi.act == 8) return launch_fast2<C, false, 8>(A, lda, B, ldb, M, N, K, epi, slots, s);
+    if (epi.bias) {
+        if (epi.act == 1) return launch_fast2<C, true, 1>(A, lda, B, ldb, M, N, K, epi, slots, s);
+        return launch_fast2<C, true, 0>(A, lda, B, ldb, M, N, K, epi, slots, s);
+    }
+    if (epi.act == 1) return launch_fast2<C, false, 1>(A, lda, B, ldb, M, N, K, epi, slots, s);
+    return launch_fast2<C, false, 0>(A, lda, B, ldb, M, N, K, epi, slots, s);
 }
 
 // ---- LayerNorm, one wave per row ----------------------------------------------------------------
@@ -1750,8 +1645,8 @@ extern "C" long pclip_gemm_kernel_launches(void) { return g_gemm_launches; }
 
 namespace {
 struct TileCfg { int bm, bn, wg_per_cu; double eff; };
-constexpr int kNumCfgs = 5;                  // configurations the cost model chooses from; index 5 (CfgBig4) only by PCLIP_GEMM_CFG=5
-constexpr TileCfg kTileCfgs[kNumCfgs + 1] = {{128, 128, 2, 0.85}, {256, 128, 1, 0.85}, {256, 256, 1, 1.0}, {256, 64, 1, 0.6}, {256, 32, 2, 0.4}, {256, 256, 1, 1.0}};
+constexpr int kNumCfgs = 5;                  // configurations the cost model chooses from
+constexpr TileCfg kTileCfgs[kNumCfgs] = {{128, 128, 2, 0.85}, {256, 128, 1, 0.85}, {256, 256, 1, 1.0}, {256, 64, 1, 0.6}, {256, 32, 2, 0.4}};
 constexpr double kLaunchCost = 0.5;          // extra launch of a split, in the same units
 
 thread_local int g_min_bn = 0;               // act 9 (statistics partials per 64 columns): tiles narrower than 64 columns are excluded
@@ -1794,7 +1689,7 @@ int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int
     if (epi.act >= 7 && pick < 0) { pclip_set_error("pclip_gemm_ln_f16: N=%d / alignment not supported by the fused epilogue", N); return PCLIP_E_INVALID; }
     if (forced >= 0) {
         may_split = false;
-        if (aligned && forced <= kNumCfgs && N % kTileCfgs[forced].bn == 0) pick = forced;
+        if (aligned && forced < kNumCfgs && N % kTileCfgs[forced].bn == 0) pick = forced;
     }
     if (pick >= 0 && may_split) {
         long split_rows = 0;                                   // rows given to the full rounds of configuration split_cfg
@@ -1828,9 +1723,6 @@ int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int
     if (pick == 0) return launch_fast<CfgSmall>(A, lda, B, ldb, M, N, K, epi, 2 * cus, s);
     if (pick == 3) return launch_fast<CfgNarrow>(A, lda, B, ldb, M, N, K, epi, cus, s);
     if (pick == 4) return launch_fast<CfgThin>(A, lda, B, ldb, M, N, K, epi, 2 * cus, s);
-#if PCLIP_CFG_BIG4
-    if (pick == 5) return launch_fast<CfgBig4>(A, lda, B, ldb, M, N, K, epi, cus, s);
-#endif
     const int tiles_m = ceil_div(M, 128), tiles_n = ceil_div(N, 128);
     linear_generic_kernel<<<tiles_m * tiles_n, 256, CfgSmall::LDS_BYTES, s>>>(A, lda, B, ldb, M, N, K, epi, tiles_n);
     return pclip_check_launch("gemm_f16 (generic)");
@@ -1857,10 +1749,9 @@ extern "C" int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, vo
         forced = f ? atoi(f) : -1;
         if (forced == 3) forced = -2;                       // generic kernel
         else if (forced == 4) forced = 3;                   // index of the 256x64 configuration
-        else if (forced == 5 && !PCLIP_CFG_BIG4) forced = -1;
+        else if (forced >= 5) forced = -1;
         live = getenv("PCLIP_GEMM_CFG_LIVE") != nullptr;   // tools/ab_cfg.py: re-read the overrides on every call
         nosplit = getenv("PCLIP_GEMM_NOSPLIT") != nullptr;
-        g_m16 = !(getenv("PCLIP_GEMM_M16") != nullptr && getenv("PCLIP_GEMM_M16")[0] == '0');
     }
     return gemm_dispatch((const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, cus, forced, !nosplit, (hipStream_t)stream);
 }
