@@ -740,6 +740,9 @@ __device__ __forceinline__ void epilogue_pipe(const Acc<C>& acc, char* stg, cons
 // with one LDS-only barrier between phases (slabs alternate between the two 32 KB halves of the staging buffer exactly as in epilogue_pipe).  What is left
 // of the epilogue outside the K-loop are the two tails.  `first`: the tile has ONE K-tile (this is also iteration 0: counted wait as in mainloop_sr).
 // ahead / pre / post as in epilogue_pipe; ahead(k) is called two phases before slab k is stored.  p (the K-tile's buffer = the next tile's K-tile 0) is unchanged.
+#ifndef PCLIP_DRAIN_ABL
+#define PCLIP_DRAIN_ABL 0
+#endif
 template <int V> struct IC { static constexpr int value = V; };      // compile-time block / slab index (a run-time index into the accumulators would send them to scratch)
 template <class C>
 struct Drain {
@@ -760,7 +763,11 @@ struct Drain {
                 const float4_t v = {acc.v[K][j][4 * g], acc.v[K][j][4 * g + 1], acc.v[K][j][4 * g + 2], acc.v[K][j][4 * g + 3]};
                 const half4_t hv = pre(K, j, coff, v, rl, g);
                 const int unit = (nl >> 2) ^ (ml & SWZ);
+#if (PCLIP_DRAIN_ABL & 2) && defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" ::"v"(hv), "v"(unit));
+#else
                 *reinterpret_cast<half4_t*>(buf + ml * RB + unit * 8) = hv;
+#endif
             }
     }
     template <int K, class Post>
@@ -771,7 +778,12 @@ struct Drain {
         for (int ps = 0; ps < NP4; ++ps) {
             const int r = tid / C::CPR + ps * RPP;
             const int pair = c ^ ((r & SWZ) >> 1);
+#if (PCLIP_DRAIN_ABL & 2) && defined(__HIP_DEVICE_COMPILE__)
+            half8_t hv;
+            asm volatile("; fake read %0 %1" : "=v"(hv) : "v"(pair));
+#else
             half8_t hv = *reinterpret_cast<const half8_t*>(buf + r * RB + pair * 16);
+#endif
             if (r & 1) hv = half8_t{hv[4], hv[5], hv[6], hv[7], hv[0], hv[1], hv[2], hv[3]};
             post((r >> 5) * (C::BM / C::WM) + K * 32 + (r & 31), c, K * NP4 + ps, hv);
         }
@@ -815,7 +827,11 @@ __device__ __forceinline__ void drain_phases(char* smem, Acc<C>& acc, int p, boo
                     for (int b = 0; b < 2; ++b) {
                         float16_t& dst = acc.v[i][j];
                         float4_t c = {dst[(a * 2 + b) * 4], dst[(a * 2 + b) * 4 + 1], dst[(a * 2 + b) * 4 + 2], dst[(a * 2 + b) * 4 + 3]};
+#if (PCLIP_DRAIN_ABL & 4) && defined(__HIP_DEVICE_COMPILE__)
+                        asm volatile("" : "+v"(c) : "v"(bf[ks][j][b]), "v"(af[ks][a]));
+#else
                         c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][j][b], af[ks][a], c, 0, 0, 0);
+#endif
 #pragma unroll
                         for (int r = 0; r < 4; ++r) dst[(a * 2 + b) * 4 + r] = c[r];
                     }
