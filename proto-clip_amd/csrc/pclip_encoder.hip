@@ -10,19 +10,6 @@ namespace {
 #ifndef PCLIP_EPI_PIPE
 #define PCLIP_EPI_PIPE 1         // 256 x 256 tiles: the LDS-staged epilogue as a four-slab pipeline (pgemm::epilogue_pipe)
 #endif
-#ifndef PCLIP_EXP_STL2
-#define PCLIP_EXP_STL2 0
-#endif
-#ifndef PCLIP_EXP_STAGGER
-#define PCLIP_EXP_STAGGER 0
-#endif
-#ifndef PCLIP_EXP_STAGGER_MODE
-#define PCLIP_EXP_STAGGER_MODE 0
-#endif
-#ifndef PCLIP_DRAIN
-#define PCLIP_DRAIN 0            // 256 x 256 tiles: the last K-tile block-major with the four-slab epilogue pipeline running under its MFMAs (pgemm::last_tile_drain)
-#endif
-
 using CfgBigT = pgemm::Cfg<256, 256, 2, 4>;
 // ---- nn.Linear on MFMA ------------------------------------------------------------------------
 // Rounding points follow the reference's fp16 tensors: r16(acc + bias); QuickGELU as three fp16
@@ -154,40 +141,6 @@ __device__ __forceinline__ void st_out(half_t* p, half8_t v) {
 #endif
 }
 
-// Rows of an output (or residual) tile through ONE buffer descriptor per tile: base = the tile's first element, num_records = the bytes from there to the
-// end of row M - 1.  A 16-byte access to a row beyond M then fails the hardware bounds check — the store is dropped, the load answered with zeros — so full
-// and partial tiles run ONE branch-free code path (every store an instruction of the same straight-line block the MFMAs are scheduled in) and issue the same
-// number of vector-memory operations (the counted waits hold for both).  Per-lane state: a 32-bit byte offset.
-typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
-struct TileRows {
-    pgemm::rsrc_t rs;
-    __device__ __forceinline__ void prepare(const half_t* base, int ld, int m0, int n0, int M) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        const uint64_t addr = (uint64_t)(base + (size_t)m0 * ld + n0);
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)addr), hi = __builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
-        const long left = ((long)(M - m0) * ld - n0) * 2;              // (a tile spans at most 256 rows: its offsets stay far below the 2 GiB clip)
-        const uint32_t size = __builtin_amdgcn_readfirstlane((uint32_t)(left < 0x7fffffffL ? left : 0x7fffffffL));
-        rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, size, 0x00020000);
-#endif
-    }
-    __device__ __forceinline__ half8_t load(int byte_off) const {
-#if defined(__HIP_DEVICE_COMPILE__)
-        return __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
-#else
-        return half8_t{};
-#endif
-    }
-    __device__ __forceinline__ void store_nt(int byte_off, half8_t v) const {
-#if defined(__HIP_DEVICE_COMPILE__)
-#if PCLIP_DRAIN_ABL & 1
-        asm volatile("" ::"v"(v), "v"(byte_off));
-#else
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v), rs, byte_off, 0, PCLIP_NT_STORE ? 2 : 0);
-#endif
-#endif
-    }
-};
-
 // ---- fast kernel: N % BN == 0, 16-byte aligned C rows, no residual -----------------------------------------
 // Persistent: one launch = at most `slots` resident workgroups; each walks output tiles round by round
 // (round r covers tiles [r*G, (r+1)*G), XCD-remapped inside the round so that one XCD's L2 sees
@@ -225,18 +178,6 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     const int G = gridDim.x;
     int tile = pgemm::xcd_remap(blockIdx.x, G);
     if (tile >= ntiles) return;
-#if PCLIP_EXP_STAGGER && defined(__HIP_DEVICE_COMPILE__)
-    if (C::BM == 256 && C::BN == 256) {                          // EXPERIMENT: start the workgroups of XCD x (or of CU group x) PCLIP_EXP_STAGGER * x cycles late
-        const unsigned steps = PCLIP_EXP_STAGGER_MODE == 0 ? (blockIdx.x & 7) : PCLIP_EXP_STAGGER_MODE == 1 ? ((blockIdx.x >> 3) & 7) : (blockIdx.x & 7) ^ ((blockIdx.x >> 3) & 7);
-        const unsigned long long want = (unsigned long long)steps * PCLIP_EXP_STAGGER;
-        unsigned long long t0, t1;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
-        do {
-            __builtin_amdgcn_s_sleep(32);
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
-        } while (t1 - t0 < want);
-    }
-#endif
     // Linear tile id -> (row block, column tile).  band == 0: column tiles fastest (a round covers whole rows of tiles).  band > 0
     // (PCLIP_GEMM_BAND, tools/ab_band.py): the output is walked in BANDS of `band` column tiles, row blocks fastest inside a band, so
     // that for half of the launch every XCD multiplies against the same `band` weight panels (N = 3072, band 6: 2.4 MB of the 4 MiB L2
@@ -333,21 +274,13 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         // 4-byte LDS-DMA per line — out_proj 301 -> 341 us, c_proj 854 -> 879 us: 1024 more requests per tile in the queue the operand
         // DMAs wait in.)
         const int next = tile + G;
-        constexpr bool BIGT = C::BM == 256 && C::BN == 256 && C::WM == 2 && C::WN == 4;
-        constexpr bool DRAIN = PCLIP_DRAIN && BIGT && !LNF;    // (the folded-LayerNorm epilogues keep 48 strip / statistics registers per lane: no room beside a K-tile's fragments)
-        const int nt = K / pgemm::BK;
-        pgemm::mainloop_sr<C, YOUNGER, !HAS_BIAS, TP>(tp, nt, smem, acc, p, prev_full, wave, lane, DRAIN ? nt - 1 : nt);
-        // The next tile's K-tile 0 goes into buffer p as soon as that is free: right here without the drain, behind the last MFMA phase with it.  The
-        // descriptor / offsets are prepared HERE in both cases, at a workgroup-uniform point: prepared inside the `full` / partial branches of the drain, the
-        // descriptor reaches the K-loop through phi nodes behind divergent (predicated-store) control flow, hipcc keeps it in VGPRs and wraps every LDS-DMA
-        // of the K-loop in a waterfall loop.
-        if (next < ntiles) {
+        pgemm::mainloop_sr<C, YOUNGER, !HAS_BIAS, TP>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane);
+        if (next < ntiles) {                                  // buffer p is free: prefetch the next tile's K-tile 0
             int tm, tn;
             decomp(next, tm, tn);
             tp.prepare(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, wave, lane);
-            if constexpr (!DRAIN) tp.stage(0, smem + p * C::STAGE_BYTES, wave);
+            tp.stage(0, smem + p * C::STAGE_BYTES, wave);
         }
-
         char* stg = smem + (p ^ 1) * C::STAGE_BYTES;          // buffer of the last K-tile, reused after a barrier
         int etid = tid;                                       // opaque copy: the epilogue's lane constants are recomputed per tile (pgemm::epilogue_f16)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -412,7 +345,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         constexpr bool RES = ACT == 5 || ACT == 6 || ACT == 9;
         // (measured, profiles/r03_ab_epilogue_pipe.txt: c_fc + QuickGELU 1001 -> 972 us; the bias-only and residual epilogues do not profit — their phases
         // are bound by the LDS write rate / the stores' address path / the residual loads' latency one after the other either way — and keep epilogue_f16)
-        constexpr bool PIPE = (PCLIP_EPI_PIPE && (ACT == 1 || ACT == 8 || PCLIP_EPI_PIPE == 2) && BIGT) || DRAIN;
+        constexpr bool PIPE = PCLIP_EPI_PIPE && (ACT == 1 || ACT == 8 || PCLIP_EPI_PIPE == 2) && C::BM == 256 && C::BN == 256 && C::WM == 2 && C::WN == 4;
         half8_t rr[RES ? C::NPASS : 1];
         // PIPE: slab k = 32-row block k of both wave rows, four passes of 16 rows; its residual chunks go to rr[(k & 1) * 4 + ps], requested one interval ahead
         auto ahead = [&](int k) {
@@ -450,46 +383,6 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             if (valid && (c & 7) == 0)
                 *reinterpret_cast<float2_t*>(partials + ((size_t)(m0 + r) * (N >> 6) + (n0 >> 6) + (c >> 3)) * 2) = float2_t{ps, pq};
         };
-        if constexpr (DRAIN) {
-            // mainloop_sr stopped in front of the last K-tile, which sits in buffer p; the staging area is buffer p ^ 1
-            static_assert(C::NPASS == 8, "rr[pass % NPASS] pairs slab parity and pass");
-            TileRows out, res;
-#if PCLIP_EXP_STL2
-            out.prepare(Cout, ldc, 0, n0, M);                      // EXPERIMENT: every row block stores to rows 0 .. 255 (L2-resident)
-#else
-            out.prepare(Cout, ldc, m0, n0, M);
-#endif
-            if (RES) res.prepare(residual, ldc, m0, n0, M);
-            const int row_off = (etid / C::CPR) * ldc * 2 + (etid % C::CPR) * 16;       // bytes from the tile's first element to this thread's chunk in row etid / CPR
-            auto ahead_d = [&](int k) {
-                if (!RES) return;
-#pragma unroll
-                for (int ps = 0; ps < 4; ++ps) {
-                    const int rs_ = etid / C::CPR + ps * 16, dr = (rs_ >> 5) * 128 + k * 32 + (rs_ & 31) - etid / C::CPR;   // compile-time after unrolling: ps * 16 and k * 32 (+ 96 for the second wave row)
-                    rr[RES ? (k & 1) * 4 + ps : 0] = res.load(row_off + dr * ldc * 2);
-                }
-            };
-            auto post = [&](int r, int c, int pass, half8_t h) {
-                if (RES) h = add_res(pass, h);
-                out.store_nt(row_off + (r - etid / C::CPR) * ldc * 2, h);
-                if (ACT == 9) put_partials(r, c, h, m0 + r < M);
-            };
-            pgemm::drain_phases<C, YOUNGER>(smem, acc, p, nt == 1, prev_full, wave, lane, etid, ahead_d, pre, post);
-            if (next < ntiles) tp.stage(0, smem + p * C::STAGE_BYTES, wave);
-            pgemm::drain_tails<C>(smem, acc, p, etid, pre, post);
-            prev_full = ACT != 9 || full;                         // every tile issues the same vector-memory operations (act 9: the partials' stores are predicated)
-            continue;
-        }
-#if (PCLIP_DRAIN_ABL & 8) && defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (BIGT) {
-#pragma unroll
-            for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-                for (int j = 0; j < C::TN; ++j) asm volatile("" ::"v"(acc.v[i][j]));
-            prev_full = false;
-            continue;
-        }
-#endif
         if constexpr (PIPE) {
             static_assert(C::NPASS == 8, "rr[pass % NPASS] pairs slab parity and pass");
             if (full)

@@ -364,14 +364,12 @@ struct TilePairR {
 #define PCLIP_IGLP 1             // __builtin_amdgcn_iglp_opt strategy of the K-loop's first scheduling region (-1: none; 0 / 2 / 3 measured: no gain)
 #endif
 // K-loop over a tile whose K-tile 0 is already on its way into buffer `p` (TP::stage(0, ..)); semantics of `p`, YOUNGER, counted_first as
-// mainloop_g.  `wave` must be wave-uniform (readfirstlane).  Iterations [0, nt_run) of the tile's nt K-tiles are run: a caller that
-// finishes the last K-tile itself (pgemm::last_tile_drain) passes nt_run = nt - 1.
+// mainloop_g.  `wave` must be wave-uniform (readfirstlane).
 template <class C, int YOUNGER = 0, bool ZERO_ACC = true, class TP = TilePair<C>>
-__device__ __forceinline__ void mainloop_sr(const TP& tp, int nt, char* smem, Acc<C>& acc, int& p, bool counted_first, int wave, int lane, int nt_run = -1) {
+__device__ __forceinline__ void mainloop_sr(const TP& tp, int nt, char* smem, Acc<C>& acc, int& p, bool counted_first, int wave, int lane) {
     static_assert(C::TM >= 2 && C::TM % 2 == 0, "group pipeline splits the wave's A rows in two halves");
     constexpr int HM = C::TM / 2;
     constexpr int NA = TP::NA, NB = TP::NB;
-    if (nt_run < 0) nt_run = nt;
     // requests of ONE K-tile this wave leaves in flight across the top barrier: every wave NA + NB pieces (TilePair), or the pieces
     // of its own operand (TilePairR)
     auto wait_ahead = [&]() {
@@ -394,7 +392,7 @@ __device__ __forceinline__ void mainloop_sr(const TP& tp, int nt, char* smem, Ac
     // (s_setprio measured on this loop, tools/ab_multi.py gemm, profiles/r03_ab_gemm_prio.txt: priority 1 around every MFMA group
     // is neutral at N = 3072 and 5 - 32 % SLOWER at N = 768 / 2304; a static priority for the younger half of the waves is +-0.5 %.)
 
-    for (int t = 0; t < nt_run; ++t) {
+    for (int t = 0; t < nt; ++t) {
         if (t == 0) { if (counted_first) wait_vm<YOUNGER>(); else wait_vm<0>(); }
         else if (t + 1 < nt) wait_ahead();
         else wait_vm<0>();
@@ -724,148 +722,6 @@ __device__ __forceinline__ void epilogue_pipe(const Acc<C>& acc, char* stg, cons
         }
         if (k + 1 < 4 && !stage_first) stage(k + 1);
     }
-}
-
-// ---- rolling drain: the LAST K-tile of an output tile fused with the four-slab epilogue pipeline ---------------------------------------
-// epilogue_pipe starts when the K-loop has ended: staging writes, barriers and 128 one-kilobyte stores per tile run with the matrix pipe idle — 15 % of
-// a K = 768 tile with a bias, 25 - 30 % with QuickGELU or a residual.  Here the last K-tile is multiplied BLOCK-major: phase i issues the
-// 16 MFMAs of 32-row block i (k-step 0, then 1: the order every accumulator sees in mainloop_sr — same bits), so block i is final when phase i ends, and
-// the OTHER stage buffer (K-tile nt - 2, consumed) is the staging area from the first barrier on:
-//   phase 0: MFMA 0
-//   phase 1: MFMA 1 | convert / activate / stage slab 0
-//   phase 2: MFMA 2 | stage slab 1 | read slab 0 row-major + store
-//   phase 3: MFMA 3 | stage slab 2 | store slab 1                    (drain_phases; the caller then requests the next tile's K-tile 0 into the K-tile's buffer)
-//   tail  4:          stage slab 3 | store slab 2
-//   tail  5:                         store slab 3                    (drain_tails)
-// with one LDS-only barrier between phases (slabs alternate between the two 32 KB halves of the staging buffer exactly as in epilogue_pipe).  What is left
-// of the epilogue outside the K-loop are the two tails.  `first`: the tile has ONE K-tile (this is also iteration 0: counted wait as in mainloop_sr).
-// ahead / pre / post as in epilogue_pipe; ahead(k) is called two phases before slab k is stored.  p (the K-tile's buffer = the next tile's K-tile 0) is unchanged.
-#ifndef PCLIP_DRAIN_ABL
-#define PCLIP_DRAIN_ABL 0
-#endif
-template <int V> struct IC { static constexpr int value = V; };      // compile-time block / slab index (a run-time index into the accumulators would send them to scratch)
-template <class C>
-struct Drain {
-    static_assert(C::TM == 4 && C::BM == 256 && C::BN % 64 == 0 && C::NWAVES == 8, "four 32-row blocks per wave, eight waves");
-    static constexpr int RB = C::BN * 2, SLAB = 64 * RB, SWZ = 15, SR = 32 * C::WM;
-    static_assert(2 * SR * RB <= C::STAGE_BYTES, "two slabs must fit one stage buffer");
-    static constexpr int RPP = C::NTHREADS / C::CPR, NP4 = SR / RPP;
-    template <int K, class Pre>
-    static __device__ __forceinline__ void stage(const Acc<C>& acc, char* stg, int tid, const Pre& pre) {
-        const int elane = tid & 63, wave = tid >> 6, wm = wave / C::WN, wn = wave % C::WN;
-        char* buf = stg + (K & 1) * SLAB;
-#pragma unroll
-        for (int j = 0; j < C::TN; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int rl = (g >> 1) * 16 + (elane & 15), coff = (g & 1) * 16 + 4 * (elane >> 4);
-                const int ml = wm * 32 + rl, nl = wn * (C::BN / C::WN) + j * 32 + coff;
-                const float4_t v = {acc.v[K][j][4 * g], acc.v[K][j][4 * g + 1], acc.v[K][j][4 * g + 2], acc.v[K][j][4 * g + 3]};
-                const half4_t hv = pre(K, j, coff, v, rl, g);
-                const int unit = (nl >> 2) ^ (ml & SWZ);
-#if (PCLIP_DRAIN_ABL & 2) && defined(__HIP_DEVICE_COMPILE__)
-                asm volatile("" ::"v"(hv), "v"(unit));
-#else
-                *reinterpret_cast<half4_t*>(buf + ml * RB + unit * 8) = hv;
-#endif
-            }
-    }
-    template <int K, class Post>
-    static __device__ __forceinline__ void store(const char* stg, int tid, const Post& post) {
-        const char* buf = stg + (K & 1) * SLAB;
-        const int c = tid % C::CPR;
-#pragma unroll
-        for (int ps = 0; ps < NP4; ++ps) {
-            const int r = tid / C::CPR + ps * RPP;
-            const int pair = c ^ ((r & SWZ) >> 1);
-#if (PCLIP_DRAIN_ABL & 2) && defined(__HIP_DEVICE_COMPILE__)
-            half8_t hv;
-            asm volatile("; fake read %0 %1" : "=v"(hv) : "v"(pair));
-#else
-            half8_t hv = *reinterpret_cast<const half8_t*>(buf + r * RB + pair * 16);
-#endif
-            if (r & 1) hv = half8_t{hv[4], hv[5], hv[6], hv[7], hv[0], hv[1], hv[2], hv[3]};
-            post((r >> 5) * (C::BM / C::WM) + K * 32 + (r & 31), c, K * NP4 + ps, hv);
-        }
-    }
-};
-template <class C, int YOUNGER, class Ahead, class Pre, class Post>
-__device__ __forceinline__ void drain_phases(char* smem, Acc<C>& acc, int p, bool first, bool counted_first, int wave, int lane, int etid,
-                                             const Ahead& ahead, const Pre& pre, const Post& post) {
-    using D = Drain<C>;
-    if (first && counted_first) wait_vm<YOUNGER>(); else wait_vm<0>();
-    lds_barrier();                                                     // K-tile nt - 1 is visible; every wave is past K-tile nt - 2: the other buffer is free
-    const char* cur = smem + p * C::STAGE_BYTES;
-    char* stg = smem + (p ^ 1) * C::STAGE_BYTES;
-    const int wm = wave / C::WN, wn = wave % C::WN;
-    const int key = (lane & 15) >> 1, q = lane >> 4;
-    const int col0 = (q ^ key) << 4;
-    const int offa = (wm * (C::BM / C::WM) + (lane & 15)) * ROW_BYTES + col0;
-    const int offb = C::A_BYTES + (wn * (C::BN / C::WN) + (lane & 15)) * ROW_BYTES + col0;
-    half8_t bf[2][C::TN][2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int j = 0; j < C::TN; ++j)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) bf[ks][j][b] = *reinterpret_cast<const half8_t*>(cur + (offb ^ (ks << 6)) + (j * 32 + b * 16) * ROW_BYTES);
-    auto load_a = [&](half8_t (&af)[2][2], int i) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int a = 0; a < 2; ++a) af[ks][a] = *reinterpret_cast<const half8_t*>(cur + (offa ^ (ks << 6)) + (i * 32 + a * 16) * ROW_BYTES);
-    };
-    auto mfma_block = [&](auto I, const half8_t (&af)[2][2]) {
-        constexpr int i = decltype(I)::value;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int j = 0; j < C::TN; ++j)
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        float16_t& dst = acc.v[i][j];
-                        float4_t c = {dst[(a * 2 + b) * 4], dst[(a * 2 + b) * 4 + 1], dst[(a * 2 + b) * 4 + 2], dst[(a * 2 + b) * 4 + 3]};
-#if (PCLIP_DRAIN_ABL & 4) && defined(__HIP_DEVICE_COMPILE__)
-                        asm volatile("" : "+v"(c) : "v"(bf[ks][j][b]), "v"(af[ks][a]));
-#else
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][j][b], af[ks][a], c, 0, 0, 0);
-#endif
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) dst[(a * 2 + b) * 4 + r] = c[r];
-                    }
-    };
-    half8_t a0[2][2], a1[2][2];
-    load_a(a0, 0);
-    load_a(a1, 1);
-    ahead(0);
-    mfma_block(IC<0>(), a0);
-    load_a(a0, 2);
-    ahead(1);
-    mfma_block(IC<1>(), a1);
-    D::template stage<0>(acc, stg, etid, pre);
-    lds_barrier();                                                     // slab 0 staged
-    load_a(a1, 3);
-    mfma_block(IC<2>(), a0);
-    D::template stage<1>(acc, stg, etid, pre);
-    D::template store<0>(stg, etid, post);
-    ahead(2);
-    lds_barrier();                                                     // slab 1 staged; the readers of slab 0's half are done
-    mfma_block(IC<3>(), a1);
-    D::template stage<2>(acc, stg, etid, pre);
-    D::template store<1>(stg, etid, post);
-    ahead(3);
-    lds_barrier();                                                     // slab 2 staged; every wave holds its last fragments: the K-tile's buffer is free
-}
-template <class C, class Pre, class Post>
-__device__ __forceinline__ void drain_tails(char* smem, const Acc<C>& acc, int p, int etid, const Pre& pre, const Post& post) {
-    using D = Drain<C>;
-    char* stg = smem + (p ^ 1) * C::STAGE_BYTES;
-    D::template stage<3>(acc, stg, etid, pre);
-    D::template store<2>(stg, etid, post);
-    lds_barrier();
-    D::template store<3>(stg, etid, post);
 }
 
 }  // namespace pgemm
