@@ -357,10 +357,13 @@ int pclip_layernorm_backward_f16(const void* x, int ldx, const void* gamma, cons
                                  float dy_scale, void* dx, int lddx, float* part, int nblk, pclip_stream_t stream);
 
 /* Backward of pclip_adapter_conv_f16 for the training step (reference: autograd through model.py:49-78; the input rows
- * are constants, main.py:266).  x, g [B, D] fp16 (input rows, gradient wrt the adapter output).  Outputs are PER-ROW fp32
- * contributions to the parameter gradients, to be summed over rows with pclip_colsum_f32: pw1/pw3 [B,16] (conv1 / conv3),
- * pw2 [B, 16*16*9] (conv2, layout [co][ci][ky][kx]), pg1/pb1, pg2/pb2 [B, 16*s*s], pg3/pb3 [B, s*s] (LayerNorm weight | bias),
- * s = ceil(sqrt(D)).  conv-2x: conv2 / ln2* / pw2 / pg2 / pb2 are NULL (those parameters receive no gradient). */
+ * are constants, main.py:266).  x, g [B, D] fp16 (input rows, gradient wrt the adapter output).  Outputs are fp32 PARTIAL sums of the
+ * parameter gradients, R rows of them, to be summed over those R rows with pclip_colsum_f32: pw1/pw3 [R,16] (conv1 / conv3),
+ * pw2 [R, 16*16*9] (conv2, layout [co][ci][ky][kx]), pg1/pb1, pg2/pb2 [R, 16*s*s], pg3/pb3 [R, s*s] (LayerNorm weight | bias),
+ * s = ceil(sqrt(D)).  R = pclip_adapter_conv_backward_partials(B, D, three_x) <= B: conv-3x with D <= 576 runs ONE persistent launch on the
+ * matrix pipe whose workgroup w accumulates rows w, w + R, ... (R = min(B, #CU); deterministic: fixed assignment, fixed order); every other
+ * case writes one partial per input row (R = B).  conv-2x: conv2 / ln2* / pw2 / pg2 / pb2 are NULL (those parameters receive no gradient). */
+int pclip_adapter_conv_backward_partials(int B, int D, int three_x);
 int pclip_adapter_conv_backward_f16(const void* x, const void* g, int B, int D, int three_x, const void* conv1, const void* ln1w,
                                     const void* ln1b, const void* conv2, const void* ln2w, const void* ln2b, const void* conv3,
                                     const void* ln3w, float* pw1, float* pw2, float* pw3, float* pg1, float* pb1, float* pg2,

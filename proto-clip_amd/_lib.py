@@ -74,6 +74,7 @@ _SIGS = {
     "pclip_gemm_f32": [_P, c_int, c_long, c_long, _P, c_int, c_long, c_long, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, c_size_t, _P],
     "pclip_colsum_f32": [_P, c_int, c_int, c_int, c_float, _P, c_int, _P, c_size_t, _P],
     "pclip_adapter_conv_backward_f16": [_P, _P, c_int, c_int, c_int] + [_P] * 8 + [_P] * 9 + [_P],
+    "pclip_adapter_conv_backward_partials": [c_int, c_int, c_int],
     "pclip_addscaled_rows_f32": [_P, c_int, _P, c_int, _P, c_float, c_int, c_int, _P],
     "pclip_nll_grad": [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P, _P],
     "pclip_nll_rows": [_P, c_int, _P, c_int, c_int, _P, _P, _P, _P],

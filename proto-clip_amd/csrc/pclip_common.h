@@ -58,6 +58,18 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
 __device__ __forceinline__ half8_t ld_half8(const half_t* p) { return *reinterpret_cast<const half8_t*>(p); }
 __device__ __forceinline__ void st_half8(half_t* p, half8_t v) { *reinterpret_cast<half8_t*>(p) = v; }
 
+// ds_read_b64_tr_b16: 64 bits per lane, 16-bit elements transposed inside each 16-lane group — lane l receives element (l & 3) of the 8-byte words
+// addressed by lanes 4 jj + ((l & 15) >> 2), jj = 0 .. 3 (probed on gfx950: tools/probe/tr_probe.hip).
+typedef __fp16 pclip_fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ half4_t lds_tr_read4(const char* lds_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const pclip_fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) pclip_fp16x4_t*)(lds_addr));
+    return __builtin_bit_cast(half4_t, v);
+#else
+    return half4_t{};
+#endif
+}
+
 // One-shot flags for per-DEVICE state (hipFuncSetAttribute applies to the current device only): a bit per device id, so a process
 // that drives several GPUs raises the LDS limit on each of them.
 struct DevOnce {

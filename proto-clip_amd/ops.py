@@ -790,13 +790,19 @@ def adapter_conv_backward(x, g, three_x: bool, conv1, ln1w, ln1b, conv2, ln2w, l
            "bn3.bias": f32(s2)}
     if three_x:
         out.update({"conv2.weight": f32(2304), "bn2.weight": f32(n1), "bn2.bias": f32(n1)})
-    c = min(chunk, max(B, 1))
-    sc = lambda n: torch.empty(c, n, dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    # rows of partial sums a launch over nb rows writes: the persistent MFMA kernel (conv-3x, D <= 576) one per workgroup — then the whole batch is
+    # ONE launch + one column sum per parameter; the per-row kernels one per input row — then the batch is walked in chunks of `chunk` rows
+    persistent = B > 0 and lib.pclip_adapter_conv_backward_partials(B, D, int(three_x)) < B
+    c = max(B, 1) if persistent else min(chunk, max(B, 1))
+    rows_of = lambda nb: lib.pclip_adapter_conv_backward_partials(nb, D, int(three_x))
+    rmax = max(rows_of(c), 1)
+    sc = lambda n: torch.empty(rmax, n, dtype=torch.float32, device=dev)
     pw1, pw3, pg1, pb1, pg3, pb3 = sc(16), sc(16), sc(n1), sc(n1), sc(s2), sc(s2)
     pw2, pg2, pb2 = (sc(2304), sc(n1), sc(n1)) if three_x else (None, None, None)
     for lo in range(0, B, c):
         nb = min(c, B - lo)
-        check(_lib.load().pclip_adapter_conv_backward_f16(
+        check(lib.pclip_adapter_conv_backward_f16(
             ptr(x[lo:lo + nb]), ptr(g[lo:lo + nb]), nb, D, int(three_x), ptr(conv1), ptr(ln1w), ptr(ln1b),
             ptr(conv2) if three_x else None, ptr(ln2w) if three_x else None, ptr(ln2b) if three_x else None, ptr(conv3), ptr(ln3w),
             ptr(pw1), ptr(pw2), ptr(pw3), ptr(pg1), ptr(pb1), ptr(pg2), ptr(pb2), ptr(pg3), ptr(pb3), stream()),
@@ -804,7 +810,7 @@ def adapter_conv_backward(x, g, three_x: bool, conv1, ln1w, ln1b, conv2, ln2w, l
         for name, part in (("conv1.weight", pw1), ("conv3.weight", pw3), ("bn1.weight", pg1), ("bn1.bias", pb1), ("bn3.weight", pg3),
                            ("bn3.bias", pb3), ("conv2.weight", pw2), ("bn2.weight", pg2), ("bn2.bias", pb2)):
             if part is not None:
-                colsum_f32(part, rows=nb, out=out[name])
+                colsum_f32(part, rows=rows_of(nb), out=out[name])
     shapes = {"conv1.weight": (16, 1, 1, 1), "conv3.weight": (1, 16, 1, 1), "conv2.weight": (16, 16, 3, 3), "bn1.weight": (16, s, s),
               "bn1.bias": (16, s, s), "bn2.weight": (16, s, s), "bn2.bias": (16, s, s), "bn3.weight": (1, s, s), "bn3.bias": (1, s, s)}
     return {k: v.view(shapes[k]) for k, v in out.items()}

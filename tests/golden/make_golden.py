@@ -28,7 +28,7 @@ sys.path.insert(0, REPO)
 from proto_clip_amd import synth                                   # noqa: E402
 from proto_clip_amd.clip.model import random_state_dict            # noqa: E402
 sys.path.insert(0, HERE)
-from spec import (E2E, E2E_CASE, E2E_VARIANTS, ENCODERS, FEWSHOT, RESNETS, TRAIN, e2e_images, e2e_jitter, e2e_state_dict, fewshot_inputs,   # noqa: E402
+from spec import (E2E, E2E_CASE, E2E_VARIANTS, ENCODERS, ENCODERS_FULL, FEWSHOT, RESNETS, TRAIN, e2e_images, e2e_jitter, e2e_state_dict, fewshot_inputs,   # noqa: E402
                   randomize_adapter_, train_inputs)
 
 
@@ -297,6 +297,26 @@ def make_encoder(tag, kw, ref_clip_model, ref_utils):
           cache_values=values.to(torch.int16), cache_labels=labels, pre_features=feats, pre_labels=flabels)
 
 
+def make_encoder_full(tag, ref_clip_model):
+    """The reference's OWN towers at a full-size architecture (spec.ENCODERS_FULL: the hyper-parameters build_model infers from OpenAI's
+    ViT-B/16 checkpoint, clip/model.py:397-434): encode_image (clip/model.py:221-238, 338-339) on 8 images and encode_text
+    (clip/model.py:341-354) on 8 prompts, with fp16 weights (its GPU-path precision) and as the fp32 model clip.load(device='cpu')
+    yields.  Outputs only (8 x 512 x 4 tensors); seeded random-init weights (no checkpoints in the build environment)."""
+    from proto_clip_amd.clip.model import BACKBONES
+    kw = BACKBONES[ENCODERS_FULL[tag]["backbone"]]
+    n_img, n_txt = ENCODERS_FULL[tag]["n_img"], ENCODERS_FULL[tag]["n_txt"]
+    sd = random_state_dict(seed=ENCODERS_FULL[tag]["sd_seed"], **kw)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m16 = ref_clip_model.build_model({k: v.clone() for k, v in sd.items()})
+        m32 = ref_clip_model.build_model({k: v.clone() for k, v in sd.items()}).float()
+    imgs = synth.make_images(n_img, kw["image_resolution"], seed=5, n_class=6)
+    toks = synth_tokens(n_txt, kw["vocab_size"], seed=5)
+    with torch.no_grad():
+        f32, t32 = m32.encode_image(imgs), m32.encode_text(toks)
+        f16, t16 = m16.encode_image(imgs), m16.encode_text(toks)
+    savez("encoder_" + tag, img_f16=f16, img_f32=f32, txt_f16=t16, txt_f32=t32, tokens=toks)
+
+
 def make_resnet(tag, kw, ref_clip_model):
     """ModifiedResNet tower of the reference (fp16-weight and fp32 variants) on seeded weights / images."""
     sd = random_state_dict(seed=13, **kw)
@@ -414,6 +434,9 @@ def main():
     for tag, kw in ENCODERS.items():
         if todo(tag):
             make_encoder(tag, kw, ref_clip_model, ref_utils)
+    for tag in ENCODERS_FULL:
+        if todo(tag):
+            make_encoder_full(tag, ref_clip_model)
     for tag, kw in RESNETS.items():
         if todo(tag):
             make_resnet(tag, kw, ref_clip_model)

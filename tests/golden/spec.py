@@ -19,6 +19,8 @@ SMALL = dict(embed_dim=128, image_resolution=64, vision_layers=3, vision_width=2
 ODD = dict(embed_dim=64, image_resolution=70, vision_layers=2, vision_width=192, vision_patch_size=14, context_length=77,
            vocab_size=300, transformer_width=64, transformer_heads=1, transformer_layers=1)   # L=26, K=588 (ViT-L/14-like pad)
 ENCODERS = {"tiny": TINY, "small": SMALL, "odd": ODD}
+# full-size towers through the reference itself (make_golden.make_encoder_full): the architecture the bench times (VERDICT r3 missing #1)
+ENCODERS_FULL = {"vitb16": dict(backbone="ViT-B/16", n_img=8, n_txt=8, sd_seed=11)}
 # image -> logits chain (make_golden.make_e2e): the SMALL towers with CLIP's real vocabulary, so that clip.tokenize feeds them
 E2E = dict(SMALL, vocab_size=49408)
 E2E_CASE = dict(N=6, K=4, Q_val=24, Q_test=48, augment_epoch=2, alpha=0.5, beta=12.0, adapter="conv-3x", n_templates=3, seed=31)
@@ -36,6 +38,11 @@ E2E_VARIANTS = {
     "e2e_s3": dict(sd_seed=20, case=dict(E2E_CASE, seed=52), adapter_seed=12, trained=False),
     "e2e_trained": dict(sd_seed=21, case=dict(E2E_CASE, seed=59), adapter_seed=13, trained=True),
     "e2e_trained2": dict(sd_seed=22, case=dict(E2E_CASE, seed=66), adapter_seed=14, trained=True),
+    # round 4: the gate became a DISTRIBUTION over 16 random-init draws + 4 trained-like ones (tests/test_gpu_e2e.py): twelve more seeded
+    # draws of the same case and two more trained-like towers
+    **{f"e2e_s{i}": dict(sd_seed=30 + i, case=dict(E2E_CASE, seed=100 + 7 * i), adapter_seed=40 + i, trained=False) for i in range(4, 16)},
+    "e2e_trained3": dict(sd_seed=60, case=dict(E2E_CASE, seed=240), adapter_seed=70, trained=True),
+    "e2e_trained4": dict(sd_seed=61, case=dict(E2E_CASE, seed=247), adapter_seed=71, trained=True),
     # the same chain behind the ModifiedResNet tower (RN50's channel widths, one bottleneck per stage, attention pool; RESNET below)
     "e2e_rn": dict(sd_seed=23, case=dict(E2E_CASE, seed=73), adapter_seed=15, trained=False, arch="rn"),
 }

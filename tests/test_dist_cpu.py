@@ -173,3 +173,84 @@ def test_bench_step_function_two_ranks_match_one():
     port = 33500 + (os.getpid() % 2000)
     mp.spawn(_step_worker, args=(2, port, two), nprocs=2, join=True)
     assert len(one[0]) == 24 and two[0] + two[1] == one[0]
+
+
+def _bench_main_worker(rank, world, port, outdir):
+    """bench.py's OWN run(): the rank / world environment of torch.distributed.run, build_state's support-set sharding, warm-up, barrier +
+    max-over-ranks timing, the self-check collective and the single JSON line — on CPU over gloo with the oracle's stages behind
+    proto_clip_amd.dist.hot_path_step (the first real `--gpus 8` run must not die on host logic)."""
+    import argparse
+    import io
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    import bench
+    from oracle import clip_oracle, proto_oracle as po
+    from proto_clip_amd import synth
+    from proto_clip_amd.clip.model import random_state_dict
+    from proto_clip_amd.dist import PrototypeExchange, hot_path_step, shard_bounds
+    kw = dict(embed_dim=64, image_resolution=32, vision_layers=2, vision_width=128, vision_patch_size=8, context_length=77,
+              vocab_size=512, transformer_width=64, transformer_heads=1, transformer_layers=1)
+    N, K, D, B = 9, 4, 64, 12
+    calls = {"build": 0, "step": 0, "check": 0}
+
+    def build_state(device, rank_, world_):
+        calls["build"] += 1
+        assert device.type == "cpu" and (rank_, world_) == (rank, world)
+        split = synth.make_split(N, K, D, 8, 8, seed=2)
+        rows = split.visual_memory_keys.t().contiguous()
+        labels = torch.arange(N).repeat_interleave(K).int()
+        lo, hi = shard_bounds(N * K, rank_, world_)
+        torch.manual_seed(0)
+        ad = {"conv1.weight": torch.randn(16, 1, 1, 1).half(), "conv2.weight": (torch.randn(16, 16, 3, 3) / 12).half(),
+              "conv3.weight": (torch.randn(1, 16, 1, 1) / 4).half()}
+        for i, c in ((1, 16), (2, 16), (3, 1)):
+            ad[f"bn{i}.weight"], ad[f"bn{i}.bias"] = torch.ones(c, 8, 8).half(), torch.zeros(c, 8, 8).half()
+        return dict(sd=random_state_dict(seed=11, **kw), ad=ad, bank=rows[lo:hi], bank_labels=labels[lo:hi],
+                    text=po.l2norm_rows(split.textual_memory_bank.t().contiguous()), images=synth.make_images(B, 32, seed=5 + rank_, n_class=N))
+
+    def step(st):
+        calls["step"] += 1
+
+        class OraclePath:
+            encode = staticmethod(lambda x: clip_oracle.encode_image(st["sd"], x, half=True))
+            l2norm = staticmethod(po.l2norm_rows)
+            adapt = staticmethod(lambda f: po.l2norm_rows(po.adapter_conv(f, st["ad"], "conv-3x")))
+            classify = staticmethod(lambda a, zi, zt_, al, be: po.P(a, zi, zt_, al, be).max(1)[1])
+
+        fin = lambda s, c, fp32_out=False: po.proto_finalize(s, c, fp32=fp32_out)
+        return hot_path_step(OraclePath, PrototypeExchange(), st["bank"], st["bank_labels"], N, st["images"], st["text"], 0.5, 12.0,
+                             partial_fn=po.partial_sums, finalize_fn=fin)
+
+    def self_check(st):
+        calls["check"] += 1
+        idx = torch.arange(0, B, 3)
+        full, sub = step(st), step(dict(st, images=st["images"][idx].contiguous()))
+        return "ok" if torch.equal(full[idx], sub) else "MISMATCH"
+
+    class CpuHooks:
+        backend, instrument, batch = "gloo", False, B
+        device = staticmethod(lambda local: torch.device("cpu"))
+        sync = staticmethod(lambda: None)
+    CpuHooks.build_state, CpuHooks.step, CpuHooks.self_check = staticmethod(build_state), staticmethod(step), staticmethod(self_check)
+
+    buf = io.StringIO()
+    args = argparse.Namespace(gpus=world, steps=3, warmup=1, no_cpu_baseline=True, no_extra=True, cpu_worker=None)
+    bench.run(args, CpuHooks, out=buf)
+    assert calls["build"] == 1 and calls["check"] == 1 and calls["step"] == 1 + 3 + 2       # warm-up + timed + the self-check's two
+    with open(os.path.join(outdir, f"out{rank}.txt"), "w") as f:
+        f.write(buf.getvalue())
+
+
+def test_bench_main_plumbing_two_ranks(tmp_path):
+    import json
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_bench_main_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    out0, out1 = (tmp_path / "out0.txt").read_text(), (tmp_path / "out1.txt").read_text()
+    assert out1 == "" and out0.count("\n") == 1                           # ONE line, from rank 0 only
+    line = json.loads(out0)
+    assert line["n_gpus"] == 2 and line["rccl_world_size"] == 2 and line["steps"] == 3 and line["warmup"] == 1
+    assert line["scaling"] == "weak" and line["self_check"] == "ok" and line["higher_is_better"] is True
+    assert line["config"]["batch_per_gpu"] == 12 and line["config"]["global_batch"] == 24
+    # value = the units ALL ranks processed / the slowest rank's time
+    assert abs(line["value"] - 3 * 12 * 2 / (line["ms_per_step"] * 3 / 1e3)) < 1e-6 * line["value"]
+    assert "cpu_baseline" not in line and "extra" not in line

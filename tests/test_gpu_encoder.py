@@ -685,6 +685,63 @@ def test_full_size_vit_b16_against_oracle():
     assert torch.equal(f1[0], f[2])
 
 
+def test_full_size_vit_b16_against_reference():
+    """The real ViT-B/16 architecture through the REFERENCE's own towers (tests/golden/encoder_vitb16.npz: make_golden.make_encoder_full runs
+    /root/reference's build_model at the hyper-parameters OpenAI's ViT-B/16 checkpoint resolves to — 12 x 768, 197 tokens, 12 heads; text
+    12 x 512 — on 8 images and 8 prompts, fp16-weight and fp32): encode_image / encode_text of the HIP path within max(2 x the reference's own
+    fp16 <-> fp32 gap, 3e-3), the bound of the toy-tower fixtures (clip/model.py:221-238, 338-354, 397-434)."""
+    from proto_clip_amd.clip.model import BACKBONES
+    from spec import ENCODERS_FULL
+    g = golden("encoder_vitb16")
+    spec_ = ENCODERS_FULL["vitb16"]
+    kw = BACKBONES[spec_["backbone"]]
+    sd = random_state_dict(seed=spec_["sd_seed"], **kw)
+    model = build_model({k: v.clone() for k, v in sd.items()}).cuda()
+    imgs = synth.make_images(spec_["n_img"], kw["image_resolution"], seed=5, n_class=6)
+    toks = torch.from_numpy(g["tokens"]).long()
+    with torch.no_grad():
+        fi, ft = model.encode_image(imgs.cuda()), model.encode_text(toks.cuda())
+    for key, out in (("img", fi), ("txt", ft)):
+        r16_, r32_ = torch.from_numpy(g[key + "_f16"]), torch.from_numpy(g[key + "_f32"])
+        gap = rel_err(r16_, r32_)
+        observe(f"full-size ViT-B/16 {key}: reference fp16<->fp32 gap (yard-stick)", gap, gap)
+        assert observe(f"full-size ViT-B/16 {key}: rel err vs REFERENCE fp32", rel_err(out, r32_), max(2.0 * gap, 3e-3)) <= max(2.0 * gap, 3e-3)
+        assert observe(f"full-size ViT-B/16 {key}: rel err vs REFERENCE fp16", rel_err(out, r16_), max(2.0 * gap, 3e-3)) <= max(2.0 * gap, 3e-3)
+
+
+@pytest.mark.parametrize("fold", [False, True])
+def test_bench_configuration_rows_equal_small_batches(fold):
+    """What bench.py times, tested: ViT-B/16 encode_image on the bench's own 1024 images (M = 201 728 token rows: persistent 256 x 256 tiles
+    over 37 rounds, the row-split 128 x 128 tails, descending tile order, the whole-batch LayerNorm kernel, the four-slab QuickGELU epilogue)
+    must give, for rows {0 .. 5, 511, 1018 .. 1023}, exactly the bits of the same images encoded in a batch of 6 / alone — the contract
+    `a row alone == the row in a batch` that test_full_size_vit_b16_against_oracle states at B = 6 — with the LayerNorm fold off (default)
+    and on; and the whole hot-path step's top-1 for those rows equals the step on the sub-batch."""
+    import bench
+    import proto_clip_amd.clip.model as M
+    from proto_clip_amd.dist import HipPath, PrototypeExchange, hot_path_step
+    st = bench.build_state(torch.device("cuda", 0), 0, 1)
+    rows = list(range(6)) + [511] + list(range(1018, 1024))
+    was = M.LN_FOLD
+    try:
+        M.LN_FOLD = fold
+        M.invalidate_ln_fold()
+        with torch.no_grad():
+            big = st["model"].encode_image(st["images"])
+            sub = st["model"].encode_image(st["images"][rows].contiguous())
+            one = st["model"].encode_image(st["images"][511:512].contiguous())
+            assert big.shape == (bench.BATCH, bench.DIM)
+            assert torch.equal(big[rows], sub), f"rows of the B = 1024 pass differ from the B = {len(rows)} pass (fold={fold})"
+            assert torch.equal(big[511], one[0])
+            path, ex = HipPath(st["model"], st["adapter"]), PrototypeExchange()
+            top_big = hot_path_step(path, ex, st["bank"], st["bank_labels"], bench.N_CLASS, st["images"], st["text"], bench.ALPHA, bench.BETA)
+            top_sub = hot_path_step(path, ex, st["bank"], st["bank_labels"], bench.N_CLASS, st["images"][rows].contiguous(), st["text"], bench.ALPHA, bench.BETA)
+            assert top_big.shape == (bench.BATCH,) and torch.equal(top_big[rows], top_sub)
+            assert len(torch.unique(top_big)) >= 2             # not a constant answer (random-init towers spread 1024 synthetic images over a handful of classes)
+    finally:
+        M.LN_FOLD = was
+        M.invalidate_ln_fold()
+
+
 @pytest.mark.parametrize("B,G2,W", [(3, 49, 768), (2, 196, 768), (1, 256, 1024), (5, 4, 128), (2, 9, 64)])
 def test_vit_stem_fused_equals_separate(ops, B, G2, W):
     """tokens + ln_pre + the first block's ln_1 in one pass (pclip_vit_embed_ln_f16) against the three separate kernels: the row

@@ -102,6 +102,30 @@ def test_partial_sums_and_finalize(ops, W):
     assert ulp_diff(out, po.proto_finalize(torch.stack([s.cpu() for s in sums]), torch.stack([c.cpu() for c in counts]))) <= 2
 
 
+@pytest.mark.parametrize("W", [2, 7, 8])
+def test_partial_sums_and_finalize_imagenet_size(ops, W):
+    """The same at the C4 size (BASELINE configs[3]: ImageNet 16-shot, N = 1000, K = 16, D = 512): 8 slabs of 2000 rows end on class
+    boundaries, 2 slabs of 8000 too, 7 slabs of 2285 / 2286 rows do not (classes straddle ranks) — the rank-ordered combine of the fp32
+    class sums must reproduce the single-GPU prototype build bit for bit in all three."""
+    from proto_clip_amd.dist import shard_bounds
+    N, K, D = 1000, 16, 512
+    mem = (torch.from_numpy(synth.normal((N * K, D), 19, 0)).float() * 1.2).half()
+    labels = torch.arange(N).repeat_interleave(K).int()
+    mem_d, lab_d = dev(mem), dev(labels)
+    sums, counts, straddle = [], [], 0
+    for r in range(W):
+        lo, hi = shard_bounds(N * K, r, W)
+        straddle += int(lo % K != 0)
+        s, c = ops.partial_sums(mem_d[lo:hi], lab_d[lo:hi], N)
+        sums.append(s)
+        counts.append(c)
+    assert (straddle > 0) == (W == 7)
+    assert int(torch.stack(counts).sum().item()) == N * K and torch.equal(torch.stack(counts).sum(0).cpu(), torch.full((N,), K, dtype=torch.int32))
+    out = ops.proto_finalize(torch.stack(sums), torch.stack(counts))
+    single = ops.proto_build(mem_d, N, K)
+    assert torch.equal(out.cpu(), single.cpu())
+
+
 def test_partial_sums_missing_classes(ops):
     N, D = 12, 64
     mem = torch.from_numpy(synth.normal((20, D), 10, 0)).half()
