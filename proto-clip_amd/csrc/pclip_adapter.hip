@@ -325,6 +325,13 @@ __global__ __launch_bounds__(256, NT <= TWO_WG_MAX ? 2 : 1) void adapter_conv3x_
     }
     __syncthreads();
 
+    // the NEXT row's values are requested a whole row ahead: a row is 1 KB straight from HBM, and its ~2 us would otherwise open every iteration
+    half_t xnext[NPX];
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+        const int pp = tid + 256 * j;
+        xnext[j] = (pp < D && (int)blockIdx.x < B) ? x[(size_t)blockIdx.x * D + pp] : (half_t)0.f;
+    }
     for (int row = blockIdx.x; row < B; row += gridDim.x) {
 #if defined(__HIP_DEVICE_COMPILE__)
         // the packed parameters are made opaque once per row: hipcc otherwise hoists their fp16 -> fp32 conversions out of the row loop and keeps
@@ -347,7 +354,9 @@ __global__ __launch_bounds__(256, NT <= TWO_WG_MAX ? 2 : 1) void adapter_conv3x_
 #pragma unroll
         for (int j = 0; j < NPX; ++j) {
             const int pp = tid + 256 * j;
-            xh[j] = pp < D ? x[(size_t)row * D + pp] : (half_t)0.f;
+            xh[j] = xnext[j];
+            const int nrow = row + (int)gridDim.x;
+            xnext[j] = (pp < D && nrow < B) ? x[(size_t)nrow * D + pp] : (half_t)0.f;
             const half2_t xx = {xh[j], xh[j]};
             if (pp < s2) {
 #pragma unroll
