@@ -205,7 +205,7 @@ def c2_kernels(device):
             "classify_gb_per_s": byts / t_cl / 1e9, "classify_frac_of_hbm_8tb": byts / t_cl / 8e12}
 
 
-PMC_TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json")     # newest committed summary first
+PMC_TRAFFIC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")     # newest committed summary first
 
 
 def pmc_traffic():

@@ -272,7 +272,10 @@ def test_adapter_against_reference_fixture(ops, name):
     assert_adapter_close(y_tape.detach(), val_raw[:4], tag=f"adapter {cfg['adapter']} under autograd vs its no_grad kernel ({name})")
 
 
-@pytest.mark.parametrize("kind,D", [("conv-3x", 512), ("conv-2x", 768), ("conv-3x", 1024), ("fc", 1024), ("conv-2x", 100)])
+# conv-3x runs on the matrix pipe (pclip_adapter.hip adapter_conv3x_mfma_kernel<NT>, NT = ceil(s^2 / 64)): D = 200 (s = 15: a partial last tile),
+# 576 (s = 24: nine full 64-pixel groups, the last two-workgroups-per-CU size), 577 (s = 25: NT = 10, one workgroup per CU), 768 (NT = 13), 1024 (NT = 16)
+@pytest.mark.parametrize("kind,D", [("conv-3x", 512), ("conv-2x", 768), ("conv-3x", 1024), ("fc", 1024), ("conv-2x", 100), ("conv-3x", 200), ("conv-3x", 576),
+                                    ("conv-3x", 577), ("conv-3x", 768), ("conv-3x", 64)])
 def test_adapter_random_weights_vs_oracle(ops, kind, D):
     from proto_clip_amd.model import Adapter, Adapter_FC
     if kind == "fc" and D % 256:
@@ -287,8 +290,11 @@ def test_adapter_random_weights_vs_oracle(ops, kind, D):
     sd = {k: v.clone() for k, v in ad.state_dict().items()}
     ref = po.adapter_fc(x, sd) if kind == "fc" else po.adapter_conv(x, sd, kind)
     with torch.no_grad():
-        y = ad.cuda()(dev(x))
+        adc = ad.cuda()
+        y = adc(dev(x))
+        y1 = adc(dev(x[7:8]))                                 # persistent kernel: a row alone (grid of one workgroup) == the row in the batch
     assert_adapter_close(y, ref, tag=f"adapter {kind} D={D} vs oracle")
+    assert torch.equal(y1[0], y[7])
 
 
 # ---------------------------------------------------------------- whole test pass ----------------------

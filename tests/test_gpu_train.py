@@ -152,7 +152,10 @@ def test_layernorm_backward(ops, R, D, scale):
     assert_grad_close(db.half(), beta.grad, "ln dbeta")
 
 
-@pytest.mark.parametrize("B,D,kind", [(40, 144, "conv-3x"), (33, 100, "conv-2x"), (700, 512, "conv-3x"), (20, 1024, "conv-3x"), (50, 768, "conv-2x")])
+# conv-3x with D <= 576 is ONE persistent launch on the matrix pipe writing one partial row per workgroup (B = 700 > #CU: several rows per workgroup;
+# B = 1 / 3: fewer rows than workgroups); D = 200: a partial last pixel tile; larger D / conv-2x: the per-row kernel in chunks
+@pytest.mark.parametrize("B,D,kind", [(40, 144, "conv-3x"), (33, 100, "conv-2x"), (700, 512, "conv-3x"), (20, 1024, "conv-3x"), (50, 768, "conv-2x"),
+                                      (1, 512, "conv-3x"), (3, 200, "conv-3x"), (300, 576, "conv-3x"), (37, 577, "conv-3x")])
 def test_adapter_conv_backward(ops, B, D, kind):
     import math
     from conftest import randomize_adapter_
