@@ -1261,6 +1261,15 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const half_t
     }
 }
 
+// (Measured and removed, round 4, profiles/r04_ab_attention16.txt — VERDICT r3 #3 "buy occupancy": the same attention on SIXTEEN-query tiles
+// (v_mfma_f32_16x16x32_f16: S^T as 16 x 16 tiles, lane = query l & 15 / keys 16 m + 4 q + r; the probabilities of a 32-key tile feed the second contraction as
+// its B operand in the k-slot order {4 q .. 4 q + 3} of both 16-key halves, V^T by two transpose reads in the same order; row maximum combined over the four
+// lanes of a query by v_permlane16/32_swap, the row sum once at the end): 60 VGPRs with one key tile per step (84 with two; forced to 72: 44 B of scratch),
+// 13-wave workgroups (208 >= 197 queries), two per CU = 26 waves = 6.5 per SIMD against 3.5 active now.  Correct on the first run (error against fp32
+// attention unchanged) and SLOWER: ViT-B/16 377 us (one tile per step) / 437 - 465 us (two) against 350 us for the 32-query kernel in the same
+// harness; ViT-L/14 195 / 200 vs 186; text (causal, L = 77) 524 / 499 - 504 vs 526; ViT-B/32 level.  Every wave reads ALL of K and V from LDS: with half
+// the queries per wave the fragment traffic per query doubles (741 KB per (image, head) through the LDS), and so do the per-tile reductions — the occupancy
+// is there (60 registers) and does not pay for them.)
 // ---- persistent, double-buffered form of the same attention (whole batches) --------------------------------------------------
 // attention_kernel is a chain of dependent phases per (image, head): K/V by LDS-DMA -> barrier -> query loads -> compute -> stores,
 // and two co-resident workgroups fall into lockstep, so the memory pipe idles while the SIMDs work and vice versa (ablation,
