@@ -1261,169 +1261,15 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const half_t
     }
 }
 
-// ---- the same attention on 16-query tiles (v_mfma_f32_16x16x32_f16): half the registers per wave, twice the waves per CU ----------------
-// attention_kernel is latency-bound at 2.7 resident waves per SIMD (profiles/r03_pmc_attention.json: issue ports 57 % busy, 124 of the 128 VGPRs four
-// waves per SIMD allow; of its eight waves seven have a 32-query tile for L = 197, and 27 of the last tile's 32 queries are padding).  Here a wave owns
-// SIXTEEN queries: S^T = K Q^T as 16 x 16 tiles (lane = query l & 15, keys 16 m + 4 q + r), O^T = V^T P^T as four 16 x 16 tiles (lane = query, d = 16 j + 4 q + r)
-// — 16 + 16 accumulator registers instead of 32 + 32, about 70 VGPRs in all, so a 13-wave workgroup (13 x 16 = 208 >= 197 queries: 5 % padding instead
-// of 12 %) fits TWICE per CU = 26 waves (6.5 per SIMD).  The probabilities of a 32-key tile are the B operand of the second contraction as they leave the
-// softmax: k-slots 8 q .. 8 q + 7 of lane group q := keys {4 q .. 4 q + 3} of the tile's two 16-key halves, and the V^T fragment is read (two transpose
-// reads) in the same slot order.  A query's row maximum / sum live in the four lanes that share it: the maximum is combined every pair of key tiles
-// (v_permlane16/32_swap), the sum once at the end (the rescale factor is the same in the four lanes).  Deferred maximum as attention_kernel (per row).
-__device__ __forceinline__ float pair_max16(float v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned a = __builtin_bit_cast(unsigned, v);
-    const auto r = __builtin_amdgcn_permlane16_swap(a, a, false, false);
-    const unsigned x = r[0], y = r[1];
-    return fmaxf(__builtin_bit_cast(float, x), __builtin_bit_cast(float, y));
-#else
-    return v;
-#endif
-}
-__device__ __forceinline__ float pair_add16(float v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned a = __builtin_bit_cast(unsigned, v);
-    const auto r = __builtin_amdgcn_permlane16_swap(a, a, false, false);
-    const unsigned x = r[0], y = r[1];
-    return __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
-#else
-    return v;
-#endif
-}
-template <int NW>
-__global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention16_kernel(const half_t* __restrict__ qp, int ldq, long q_batch,
-                                                                              const half_t* __restrict__ kvp, int ldkv, int k_off, int v_off,
-                                                                              half_t* __restrict__ out, int L, int Lq, int H, int causal, int NT) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int LP = NT * 32;
-    half_t* Ks = reinterpret_cast<half_t*>(smem);             // [LP][64], 16-byte chunks XOR-swizzled by swz_key(row)
-    half_t* Vs = Ks + LP * ATT_DH;                            // [LP][64] row-major, chunk ^ 4 * ((row >> 1) & 1)
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int W = H * ATT_DH;
-    const half_t* kbase = kvp + (size_t)b * L * ldkv + h * ATT_DH + k_off;
-    const half_t* vbase = kvp + (size_t)b * L * ldkv + h * ATT_DH + v_off;
-    const half_t* qbase = qp + (size_t)b * q_batch + h * ATT_DH;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int r0 = wave * 8; r0 < LP; r0 += NW * 8) {
-        const int r = r0 + (lane >> 3);
-        const int c = (lane & 7) ^ pgemm::swz_key(r);
-        const int rc = r < L ? r : L - 1;
-        __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(kbase + (size_t)rc * ldkv + c * 8), (pgemm::lds_ptr_t)(Ks + r0 * ATT_DH), 16, 0, 0);
-    }
-    for (int r0 = wave * 8; r0 < LP; r0 += NW * 8) {
-        const int r = r0 + (lane >> 3);
-        const int c = (lane & 7) ^ (((r >> 1) & 1) << 2);
-        const int rc = r < L ? r : L - 1;
-        __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(vbase + (size_t)rc * ldkv + c * 8), (pgemm::lds_ptr_t)(Vs + r0 * ATT_DH), 16, 0, 0);
-    }
-    __syncthreads();
-
-    const int q4 = lane >> 4, i16 = lane & 15;
-    // V^T fragment addressing (transpose reads): lane i of a 16-lane group points at V[key0 + (i >> 2)][16 j + 4 (i & 3) ..], key0 = 4 q (+ 16, + 32 t)
-    int voff[4];
-    {
-        const int vrow = 4 * q4 + (i16 >> 2), vswz = ((i16 >> 3) & 1) << 2;                      // ((row >> 1) & 1) of every row this lane ever addresses
-#pragma unroll
-        for (int j = 0; j < 4; ++j) voff[j] = vrow * (ATT_DH * 2) + (((2 * j + ((i16 >> 1) & 1)) ^ vswz) << 4) + (i16 & 1) * 8;
-    }
-    constexpr float kScale = 0.125f * 1.4426950408889634f;
-    const int NTq = (Lq + 15) >> 4;
-    for (int qb = wave; qb < NTq; qb += NW) {
-        const int q = qb * 16 + i16;                                 // this lane's query row (shared with lanes i16 + 16, + 32, + 48)
-        const int qc = q < Lq ? q : Lq - 1;
-        half8_t qf[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[ks] = ld_half8(qbase + (size_t)qc * ldq + ks * 32 + q4 * 8);
-        float4_t o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = float4_t{0.f, 0.f, 0.f, 0.f};
-        float mrun = -__builtin_inff(), lrun = 0.f;                  // lrun: THIS lane's share of the row sum
-        const int tend = causal ? ((qb * 16 + 15) / 32 + 1 < NT ? (qb * 16 + 15) / 32 + 1 : NT) : NT;
-        const int kend = causal ? (q + 1 < L ? q + 1 : L) : L;       // key k is valid iff k < kend
-        auto tiles = [&](auto NTILE_C, int t0) {
-            constexpr int NTILE = decltype(NTILE_C)::value;
-            float4_t st[2 * NTILE];
-#pragma unroll
-            for (int m = 0; m < 2 * NTILE; ++m) st[m] = float4_t{0.f, 0.f, 0.f, 0.f};
-#if defined(__HIP_DEVICE_COMPILE__)
-            __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int m = 0; m < 2 * NTILE; ++m) {
-                    const int kr = t0 * 32 + 16 * m + i16;
-                    const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + kr * ATT_DH + (((ks * 4 + q4) ^ pgemm::swz_key(kr)) << 3));
-                    st[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], st[m], 0, 0, 0);
-                }
-#if defined(__HIP_DEVICE_COMPILE__)
-            __builtin_amdgcn_s_setprio(0);
-#endif
-            if ((t0 + NTILE) * 32 > L || (causal && (t0 + NTILE) * 32 > qb * 16 + 1)) {      // wave-uniform: only edge tiles pay for the mask
-                const int lim = kend - t0 * 32 - 4 * q4;
-#pragma unroll
-                for (int m = 0; m < 2 * NTILE; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (!(16 * m + r < lim)) st[m][r] = -__builtin_inff();
-            }
-            float tmax = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
-#pragma unroll
-            for (int m = 1; m < 2 * NTILE; ++m) tmax = fmaxf(tmax, fmaxf(fmaxf(st[m][0], st[m][1]), fmaxf(st[m][2], st[m][3])));
-            tmax = half_wave_max(pair_max16(tmax)) * kScale;
-            const bool moved = tmax > mrun + kAttDefer;              // deferred maximum, per row (attention_kernel VAR & 1)
-            const float mnew = moved ? fmaxf(mrun, tmax) : mrun;
-            const bool grow = __any(moved);
-            float psum = 0.f;
-#pragma unroll
-            for (int m = 0; m < 2 * NTILE; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    st[m][r] = __builtin_amdgcn_exp2f(fmaf(st[m][r], kScale, -mnew));
-                    psum += st[m][r];
-                }
-            if (grow) {
-                const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-                lrun *= alpha;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[j][r] *= alpha;
-            }
-            lrun += psum;
-            mrun = mnew;
-#pragma unroll
-            for (int u = 0; u < NTILE; ++u) {
-                const half8_t pf = {(half_t)st[2 * u][0], (half_t)st[2 * u][1], (half_t)st[2 * u][2], (half_t)st[2 * u][3],
-                                    (half_t)st[2 * u + 1][0], (half_t)st[2 * u + 1][1], (half_t)st[2 * u + 1][2], (half_t)st[2 * u + 1][3]};
-                const char* vb = reinterpret_cast<const char*>(Vs) + (t0 + u) * 32 * (ATT_DH * 2);
-#if defined(__HIP_DEVICE_COMPILE__)
-                __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const half4_t v0 = tr_read4(vb + voff[j]), v1 = tr_read4(vb + voff[j] + 16 * (ATT_DH * 2));
-                    const half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    o[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[j], 0, 0, 0);
-                }
-#if defined(__HIP_DEVICE_COMPILE__)
-                __builtin_amdgcn_s_setprio(0);
-#endif
-            }
-        };
-        int t = 0;
-        for (; t + 1 < tend; t += 2) tiles(std::integral_constant<int, 2>{}, t);
-        if (t < tend) tiles(std::integral_constant<int, 1>{}, t);
-        const float inv = 1.f / half_wave_sum(pair_add16(lrun));
-        if (q < Lq) {
-            half_t* orow = out + ((size_t)b * Lq + q) * W + h * ATT_DH + 4 * q4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<half4_t*>(orow + 16 * j) = half4_t{(half_t)(o[j][0] * inv), (half_t)(o[j][1] * inv), (half_t)(o[j][2] * inv), (half_t)(o[j][3] * inv)};
-        }
-    }
-}
-
+// (Measured and removed, round 4, profiles/r04_ab_attention16.txt — VERDICT r3 #3 "buy occupancy": the same attention on SIXTEEN-query tiles
+// (v_mfma_f32_16x16x32_f16: S^T as 16 x 16 tiles, lane = query l & 15 / keys 16 m + 4 q + r; the probabilities of a 32-key tile feed the second contraction as
+// its B operand in the k-slot order {4 q .. 4 q + 3} of both 16-key halves, V^T by two transpose reads in the same order; row maximum combined over the four
+// lanes of a query by v_permlane16/32_swap, the row sum once at the end): 60 VGPRs with one key tile per step (84 with two; forced to 72: 44 B of scratch),
+// 13-wave workgroups (208 >= 197 queries), two per CU = 26 waves = 6.5 per SIMD against 3.5 active now.  Correct on the first run (error against fp32
+// attention unchanged) and SLOWER: ViT-B/16 377 us (one tile per step) / 437 - 465 us (two) against 350 us for the 32-query kernel in the same
+// harness; ViT-L/14 195 / 200 vs 186; text (causal, L = 77) 524 / 499 - 504 vs 526; ViT-B/32 level.  Every wave reads ALL of K and V from LDS: with half
+// the queries per wave the fragment traffic per query doubles (741 KB per (image, head) through the LDS), and so do the per-tile reductions — the occupancy
+// is there (60 registers) and does not pay for them.)
 // ---- persistent, double-buffered form of the same attention (whole batches) --------------------------------------------------
 // attention_kernel is a chain of dependent phases per (image, head): K/V by LDS-DMA -> barrier -> query loads -> compute -> stores,
 // and two co-resident workgroups fall into lockstep, so the memory pipe idles while the SIMDs work and vice versa (ablation,
@@ -2433,29 +2279,6 @@ extern "C" int pclip_attention_q_f16(const void* q, int ldq, long q_batch_stride
         return pclip_check_launch("attention (pipelined)");
     }
     const size_t lds = 2 * (size_t)LP * ATT_DH * 2;
-    static const bool att16 = !(getenv("PCLIP_ATT16") && getenv("PCLIP_ATT16")[0] == '0');        // A/B switch: 0 = the 32-query-tile kernels
-    if (att16) {
-        static DevOnce attr16;
-        if (!attr16.done()) {
-            const void* fns[] = {(const void*)attention16_kernel<4>, (const void*)attention16_kernel<5>, (const void*)attention16_kernel<9>, (const void*)attention16_kernel<13>};
-            for (const void* f : fns)
-                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) {
-                    pclip_set_error("pclip_attention_f16: cannot raise the dynamic LDS limit");
-                    return PCLIP_E_LAUNCH;
-                }
-            attr16.set();
-        }
-        const int ntq = (Lq + 15) / 16;          // 16-query tiles: one per wave where the workgroup size allows, two rounds above 13
-#define PCLIP_ATT16_LAUNCH(NW)                                                                                                                  \
-        attention16_kernel<NW><<<B * H, NW * 64, lds, (hipStream_t)stream>>>((const half_t*)q, ldq, q_batch_stride, (const half_t*)kv, ldkv, k_off, \
-                                                                               v_off, (half_t*)out, L, Lq, H, causal, NT)
-        if (ntq <= 4) PCLIP_ATT16_LAUNCH(4);
-        else if (ntq == 5) PCLIP_ATT16_LAUNCH(5);
-        else if (ntq <= 9 || (ntq > 13 && ntq <= 18)) PCLIP_ATT16_LAUNCH(9);
-        else PCLIP_ATT16_LAUNCH(13);
-#undef PCLIP_ATT16_LAUNCH
-        return pclip_check_launch("attention (16-query tiles)");
-    }
     // The softmax variant follows the SEQUENCE (more than four key tiles: the long form), not the kernel: the one-query form of the
     // last vision block (Lq = 1, four waves) must produce the bits of the full attention over the same keys.
     static DevOnce attr_set;
