@@ -101,8 +101,12 @@ def _folded(blk, name, w, b, ln):
     hit = cache.get(name)
     if hit is None or hit[0] != tag:
         f32 = lambda t: t.detach() if t.dtype == torch.float32 else t.detach().float()
+        if w.is_cuda and torch.cuda.is_current_stream_capturing():
+            # the overflow check below is a host read: illegal inside a hipGraph capture.  Fold eagerly first (one warm-up forward, or
+            # invalidate_ln_fold + a forward after changing parameters), then capture.
+            raise RuntimeError("PCLIP_LN_FOLD: the folded LayerNorm / linear operands must be built before a graph capture starts (run one eager forward first)")
         folded = ops.ln_fold_weights(w.detach(), b.detach(), f32(ln.weight), f32(ln.bias))
-        if not bool(torch.isfinite(folded[0]).all()):      # once per (LayerNorm, Linear) pair
+        if not all(bool(torch.isfinite(t).all()) for t in folded):      # Wf, colsum and the folded bias; once per (LayerNorm, Linear) pair
             folded = None
         hit = (tag, folded)
         cache[name] = hit

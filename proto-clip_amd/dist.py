@@ -90,6 +90,11 @@ class PrototypeExchange:
         if self.stream is None:
             self.stream = torch.cuda.Stream(mem_shard.device)
         self.stream.wait_stream(torch.cuda.current_stream(mem_shard.device))      # the bank may have been written on the main stream
+        # the operands were allocated on the caller's stream and are READ on the side stream: tell the caching allocator, or a caller that
+        # passes temporaries (bank[lo:hi].to(device) per step) and drops them before result() could get the memory handed back to the main
+        # stream while partial_sums still reads it
+        mem_shard.record_stream(self.stream)
+        labels_shard.record_stream(self.stream)
         with torch.cuda.stream(self.stream):
             self.out = sharded_prototypes(mem_shard, labels_shard, N, **kw)
         return self
