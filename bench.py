@@ -288,10 +288,10 @@ def cpu_worker(args):
 
 def cpu_baseline(batch=64, budget_s=150.0):
     """The ORACLE (CPU restatement of the reference path) timed on the HOST's cores (north_star: the same box's host cores, core count stated)
-    on a bounded sample of the same workload: one batch of 64 images per process; configurations processes x threads with DISJOINT CPU
-    ranges — 1 x 16 in this process, then k x 16 in k worker processes started together (k = 4, 8, 16 while k * 16 logical cores and 4 GB per
-    process exist) — host-level rate = images of all processes / (last finish - first start); the best configuration is reported, `cores`
-    = the logical cores it used."""
+    on a bounded sample of the same workload (~256 images per configuration): configurations processes x threads with DISJOINT CPU
+    ranges — 1 x 16 in this process (one batch of 64), then k x 16 in k worker processes started together (k = 4, 8, 16 while k * 16 logical
+    cores and 4 GB per process exist and the rate still rises; 256 / k images each, at least 16) — host-level rate = images of all processes /
+    (last finish - first start); the best configuration is reported, `cores` = the logical cores it used."""
     import subprocess
     import tempfile
     ncpu = os.cpu_count() or 1
@@ -314,11 +314,13 @@ def cpu_baseline(batch=64, budget_s=150.0):
             avail_gb = next(int(l.split()[1]) for l in f if l.startswith("MemAvailable")) / 2 ** 20
     except Exception:
         avail_gb = 0.0
+    prev_rate = rates[(1, thr)]
     for k in (4, 8, 16):
         if k * thr > ncpu or k * 4.0 > 0.5 * avail_gb or time.perf_counter() - t_start > budget_s * 0.6:
             break
+        pb = max(16, 4 * batch // k)                       # images per process: the sample stays ~256 images per configuration (bounded CPU time)
         d = tempfile.mkdtemp(prefix="pclip_cpu_")
-        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{thr},{batch},{i * thr},{d},{i}"],
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{thr},{pb},{i * thr},{d},{i}"],
                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(thr)))
                  for i in range(k)]
         try:
@@ -329,7 +331,10 @@ def cpu_baseline(batch=64, budget_s=150.0):
             for p_ in procs:
                 p_.wait(timeout=180)
             spans = [tuple(map(float, open(os.path.join(d, f"done{i}")).read().split())) for i in range(k)]
-            rates[(k, thr)] = k * batch / (max(t1 for _, t1 in spans) - min(t0 for t0, _ in spans))
+            rates[(k, thr)] = k * pb / (max(t1 for _, t1 in spans) - min(t0 for t0, _ in spans))
+            if rates[(k, thr)] < prev_rate:                # past the host's optimum (memory-bound): more processes only get slower
+                break
+            prev_rate = rates[(k, thr)]
         except Exception:
             for p_ in procs:
                 if p_.poll() is None:
@@ -340,7 +345,7 @@ def cpu_baseline(batch=64, budget_s=150.0):
             shutil.rmtree(d, ignore_errors=True)
     best = max(rates, key=rates.get)
     return dict(value=rates[best], unit="query images/sec", cores=best[0] * best[1], kind="port", processes=best[0], threads_per_process=best[1],
-                sample=f"one batch of {batch} images per process through the oracle (fp32 ViT-B/16 encode_image + conv-3x adapter + P), processes x torch threads on "
+                sample=f"one batch per process (64 images in-process, 256 / k per worker, >= 16) through the oracle (fp32 ViT-B/16 encode_image + conv-3x adapter + P), processes x torch threads on "
                        f"disjoint logical-CPU ranges, host-level img/s: {', '.join(f'{k}x{t}: {v:.1f}' for (k, t), v in rates.items())}; host has {ncpu} logical cores; "
                        f"the reference module itself measured 14.2 img/s on 8 threads at survey time (SURVEY.md section 6)")
 
