@@ -462,8 +462,9 @@ __device__ __forceinline__ void mainloop_sr(const TP& tp, int nt, char* smem, Ac
 // (Measured and removed, round 4, profiles/r04_ab_drain.txt item 5: EVERY fragment of the K-tile read behind the top barrier (96 registers), ONE barrier that frees
 // the whole buffer, waves 0 - 3 issuing their eight pieces right behind it and waves 4 - 7 a group and a half later — each burst beside >= 32 MFMAs of
 // the SIMD partner with no barrier in between.  A timeline model with independent MFMA / vector-memory issue predicts -20 % per K-tile; measured,
-// bit-identical: in_proj +1 %, c_fc +3 %, the residual instantiations +6 ... +10 % (108 B of scratch).  A wave's LDS-DMA issue is NOT hidden by its SIMD
-// partner's MFMAs, whatever the barrier structure.)
+// bit-identical: in_proj +1 %, c_fc +3 %, the residual instantiations +6 ... +10 % (108 B of scratch): the 24 up-front fragment reads (768 LDS cycles for the
+// workgroup) and the late first burst cost what the freed barrier saves.  tools/probe/issue_overlap_probe.hip (profiles/r04_issue_overlap_probe.txt) shows the chip itself
+// overlaps the pieces with MFMAs at + 6 % when nothing couples them; a barrier between the roles' bursts costs + 18 %.)
 // (Measured and removed, profiles/r03_ab_gemm_sched.txt: the same loop software-pipelined ACROSS the K-tile boundary — the barrier that
 // publishes K-tile t + 1 moved in front of the last MFMA group of iteration t and the first fragments of t + 1 requested under that
 // group, so that an iteration starts issuing MFMAs at once.  Bit-identical and 4 - 6 % SLOWER: waiting for K-tile t + 1 a quarter of an
