@@ -225,6 +225,55 @@ void run_role(const char* name, const char* src, size_t region, float* sink) {
     printf("%-110s %8.1f ns per iteration\n", name, ms * 1e6 / iters);
 }
 
+// ---- what a THREE-stage 256 x 128 tile would run per K-tile: 32 MFMAs + 6 pieces per wave (48 KB per CU), ONE barrier, K-tile t + 2 requested at the top of t
+// (waves 0 - 3) / after 16 MFMAs (waves 4 - 7); two of these = the FLOPs of one 256 x 256 K-tile (R0 above)
+template <int INFLIGHT>
+__global__ __launch_bounds__(512, 2) void w3_probe(const char* __restrict__ src, size_t region, float* __restrict__ sink, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    half8_t a = {1, 2, 3, 4, 5, 6, 7, 8}, b = {8, 7, 6, 5, 4, 3, 2, 1};
+    for (int i = 0; i < 8; ++i) { a[i] += (_Float16)(lane & 3); b[i] -= (_Float16)(lane & 1); }
+    float4_t acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = float4_t{0.f, 0.f, 0.f, 0.f};
+    const unsigned mask = (unsigned)(region - 1), cu_off = (unsigned)(((size_t)blockIdx.x * 8 + wave) * (region / 2048)) & mask;
+    auto burst = [&](int it) {
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            const unsigned off = (cu_off + ((unsigned)(it * 6 + g) * 64 + lane) * 16) & mask;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + off), (lds_ptr_t)(smem + (wave * 6 + g) * 1024), 16, 0, 0);
+        }
+    };
+    auto mf16 = [&]() {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[i], 0, 0, 0);
+    };
+    for (int it = 0; it < iters; ++it) {
+        __builtin_amdgcn_s_waitcnt((INFLIGHT & 15) | (7 << 4) | (15 << 8) | ((INFLIGHT >> 4) << 14));
+        __builtin_amdgcn_s_barrier();
+        if (wave < 4) burst(it);
+        mf16();
+        if (wave >= 4) burst(it);
+        mf16();
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3];
+    sink[blockIdx.x * 512 + tid] = s;
+}
+template <int INFLIGHT>
+void run_w3(const char* name, const char* src, size_t region, float* sink) {
+    const int iters = 4000, grid = 256;
+    hipFuncSetAttribute((const void*)w3_probe<INFLIGHT>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    w3_probe<INFLIGHT><<<grid, 512, 128 * 1024>>>(src, region, sink, 50);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    w3_probe<INFLIGHT><<<grid, 512, 128 * 1024>>>(src, region, sink, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-110s %8.1f ns per iteration, %8.1f ns per 256 x 256 K-tile equivalent\n", name, ms * 1e6 / iters, 2 * ms * 1e6 / iters);
+}
+
 int main() {
     const size_t big = (size_t)512 << 20, small = (size_t)4 << 20;
     char *src, *dst; unsigned long long* cyc; float* sink;
@@ -253,6 +302,11 @@ int main() {
     run_role<1, 8>("R1  asymmetric:   16 | b2 | X burst+16 / Y 32 | b3 | X 32 / Y burst+16  (L2-resident 4 MB)", src, small, sink);
     run_role<0, 8>("R2  present form, 64 MB source (Infinity Cache)", src, (size_t)64 << 20, sink);
     run_role<1, 8>("R3  asymmetric,   64 MB source (Infinity Cache)", src, (size_t)64 << 20, sink);
+    printf("---- a three-stage 256 x 128 tile (one barrier, two K-tiles of lead): 32 MFMAs + 6 pieces per wave and iteration\n");
+    run_w3<6>("W1  L2-resident 4 MB, one K-tile in flight beyond the awaited one", src, small, sink);
+    run_w3<12>("W2  L2-resident 4 MB, two in flight", src, small, sink);
+    run_w3<6>("W3  64 MB source (Infinity Cache), one in flight", src, (size_t)64 << 20, sink);
+    run_w3<12>("W4  64 MB source (Infinity Cache), two in flight", src, (size_t)64 << 20, sink);
     printf("---- delivery rate of the LDS-DMA path by bytes in flight / source size / active CUs (burst at the top, no barrier; 64 KB per CU and iteration)\n");
     run_sym<1, 0, 16>("D1  L2-resident 4 MB, TWO iterations in flight (128 KB per CU)", src, small, sink);
     run_sym<1, 0, 24>("D2  L2-resident 4 MB, THREE iterations in flight", src, small, sink);
