@@ -9,8 +9,9 @@ for name, B in (("ViT-B/32", 1024), ("ViT-B/16", 1024), ("ViT-L/14", 512), ("RN5
     model = build_model(random_state_dict(seed=1, **kw)).cuda()
     x = torch.randn(B, 3, kw["image_resolution"], kw["image_resolution"], device="cuda")
     with torch.no_grad():
-        model.encode_image(x); torch.cuda.synchronize()
-        t0 = time.perf_counter(); n = 3
+        for _ in range(3): model.encode_image(x)          # (one warm-up pass was not enough: RN50 once read 9.7 ms instead of 6.9, profiles/r04_ab_attention16.txt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); n = 10
         for _ in range(n): model.encode_image(x)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     print(f"{name:9s} batch {B:5d}: {1e3*dt:8.1f} ms  {B/dt:9.0f} img/s  {B/dt*GF[name]/1e3:7.0f} TFLOP/s-equivalent", flush=True)
