@@ -1208,7 +1208,10 @@ __device__ __forceinline__ void attn_store_tile(half_t* orow, const float16_t (&
 // General operand form: queries q [B][Lq rows, row stride ldq] (the FIRST Lq tokens of each sequence), keys / values in
 // kv [B*L rows, row stride ldkv] at column offsets k_off / v_off; the fused-QKV case is q = kv = qkv, ldq = ldkv = 3W,
 // k_off = W, v_off = 2W, Lq = L.  Lq < L serves the last vision block, whose output is only read at the class token.
-template <int NW, int VAR>   // waves per workgroup (__launch_bounds__'s second argument = waves per SIMD: two workgroups per CU); softmax variant
+// QF (round 4): every wave has AT MOST ONE query tile (the host guarantees ceil(Lq / 32) <= NW) and requests its query fragments BEFORE the K / V stages, so
+// their round trip passes under the staging instead of opening the compute phase behind the barrier: ViT-B/16 354 -> 320 us stand-alone, same bits
+// (profiles/r04_ab_attention_qfirst.txt).  Not for waves that loop over several tiles (ViT-L/14: + 6 %) nor the short causal text sequences (+ 7 %).
+template <int NW, int VAR, bool QF = false>   // waves per workgroup (__launch_bounds__'s second argument = waves per SIMD: two workgroups per CU); softmax variant
 __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const half_t* __restrict__ qp, int ldq, long q_batch,
                                                            const half_t* __restrict__ kvp, int ldkv, int k_off, int v_off,
                                                            half_t* __restrict__ out, int L, int Lq, int H, int causal, int NT,
@@ -1223,6 +1226,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const half_t
     const half_t* vbase = kvp + (size_t)b * L * ldkv + h * ATT_DH + v_off;
     const half_t* qbase = qp + (size_t)b * q_batch + h * ATT_DH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    half8_t qf0[4];
+    if (QF) {
+        const int q0 = wave * 32 + (lane & 31), qc0 = q0 < Lq ? q0 : Lq - 1;
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) qf0[s_] = ld_half8(qbase + (size_t)qc0 * ldq + s_ * 16 + (lane >> 5) * 8);
+    }
 
     // K: global_load_lds, 8 rows x 128 B per wave instruction, swizzle on the source chunk (as the GEMM tiles)
     for (int r0 = wave * 8; r0 < LP; r0 += NW * 8) {
@@ -1248,28 +1257,27 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const half_t
     int voff[2];
     attn_voff(lane, voff);
     const int NTq = (Lq + 31) >> 5;
+    auto process = [&](int qb, const half8_t (&qf)[4]) {
+        const int q = qb * 32 + ql;
+        float16_t o[2];
+        float lrun;
+        attn_query_tile<false, VAR>(Ks, Vs, qf, q, qb, L, causal, NT, hi, ql, voff, o, lrun);
+        attn_store_tile(out + ((size_t)b * Lq + q) * W + h * ATT_DH, o, lrun, hi, q < Lq);
+    };
+    if (QF) {
+        if (wave < NTq) process(wave, qf0);
+        return;
+    }
     for (int qb = wave; qb < NTq; qb += NW) {
         const int q = qb * 32 + ql;                     // this lane's query row
         const int qc = q < Lq ? q : Lq - 1;
         half8_t qf[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[s] = ld_half8(qbase + (size_t)qc * ldq + s * 16 + hi * 8);
-        float16_t o[2];
-        float lrun;
-        attn_query_tile<false, VAR>(Ks, Vs, qf, q, qb, L, causal, NT, hi, ql, voff, o, lrun);
-        attn_store_tile(out + ((size_t)b * Lq + q) * W + h * ATT_DH, o, lrun, hi, q < Lq);
+        process(qb, qf);
     }
 }
 
-// (Measured and removed, round 4, profiles/r04_ab_attention16.txt — VERDICT r3 #3 "buy occupancy": the same attention on SIXTEEN-query tiles
-// (v_mfma_f32_16x16x32_f16: S^T as 16 x 16 tiles, lane = query l & 15 / keys 16 m + 4 q + r; the probabilities of a 32-key tile feed the second contraction as
-// its B operand in the k-slot order {4 q .. 4 q + 3} of both 16-key halves, V^T by two transpose reads in the same order; row maximum combined over the four
-// lanes of a query by v_permlane16/32_swap, the row sum once at the end): 60 VGPRs with one key tile per step (84 with two; forced to 72: 44 B of scratch),
-// 13-wave workgroups (208 >= 197 queries), two per CU = 26 waves = 6.5 per SIMD against 3.5 active now.  Correct on the first run (error against fp32
-// attention unchanged) and SLOWER: ViT-B/16 377 us (one tile per step) / 437 - 465 us (two) against 350 us for the 32-query kernel in the same
-// harness; ViT-L/14 195 / 200 vs 186; text (causal, L = 77) 524 / 499 - 504 vs 526; ViT-B/32 level.  Every wave reads ALL of K and V from LDS: with half
-// the queries per wave the fragment traffic per query doubles (741 KB per (image, head) through the LDS), and so do the per-tile reductions — the occupancy
-// is there (60 registers) and does not pay for them.)
 // ---- persistent, double-buffered form of the same attention (whole batches) --------------------------------------------------
 // attention_kernel is a chain of dependent phases per (image, head): K/V by LDS-DMA -> barrier -> query loads -> compute -> stores,
 // and two co-resident workgroups fall into lockstep, so the memory pipe idles while the SIMDs work and vice versa (ablation,
@@ -2284,7 +2292,7 @@ extern "C" int pclip_attention_q_f16(const void* q, int ldq, long q_batch_stride
     static DevOnce attr_set;
     if (!attr_set.done()) {
         const void* fns[] = {(const void*)attention_kernel<8, PCLIP_ATT_VAR_LONG>, (const void*)attention_kernel<4, PCLIP_ATT_VAR_LONG>,
-                             (const void*)attention_kernel<4, PCLIP_ATT_VAR_SHORT>};
+                             (const void*)attention_kernel<4, PCLIP_ATT_VAR_SHORT>, (const void*)attention_kernel<8, PCLIP_ATT_VAR_LONG, true>};
         for (const void* f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) {
                 pclip_set_error("pclip_attention_f16: cannot raise the dynamic LDS limit");
@@ -2298,7 +2306,11 @@ extern "C" int pclip_attention_q_f16(const void* q, int ldq, long q_batch_stride
 #define PCLIP_ATT_LAUNCH(NW, VAR)                                                                                                         \
     attention_kernel<NW, VAR><<<B * H, NW * 64, lds, (hipStream_t)stream>>>((const half_t*)q, ldq, q_batch_stride, (const half_t*)kv, ldkv, k_off, \
                                                                              v_off, (half_t*)out, L, Lq, H, causal, NT, LV)
-    if ((Lq + 31) / 32 > 4) PCLIP_ATT_LAUNCH(8, PCLIP_ATT_VAR_LONG);
+    static const bool qfirst = !(getenv("PCLIP_ATT_QFIRST") && getenv("PCLIP_ATT_QFIRST")[0] == '0');      // A/B switch
+    if ((Lq + 31) / 32 > 4 && (Lq + 31) / 32 <= 8 && qfirst)
+        attention_kernel<8, PCLIP_ATT_VAR_LONG, true><<<B * H, 8 * 64, lds, (hipStream_t)stream>>>((const half_t*)q, ldq, q_batch_stride, (const half_t*)kv, ldkv, k_off,
+                                                                                                    v_off, (half_t*)out, L, Lq, H, causal, NT, LV);
+    else if ((Lq + 31) / 32 > 4) PCLIP_ATT_LAUNCH(8, PCLIP_ATT_VAR_LONG);
     else if (NT > 4) PCLIP_ATT_LAUNCH(4, PCLIP_ATT_VAR_LONG);
     else PCLIP_ATT_LAUNCH(4, PCLIP_ATT_VAR_SHORT);
 #undef PCLIP_ATT_LAUNCH
