@@ -1011,7 +1011,9 @@ __device__ __forceinline__ float half_wave_sum(float v) { float a, b; half_wave_
 // DEEP (the persistent kernel: two waves per SIMD, registers to spare): the K fragments of the NEXT pair of key tiles and the
 // V^T fragments of THIS pair are requested right after the pair's score MFMAs, so their LDS latency passes under the softmax
 // arithmetic instead of in front of every MFMA (+64 VGPRs).  Same operations in the same order per accumulator: same bits.
-template <bool DEEP = false, int VAR = 0>
+// VBAR: the caller has only made K visible so far (V is still landing); the first pair of key tiles waits for V — own pieces, then a workgroup barrier —
+// between its softmax and its second contraction, so V's arrival passes under the first scores.  Every wave of the workgroup must pass that barrier once.
+template <bool DEEP = false, int VAR = 0, bool VBAR = false>
 __device__ __forceinline__ void attn_query_tile(const half_t* Ks, const half_t* Vs, const half8_t (&qf)[4], int q, int qb, int L, int causal,
                                                 int NT, int hi, int ql, const int (&voff)[2], float16_t (&o)[2], float& lrun_out) {
 #pragma unroll
@@ -1146,6 +1148,7 @@ __device__ __forceinline__ void attn_query_tile(const half_t* Ks, const half_t* 
         }
         lrun += psum;
         mrun = mnew;
+        if (VBAR && t0 == 0) { pgemm::wait_vm<0>(); pgemm::lds_barrier(); }
 #pragma unroll
         for (int u = 0; u < NTILE; ++u)
 #pragma unroll
@@ -1208,9 +1211,10 @@ __device__ __forceinline__ void attn_store_tile(half_t* orow, const float16_t (&
 // General operand form: queries q [B][Lq rows, row stride ldq] (the FIRST Lq tokens of each sequence), keys / values in
 // kv [B*L rows, row stride ldkv] at column offsets k_off / v_off; the fused-QKV case is q = kv = qkv, ldq = ldkv = 3W,
 // k_off = W, v_off = 2W, Lq = L.  Lq < L serves the last vision block, whose output is only read at the class token.
-// QF (round 4): every wave has AT MOST ONE query tile (the host guarantees ceil(Lq / 32) <= NW) and requests its query fragments BEFORE the K / V stages, so
-// their round trip passes under the staging instead of opening the compute phase behind the barrier: ViT-B/16 354 -> 320 us stand-alone, same bits
-// (profiles/r04_ab_attention_qfirst.txt).  Not for waves that loop over several tiles (ViT-L/14: + 6 %) nor the short causal text sequences (+ 7 %).
+// QF (round 4): every wave has AT MOST ONE query tile (the host guarantees ceil(Lq / 32) <= NW, hence LP <= 256: at most four pieces per wave and operand) and
+// requests its query fragments BEFORE the K / V stages, so their round trip passes under the staging instead of opening the compute phase behind the barrier
+// (ViT-B/16 354 -> 320 us stand-alone); and the workgroup barrier only waits for K — V is awaited (own pieces + a second LDS-only barrier) between the first
+// pair of key tiles' softmax and its second contraction (-> 303 us).  Same bits (profiles/r04_ab_attention_qfirst.txt).  Not for waves that loop over several tiles (ViT-L/14: + 6 %) nor the short causal text sequences (+ 7 %).
 template <int NW, int VAR, bool QF = false>   // waves per workgroup (__launch_bounds__'s second argument = waves per SIMD: two workgroups per CU); softmax variant
 __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const half_t* __restrict__ qp, int ldq, long q_batch,
                                                            const half_t* __restrict__ kvp, int ldkv, int k_off, int v_off,
@@ -1251,7 +1255,18 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const half_t
         __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(vbase + (size_t)rc * ldkv + c * 8),
                                          (pgemm::lds_ptr_t)(Vs + r0 * ATT_DH), 16, 0, 0);
     }
-    __syncthreads();
+#ifndef PCLIP_ATT_VBAR
+#define PCLIP_ATT_VBAR 1          // QF kernels: barrier on K alone, V awaited between the first scores and the first second contraction (334.7 -> 303.5 us stand-alone, same bits)
+#endif
+    constexpr bool VB = PCLIP_ATT_VBAR && QF;
+    if (VB) {
+        // the wave's V pieces (the youngest operations: rows wave * 8 + 64 k < LP, two to four of them) stay in flight: K and the query fragments have landed
+        // once no more than those are outstanding
+        const int nv = (LP - wave * 8 + NW * 8 - 1) / (NW * 8);
+        if (nv <= 2) pgemm::wait_vm<2>(); else if (nv == 3) pgemm::wait_vm<3>(); else pgemm::wait_vm<4>();
+        pgemm::lds_barrier();
+    } else
+        __syncthreads();
 
     const int hi = lane >> 5, ql = lane & 31;
     int voff[2];
@@ -1261,11 +1276,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(const half_t
         const int q = qb * 32 + ql;
         float16_t o[2];
         float lrun;
-        attn_query_tile<false, VAR>(Ks, Vs, qf, q, qb, L, causal, NT, hi, ql, voff, o, lrun);
+        attn_query_tile<false, VAR, VB>(Ks, Vs, qf, q, qb, L, causal, NT, hi, ql, voff, o, lrun);
         attn_store_tile(out + ((size_t)b * Lq + q) * W + h * ATT_DH, o, lrun, hi, q < Lq);
     };
     if (QF) {
         if (wave < NTq) process(wave, qf0);
+        else if (VB) { pgemm::wait_vm<0>(); pgemm::lds_barrier(); }      // the barrier inside the first pair of key tiles
         return;
     }
     for (int qb = wave; qb < NTq; qb += NW) {
