@@ -207,6 +207,15 @@ int pclip_layernorm_f16(const void* x, int ld_x, const float* gamma, const float
 int pclip_gemm_res_stats_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* bias,
                              const void* residual, float* partials, pclip_stream_t stream);
 int pclip_row_stats_finalize(const float* partials, int R, int D, float eps, float* stats, pclip_stream_t stream);
+/* The two statements of a ResidualAttentionBlock that follow each other without a choice (clip/model.py:188-189 and the LayerNorm the next linear reads:
+ * ln_2 behind `x = x + attention(..)`, the next block's ln_1 behind `x = x + mlp(..)`) as ONE launch, with the reference's rounding points:
+ *   C [M, N] fp16 (row stride ldc) = r16(C + r16(A B^T + bias))   in place,   y [M, N] fp16 (contiguous) = r16(LayerNorm(C) gamma + beta), fp32 statistics.
+ * The GEMM's workgroups count their finished tiles per row panel and the one that completes a panel normalises its rows while they are still on the chip:
+ * there is no LayerNorm pass over x (620 MB of HBM traffic per call at the bench's size).  Bit-identical to pclip_gemm_f16(.., residual = C) followed by
+ * pclip_layernorm_f16 — which is what runs when the shape has no fused form (few tiles, N > 1024, K = 64), when panel_counters is NULL, or under PCLIP_RES_LN=0.
+ * panel_counters: M / 128 + 2 ints of device memory, ZERO on entry, zero again when the call has executed (one array per stream that calls this). */
+int pclip_gemm_res_ln_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* bias,
+                          const float* gamma, const float* beta, float eps, void* y, int32_t* panel_counters, pclip_stream_t stream);
 int pclip_ln_fold_weights_f16(const void* W, int ldw, int N, int K, const float* gamma, const float* beta, const void* bias,
                               void* Wf, float* colsum, float* bfold, pclip_stream_t stream);
 int pclip_row_stats_f16(const void* x, int ld_x, float eps, float* stats, int R, int D, pclip_stream_t stream);

@@ -74,6 +74,10 @@ LN_FOLD = os.environ.get("PCLIP_LN_FOLD", "0") == "1"
 # ... and the row statistics come out of the epilogue of the residual GEMM that writes x (ops.gemm_res_stats) instead of a pass
 # over x; PCLIP_LN_STATS_EPI=0 keeps the separate pass (same values bit for bit).
 STATS_IN_EPILOGUE = os.environ.get("PCLIP_LN_STATS_EPI", "1") != "0"
+# Unfolded path, PCLIP_RES_LN_FUSE=1: the LayerNorm that follows a residual add (ln_2, the next block's ln_1) is computed inside the launch of that add's GEMM, by
+# the workgroup that owns the finished row panel (ops.gemm_res_ln) — the same bits as the two launches, no LayerNorm pass over x.  Off by default: measured 1.2 %
+# SLOWER in the bench (profiles/r04_ab_res_ln.txt: the rows' LayerNorm arithmetic is VALU-bound on the GEMM's eight waves per CU, 17 us per 256-row panel).
+RES_LN = os.environ.get("PCLIP_RES_LN_FUSE", "0") == "1"
 
 
 # block -> {linear name: (tag, folded operands)}.  Kept OUTSIDE the modules (weak keys): the folded copies (~7 W^2 halves per
@@ -180,6 +184,9 @@ def _run_blocks(x, blocks, B, L, heads, causal, select=None, first_token=False, 
         if ln is not None and LN_FOLD and STATS_IN_EPILOGUE and not ops.splitk_active(x_.shape[0]):
             stats = ops.gemm_res_stats(a_, lin.weight, lin.bias, x_)       # the add, and the statistics of the updated rows with it
             return x_, (_Norm(x_, ln, stats=stats) if stats is not None else norm_of(x_, ln))
+        if ln is not None and RES_LN and not LN_FOLD:
+            # the residual add and the LayerNorm behind it in one launch (ops.gemm_res_ln): no pass over x between the two linears
+            return x_, _Norm(x_, ln, h=ops.gemm_res_ln(a_, lin.weight, lin.bias, x_, ln.weight, ln.bias))
         ops.gemm(a_, lin.weight, lin.bias, residual=x_, out=x_)
         return x_, norm_of(x_, ln)
 

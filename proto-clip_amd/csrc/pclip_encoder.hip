@@ -15,6 +15,7 @@ using CfgBigT = pgemm::Cfg<256, 256, 2, 4>;
 // Rounding points follow the reference's fp16 tensors: r16(acc + bias); QuickGELU as three fp16
 // elementwise ops (clip/model.py:166); residual add rounds once more (clip/model.py:188-189).
 typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
 struct LinearEpi {
     const half_t* __restrict__ bias;
     const half_t* __restrict__ residual;
@@ -25,7 +26,14 @@ struct LinearEpi {
     const float* __restrict__ shift;  //                                                           act 7 / 8: folded bias
     const float* __restrict__ rowstats = nullptr;   // act 7 / 8: (mean, rstd) per row of A, [round_up(M, 256) + 256][2] fp32
     float* __restrict__ partials = nullptr;         // act 9: (sum, sum of squares) per row and 64 output columns, [M][N / 64][2] fp32
+    // act 10 = act 6 + y = LayerNorm(updated rows) by the workgroup that completes a row panel (see linear_fast_kernel)
+    const float* ln_gamma = nullptr;
+    const float* ln_beta = nullptr;
+    half_t* ln_y = nullptr;                         // [M][N], contiguous rows
+    int* ln_cnt = nullptr;                          // arrival counters, one per 128 rows of C, zero before and after every launch
+    float ln_eps = 0.f;
 };
+struct LnPanel { const float* gamma; const float* beta; half_t* y; int* cnt; float eps; };
 
 // LayerNorm folded into the linear that consumes it (act 7; 8 = + QuickGELU):  LN(x) W^T + b with LN(x) = (x - mu) rstd g + beta
 //   = rstd (x (g . W)^T - mu colsum(g . W)) + (beta W^T + b):  the GEMM runs on the UN-normalised rows x against the folded weight
@@ -127,6 +135,93 @@ __device__ __forceinline__ half4_t quick_gelu16x4(float4_t v) {
     return half4_t{y01[0], y01[1], y23[0], y23[1]};
 }
 
+// The two places of a LayerNorm row where a multiply is followed by an add: hipcc contracted them into an fma in some instantiations and not in others (NCH = 1 and
+// NCH = 2 of the SAME source differed — one fp16 ulp on 1e-5 of the elements — as soon as the code around them changed), and "a row alone == the row in a batch"
+// needs every LayerNorm kernel to round alike.  Spelled out, contraction off: the squared deviations accumulate by fma, the affine is two rounded multiplies and a
+// rounded add (what the D = 768 / 1024 instantiations had compiled to).
+__device__ __forceinline__ float ln_sq_acc(float t, float q) { return __builtin_fmaf(t, t, q); }
+__device__ __forceinline__ float ln_affine_dev(float t, float rstd, float g, float b) {      // t = v - mean
+#pragma clang fp contract(off)
+    return (t * rstd) * g + b;
+}
+__device__ __forceinline__ float ln_affine(float v, float mean, float rstd, float g, float b) { return ln_affine_dev(v - mean, rstd, g, b); }
+
+// ... and its last four levels (lane ^ 8, ^ 4, ^ 2, ^ 1: inside a DPP row of 16 lanes) on their own
+__device__ __forceinline__ float row16_sum_x(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int i = __builtin_bit_cast(int, v);
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x128, 0xF, 0xF, false));            // row_ror:8: lane ^ 8
+    i = __builtin_bit_cast(int, v);
+    int t = __builtin_amdgcn_update_dpp(i, i, 0x104, 0xF, 0x5, false);                                         // row_shl:4 into lanes 0-3, 8-11 of a row: lane + 4
+    t = __builtin_amdgcn_update_dpp(t, i, 0x114, 0xF, 0xA, false);                                             // row_shr:4 into lanes 4-7, 12-15: lane - 4
+    v = v + __builtin_bit_cast(float, t);
+    i = __builtin_bit_cast(int, v);
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x4E, 0xF, 0xF, false));             // quad_perm [2,3,0,1]: lane ^ 2
+    i = __builtin_bit_cast(int, v);
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0xB1, 0xF, 0xF, false));             // quad_perm [1,0,3,2]: lane ^ 1
+#endif
+    return v;
+}
+
+// wave_sum(v) — v += v[lane ^ 32], ^ 16, ^ 8, ^ 4, ^ 2, ^ 1 in that order — without its six ds_bpermute round trips through the LDS crossbar: the same additions
+// (a + b is commutative, so every lane forms the same values level by level: same bits) on the VALU: v_permlane32_swap, v_permlane16_swap, DPP row_ror:8,
+// two bank-masked DPP row shifts for ^ 4 (gfx9 has no row_xmask), quad_perm for ^ 2 and ^ 1.
+__device__ __forceinline__ float wave_sum_x(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+        const unsigned a = __builtin_bit_cast(unsigned, v);
+        const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+        v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
+    {
+        const unsigned a = __builtin_bit_cast(unsigned, v);
+        const auto r = __builtin_amdgcn_permlane16_swap(a, a, false, false);
+        v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
+#endif
+    return row16_sum_x(v);
+}
+
+// One row of the whole-batch LayerNorm: the lane's chunks `cur` (eight halves per 512-column chunk) -> `out`; affine(c, j) returns (gamma, beta) of column
+// c * 512 + lane * 8 + j.  ONE definition for layernorm_pf_kernel and for the row-panel LayerNorm inside the residual GEMM (linear_fast_kernel act 10): same
+// operations in the same order, so both produce the same bits (tests/test_gpu_encoder.py::test_gemm_res_ln_equals_two_launches).
+template <int NCH, class Affine>
+__device__ __forceinline__ void ln_row_pf(const half8_t (&cur)[NCH], int D, int lane, float eps, const Affine& affine, half8_t (&out)[NCH]) {
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c * 512 + lane * 8 < D) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[c][j] = (float)cur[c][j]; s += v[c][j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+        }
+    }
+    const float mean = wave_sum_x(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+        if (c * 512 + lane * 8 < D) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float t = v[c][j] - mean; q = ln_sq_acc(t, q); }
+        }
+    const float rstd = 1.f / sqrtf(wave_sum_x(q) / (float)D + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c * 512 + lane * 8 < D) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float2_t gb = affine(c, j);
+                float t = ln_affine(v[c][j], mean, rstd, gb[0], gb[1]);
+                t = r16(t);
+                out[c][j] = (half_t)t;
+            }
+        }
+    }
+}
+
 // Output rows of the persistent linear kernels: non-temporal 16-byte stores (A/B switch PCLIP_NT_STORE) — a c_fc launch writes
 // 1.2 GB that nobody re-reads before it has left the 4 MiB L2 anyway; keeping it out leaves the L2 to the operand panels.
 #ifndef PCLIP_NT_STORE
@@ -138,6 +233,17 @@ __device__ __forceinline__ void st_out(half_t* p, half8_t v) {
     __builtin_nontemporal_store(__builtin_bit_cast(f32x4_t, v), reinterpret_cast<f32x4_t*>(p));
 #else
     st_half8(p, v);
+#endif
+}
+
+// act 10: the updated residual rows are read again by ANOTHER workgroup (possibly on another XCD, whose L2 is not coherent with this one's) inside the same launch:
+// device-scope write-through stores (sc1) put them where every XCD sees them once the store has completed (vmcnt).
+// (Inline assembly because no builtin stores 16 bytes with a scope.  hipcc's hazard recogniser does not look inside the statement: a VALU write to the data registers of a
+// store of more than 8 bytes needs two wait states behind it on gfx940+, and the compiler re-used them in the very next instructions — every 16-byte chunk's first dword
+// came out as an address fragment.  Hence the s_nop 1.)
+__device__ __forceinline__ void st_out_dev(half_t* p, half8_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v));
 #endif
 }
 
@@ -159,7 +265,17 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
                                                                      half_t* Cout, int ldc, int tiles_n,
                                                                      int ntiles, const half_t* residual = nullptr,
                                                                      const float* __restrict__ rowstats = nullptr,
-                                                                     float* __restrict__ partials = nullptr, int band = 0) {
+                                                                     float* __restrict__ partials = nullptr, int band = 0,
+                                                                     LnPanel lnp = LnPanel{}) {
+    // ACT 10: ACT 6, and the LayerNorm that follows the residual add in a transformer block (clip/model.py:188-189: ln_2 behind `x + attn`, the next block's ln_1
+    // behind `x + mlp`) WITHOUT a pass of its own over x: a row panel (BM rows x N) is complete when its N / BN tiles — computed by as many workgroups at about the same
+    // time, which is what lets them share the A rows in L2 — have all been stored; every workgroup counts its finished tiles into the panel's counter (device-scope
+    // atomic), and the one whose increment completes the panel normalises the panel's rows: it reads them back (device-scope loads; they are a few tens of microseconds
+    // old and still on the chip) and writes y with ordinary streaming stores that drain while the launch multiplies on.  The separate pass was bound by HBM (620 MB at
+    // 6 TB/s = 102 us); here the 310 MB of reads never reach HBM and the writes overlap the K-loops.  Row arithmetic = ln_row_pf, the pass's own: same bits.
+    // No workgroup ever WAITS for another (nothing spins), so there is no forward-progress assumption.  A tile is counted two tiles late — after the K-loop of the
+    // NEXT tile, whose last iteration drained the vector-memory counter of every wave (wait_vm<0> + barrier), i.e. without a wait of its own for the stores — and the
+    // returned count is looked at another tile later; the last two tiles of a workgroup are settled behind the loop.
     // ACT 5: relu(r16(r16(r16(acc) * scale + shift) + residual)) — bn3 + `out += identity` + ReLU of a bottleneck (clip/model.py:49-52)
     // in the epilogue of its conv3 GEMM; the residual rows are read row-major in the coalesced store pass.
     // ACT 9: ACT 6 + the row-statistics partials of the updated rows (stats_chunk / stats_butterfly) into `partials` [M][N/64][2]
@@ -175,6 +291,13 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     constexpr int STRIP_BYTES = AFFINE ? 2 * 2 * C::BN * 4 : 2 * C::BN * 2;   // then 256 bytes of scrap for the L2 prefetch
     constexpr int NSTAT = LNF ? (C::BM * 8 + 1023) / 1024 : 0;                // LDS-DMA pieces of a tile's (mean, rstd) rows
     float* stats_lds = reinterpret_cast<float*>(smem + C::LDS_BYTES + STRIP_BYTES + 256);   // LNF: [2][BM][2] fp32
+    constexpr bool LNP = ACT == 10;
+    // LNP: [2][2] panels to normalise behind this tile's epilogue (-1: none) | thread 0's bookkeeping: [8] owned panels not yet complete, their number, the one whose
+    // count is on its way back | [12] + number: the panels settled behind the loop
+    int* lnp_flag = reinterpret_cast<int*>(smem + C::LDS_BYTES + STRIP_BYTES + 256);
+    int* lnp_own = lnp_flag + 4;
+    float* lnp_gb = reinterpret_cast<float*>(smem + C::LDS_BYTES + STRIP_BYTES + 256 + 128);   // LNP: [gamma | beta][plane][2 * 256] fp32 for the whole launch (layernorm_pf_kernel's layout)
+    constexpr int LNP_OQ = 8, LNP_NOWN = 8, LNP_CHK = 9, LNP_LIST = 10, LNP_NL = 22, LNP_ORPH = 1 << 16;
     const int G = gridDim.x;
     int tile = pgemm::xcd_remap(blockIdx.x, G);
     if (tile >= ntiles) return;
@@ -226,6 +349,13 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
                 __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(rowstats + ((size_t)tm * C::BM + i * 128 + lane * 2) * 2),
                                                  (pgemm::lds_ptr_t)(stats_lds + par * C::BM * 2 + i * 256), 16, 0, 0);
     };
+    if constexpr (LNP) {
+        for (int i = tid; i < 2 * 512; i += C::NTHREADS) {
+            const int pos = (i >> 9) * 256 + ((i & 511) >> 3) * 4 + (i & 3), plane = (i >> 2) & 1;
+            lnp_gb[plane * 2 * 256 + pos] = i < N ? lnp.gamma[i] : 0.f;
+            lnp_gb[(2 + plane) * 2 * 256 + pos] = i < N ? lnp.beta[i] : 0.f;
+        }
+    }
     if (HAS_BIAS || AFFINE) {
         if (AFFINE) copy_affine(tile, 0); else copy_bias(tile, 0);
         if (LNF) copy_stats(tile, 0);
@@ -243,6 +373,132 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     constexpr int YOUNGER = C::NH * C::NPASS * (1 + PST) + (AFFINE ? 2 : (HAS_BIAS ? 1 : 0)) + NSTAT;
     bool prev_full = false;
     int parity = 0;
+    // LNP: `stored` = panel of the tile whose stores are in flight (not yet counted), `counted` = panel of the tile whose count is on its way back in `ticket` (thread 0)
+    int stored = -1, counted = -1, ticket = 0, chkv = 0;
+    if (LNP && tid == 0) { lnp_own[LNP_NOWN] = 0; lnp_own[LNP_CHK] = -1; }
+    // WHO normalises a complete panel.  "The workgroup whose count completes it" piles the work up: a workgroup that has normalised one panel is late from then on, so
+    // it is the last to arrive at its following panels too and normalises those as well (measured: 0 - 7 panels per workgroup, the launch as slow as the busiest).  So
+    // every panel has an OWNER — the workgroup that computes one designated tile of it (below), a third of everybody's tiles at N = 768 — which looks at
+    // the counter of its oldest unfinished panel once per tile (a device-scope load, requested behind one K-loop and read behind the next) and normalises the panel
+    // once it reads the full count.  Still nobody waits: behind its last tile an owner adds LNP_ORPH to the counters of the panels it still holds — complete ones
+    // it normalises on the spot, incomplete ones are now ORPHANS, normalised by the workgroup whose count completes them (it sees the flag in the value its
+    // atomic returns).  The atomics on one counter are totally ordered, so exactly one of the two happens.
+    // (Which tile: in round r — r = (LAST tile of the panel) / G — the column tile (r (G % tiles_n + 1)) % tiles_n.  In the ascending order a workgroup's column
+    // tile advances by G % tiles_n per round, so it owns a panel exactly every tiles_n-th round: 3 of its 9 tiles at N = 768, nobody more.  With the round of the
+    // panel's FIRST tile the two workgroups at a round's seam owned 7 and 0.)
+    auto owner_tile = [&](int tm, int tn) { return tn == (((tm * tiles_n + tiles_n - 1) / G) * (G % tiles_n + 1)) % tiles_n; };
+    // rows of panel lp (complete: every tile of it has been counted) -> lnp.y.  No barrier: a wave reads x, the launch's gamma / beta copy in LDS, and writes y.
+    auto ln_panel = [&](int lp) {
+        if constexpr (LNP) {
+            constexpr int NCH = 2;                                      // 512 <= N <= 1024, N % 128 == 0 (launcher)
+            const float* gb = lnp_gb;
+            int lt = tid;                                             // opaque copy: the constants below are formed here, not hoisted across the K-loop (they spilled)
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(lt));
+#endif
+            const int ln = lt & 63;
+            const int r0 = lp * C::BM, rows = M - r0 < C::BM ? M - r0 : C::BM;
+            // FOUR rows per wave instruction: the 16 lanes of a DPP row own one row of x, lane p of them the columns of ln_row_pf's lanes p, p + 16, p + 32, p + 48
+            // ("slots" 0 - 3: 8 columns of the first 512 each, 8 more of the columns beyond for the slots those reach) — every lane is busy at N = 768 (a quarter
+            // idles in the one-row-per-wave form), the per-row scalars (two divisions, a square root) and the reductions cost a quarter, and a reduction is two
+            // in-lane levels + four DPP levels.  SAME BITS as ln_row_pf: a slot's partial sums run over its columns in ln_row_pf's order, and
+            // (P0 + P2) + (P1 + P3) followed by row16_sum_x is wave_sum's tree (levels ^ 32, ^ 16 pair slots, ^ 8 ... ^ 1 pair lanes of the row).
+            // Rows and columns beyond the panel / N fail the descriptors' bounds checks (loads answer zeros, stores are dropped): every quad issues the SAME eight
+            // loads and eight stores, so the waits are counted.  Loads: inline assembly, device scope (sc1) — issued through builtins hipcc serialised them with
+            // vmcnt(0); their destination registers are not touched before the counted wait and the pin behind it.
+            uint4_t rx;
+            pgemm::rsrc_t ry;
+#if defined(__HIP_DEVICE_COMPILE__)
+            {
+                const uint64_t ax = (uint64_t)(Cout + (size_t)r0 * ldc), ay = (uint64_t)(lnp.y + (size_t)r0 * N);
+                rx = uint4_t{(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ax), (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ax >> 32)) & 0xffffu,
+                             (uint32_t)__builtin_amdgcn_readfirstlane(rows * ldc * 2), 0x00020000u};
+                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)ay), hi = __builtin_amdgcn_readfirstlane((uint32_t)(ay >> 32));
+                ry = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(rows * N * 2), 0x00020000);
+            }
+#endif
+            constexpr int NIT = C::BM / (C::NWAVES * 4), NOP = 8;       // quads per wave; vector-memory operations of a quad (loads, and stores)
+            static_assert(C::BM % (C::NWAVES * 8) == 0, "quads are walked in pairs (two register buffers)");
+            const int ns1 = (N - 512) >> 7;                           // slots that reach beyond column 512 (uniform): 2 at N = 768
+            const int p16 = ln & 15, g4 = ln >> 4;
+            const float fN = (float)N;
+            half8_t bufa[8], bufb[8];
+            auto load = [&](half8_t (&h)[8], int it) {
+                const int r = (it * C::NWAVES + wave) * 4 + g4;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int d = (q >> 2) * 512 + ((q & 3) * 16 + p16) * 8;
+                    const int off = d < N ? (r * ldc + d) * 2 : 0x7ffffff0;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen sc1" : "=v"(h[q]) : "v"(off), "s"(rx));
+#endif
+                }
+            };
+            auto quad = [&](half8_t (&h)[8], int it) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(h[q]));                 // the values exist from here on (behind the wait)
+#endif
+                const int r = (it * C::NWAVES + wave) * 4 + g4;
+                float P[4];
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a += (float)h[sl][j];
+                    if (sl < ns1) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) a += (float)h[4 + sl][j];
+                    }
+                    P[sl] = a;
+                }
+                const float mean = row16_sum_x((P[0] + P[2]) + (P[1] + P[3])) / fN;
+                float t[8][8];
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { t[sl][j] = (float)h[sl][j] - mean; a = ln_sq_acc(t[sl][j], a); }
+                    if (sl < ns1) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { t[4 + sl][j] = (float)h[4 + sl][j] - mean; a = ln_sq_acc(t[4 + sl][j], a); }
+                    }
+                    P[sl] = a;
+                }
+                const float rstd = 1.f / sqrtf(row16_sum_x((P[0] + P[2]) + (P[1] + P[3])) / fN + lnp.eps);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int sl = q & 3, c = q >> 2, d = c * 512 + (sl * 16 + p16) * 8;
+                    half8_t o;
+                    if (c == 0 || sl < ns1) {
+                        const float* gp = gb + c * 256 + (sl * 16 + p16) * 4;
+                        const float4_t ga = *reinterpret_cast<const float4_t*>(gp), gc = *reinterpret_cast<const float4_t*>(gp + NCH * 256);
+                        const float4_t ba = *reinterpret_cast<const float4_t*>(gp + 2 * NCH * 256), bc = *reinterpret_cast<const float4_t*>(gp + 3 * NCH * 256);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            o[j] = (half_t)r16(ln_affine_dev(t[q][j], rstd, ga[j], ba[j]));
+                            o[j + 4] = (half_t)r16(ln_affine_dev(t[q][j + 4], rstd, gc[j], bc[j]));
+                        }
+                    }
+#if defined(__HIP_DEVICE_COMPILE__)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o), ry, d < N ? (r * N + d) * 2 : 0x7ffffff0, 0, PCLIP_NT_STORE ? 2 : 0);
+#endif
+                }
+            };
+            // issue order per wave: L0 L1 | quad 0, S0, L2 | quad 1, S1, L3 | ...: counted waits — first quad vmcnt(NOP) (only L1 is younger), middle quads
+            // vmcnt(2 NOP) (S(b-1) and L(b+1)), last quad vmcnt(NOP) (S(b-1))
+            load(bufa, 0);
+#pragma unroll 1
+            for (int it = 0; it < NIT; it += 2) {
+                load(bufb, it + 1);
+                if (it == 0) pgemm::wait_vm<NOP>(); else pgemm::wait_vm<2 * NOP>();
+                quad(bufa, it);
+                if (it + 2 < NIT) { load(bufa, it + 2); pgemm::wait_vm<2 * NOP>(); } else pgemm::wait_vm<NOP>();
+                quad(bufb, it + 1);
+            }
+            if (lt == 0) lnp.cnt[lp] = 0;                            // the counter is this workgroup's now: zero for the next launch
+        }
+    };
     for (; tile < ntiles; tile += G, parity ^= 1) {
         int tile_m, tile_n;
         decomp(tile, tile_m, tile_n);
@@ -275,6 +531,31 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         // DMAs wait in.)
         const int next = tile + G;
         pgemm::mainloop_sr<C, YOUNGER, !HAS_BIAS, TP>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane);
+        if constexpr (LNP) {
+            // K >= 2 K-tiles (launcher): the last iteration began with wait_vm<0> + barrier — every store of the previous tile, from every wave, has completed
+            if (tid == 0) {
+                // the count of tile i - 2 is back: did it complete a panel nobody owns any more?
+                lnp_flag[2 * parity] = counted >= 0 && (ticket & 0xffff) == tiles_n - 1 && (ticket & LNP_ORPH) ? counted : -1;
+                int no = lnp_own[LNP_NOWN], ck = lnp_own[LNP_CHK], f1 = -1;
+                if (ck >= 0 && (chkv & 0xffff) == tiles_n) {          // my oldest panel is complete (it cannot be an orphan: only I could have made it one)
+                    f1 = ck;
+                    for (int k = 0; k + 1 < no; ++k) lnp_own[k] = lnp_own[k + 1];
+                    --no;
+                }
+                lnp_flag[2 * parity + 1] = f1;
+                if (owner_tile(tile_m, tile_n)) {
+                    if (no < LNP_OQ) lnp_own[no++] = tile_m;
+                    else __hip_atomic_fetch_add(lnp.cnt + tile_m, LNP_ORPH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (list full: this tile is not counted yet, so the panel cannot be complete)
+                }
+                lnp_own[LNP_NOWN] = no;
+                if (stored >= 0) ticket = __hip_atomic_fetch_add(lnp.cnt + stored, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ck = no > 0 ? lnp_own[0] : -1;
+                if (ck >= 0) chkv = __hip_atomic_load(lnp.cnt + ck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lnp_own[LNP_CHK] = ck;
+            }
+            counted = stored;
+            stored = tile_m;
+        }
         if (next < ntiles) {                                  // buffer p is free: prefetch the next tile's K-tile 0
             int tm, tn;
             decomp(next, tm, tn);
@@ -342,10 +623,10 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         // the slab is staged (they fly during the LDS write pass) — Cout may alias residual (in-place residual stream), so the
         // compiler cannot hoist a later pass's load above an earlier pass's store by itself: load -> wait -> store per pass was
         // 16 dependent round trips per tile.
-        constexpr bool RES = ACT == 5 || ACT == 6 || ACT == 9;
+        constexpr bool RES = ACT == 5 || ACT == 6 || ACT == 9 || ACT == 10;
         // (measured, profiles/r03_ab_epilogue_pipe.txt: c_fc + QuickGELU 1001 -> 972 us; the bias-only and residual epilogues do not profit — their phases
         // are bound by the LDS write rate / the stores' address path / the residual loads' latency one after the other either way — and keep epilogue_f16)
-        constexpr bool PIPE = PCLIP_EPI_PIPE && (ACT == 1 || ACT == 8 || PCLIP_EPI_PIPE == 2) && C::BM == 256 && C::BN == 256 && C::WM == 2 && C::WN == 4;
+        constexpr bool PIPE = PCLIP_EPI_PIPE && (ACT == 1 || ACT == 8 || PCLIP_EPI_PIPE == 2) && !LNP && C::BM == 256 && C::BN == 256 && C::WM == 2 && C::WN == 4;
         half8_t rr[RES ? C::NPASS : 1];
         // PIPE: slab k = 32-row block k of both wave rows, four passes of 16 rows; its residual chunks go to rr[(k & 1) * 4 + ps], requested one interval ahead
         auto ahead = [&](int k) {
@@ -406,17 +687,45 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             pgemm::epilogue_f16<C, M16>(acc, stg, slab, pre, [&](int r, int c, int pass, half8_t h) {
                 const size_t o = (size_t)(m0 + r) * ldc + col;
                 if (RES) h = add_res(pass, h);
-                st_out(Cout + o, h);
+                if (LNP) st_out_dev(Cout + o, h); else st_out(Cout + o, h);
                 if (ACT == 9) put_partials(r, c, h, true);
             });
         else
             pgemm::epilogue_f16<C, M16>(acc, stg, slab, pre, [&](int r, int c, int pass, half8_t h) {
                 const size_t o = (size_t)(m0 + r) * ldc + col;
                 if (RES) h = add_res(pass, h);
-                if (m0 + r < M) st_out(Cout + o, h);
+                if (m0 + r < M) { if (LNP) st_out_dev(Cout + o, h); else st_out(Cout + o, h); }
                 if (ACT == 9) put_partials(r, c, h, m0 + r < M);
             });
         prev_full = full;
+        if constexpr (LNP) {
+#pragma unroll 1
+            for (int k = 0; k < 2; ++k) {
+                const int lp = __builtin_amdgcn_readfirstlane(lnp_flag[2 * parity + k]);       // written before this epilogue's barriers
+                if (lp >= 0) ln_panel(lp);
+            }
+        }
+    }
+    if constexpr (LNP) {
+        // behind the loop: the last tile's stores, then both outstanding counts
+        pgemm::wait_vm<0>();
+        __syncthreads();
+        if (tid == 0) {
+            int* list = lnp_own + LNP_LIST;
+            int nl = 0;
+            auto mine = [&](int t) { return (t & 0xffff) == tiles_n - 1 && (t & LNP_ORPH); };
+            if (counted >= 0 && mine(ticket)) list[nl++] = counted;
+            if (stored >= 0 && mine(__hip_atomic_fetch_add(lnp.cnt + stored, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) list[nl++] = stored;
+            // the panels this workgroup still owns: complete -> normalised here; incomplete -> orphans from now on
+            const int no = lnp_own[LNP_NOWN];
+            for (int k = 0; k < no; ++k)
+                if ((__hip_atomic_fetch_add(lnp.cnt + lnp_own[k], LNP_ORPH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffff) == tiles_n) list[nl++] = lnp_own[k];
+            lnp_own[LNP_NL] = nl;
+        }
+        __syncthreads();
+        const int nl = __builtin_amdgcn_readfirstlane(lnp_own[LNP_NL]);
+#pragma unroll 1
+        for (int k = 0; k < nl; ++k) ln_panel(__builtin_amdgcn_readfirstlane(lnp_own[LNP_LIST + k]));
     }
 }
 
@@ -573,7 +882,7 @@ static int launch_fast2(const void* A, int lda, const void* B, int ldb, int M, i
     static DevOnce attr;
     constexpr bool LNF = ACT == 7 || ACT == 8;
     constexpr int LDS = C::LDS_BYTES + ((ACT == 2 || ACT == 3 || ACT == 5 || LNF) ? 2 * 2 * C::BN * 4 : 2 * C::BN * 2) + 256 +
-                        (LNF ? 2 * C::BM * 8 : 0);   // K-tile ring + double-buffered bias / affine strips + prefetch scrap + (mean, rstd) rows
+                        (LNF ? 2 * C::BM * 8 : 0) + (ACT == 10 ? 128 + 8192 : 0);   // K-tile ring + double-buffered bias / affine strips + prefetch scrap + (mean, rstd) rows | panel flags
     if (!attr.done()) {
         if (hipFuncSetAttribute((const void*)linear_fast_kernel<C, HAS_BIAS, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS) != hipSuccess) {
@@ -591,10 +900,12 @@ static int launch_fast2(const void* A, int lda, const void* B, int ldb, int M, i
     // rows to be evicted, its low rows fresh for the ascending pass behind it).  Same bits (tile order only); bench +0.4 % (profiles/r03_bench_rev.txt).  Default 2.
     const int rev_mode = order.rev;
     // 1: every launch descending; 2: only the launches that read a LayerNorm / attention output (K <= 1024: in_proj, c_fc, out_proj), c_proj ascending behind the descending c_fc
-    const bool rev = rev_mode == 1 || (rev_mode == 2 && K <= 1024);
+    // act 10 writes the LayerNorm output its consumer reads next (descending): ascending here, whatever it reads itself (PCLIP_LNP_REV=1: as act 6)
+    static const bool lnp_rev = getenv("PCLIP_LNP_REV") && getenv("PCLIP_LNP_REV")[0] == '1';
+    const bool rev = (rev_mode == 1 || (rev_mode == 2 && K <= 1024)) && (ACT != 10 || lnp_rev);
     linear_fast_kernel<C, HAS_BIAS, ACT><<<grid, C::NTHREADS, LDS, s>>>(
         (const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi.bias, epi.scale, epi.shift, epi.C, epi.ldc, tiles_n, ntiles, epi.residual,
-        epi.rowstats, epi.partials, rev ? -1 : (tiles_n >= 8 ? band : 0));
+        epi.rowstats, epi.partials, rev ? -1 : (tiles_n >= 8 ? band : 0), LnPanel{epi.ln_gamma, epi.ln_beta, epi.ln_y, epi.ln_cnt, epi.ln_eps});
     return pclip_check_launch("gemm_f16");
 }
 
@@ -606,6 +917,11 @@ static int launch_fast(const void* A, int lda, const void* B, int ldb, int M, in
     if (epi.act == 5) return launch_fast2<C, false, 5>(A, lda, B, ldb, M, N, K, epi, slots, s);
     if (epi.act == 6) return launch_fast2<C, true, 6>(A, lda, B, ldb, M, N, K, epi, slots, s);
     if (epi.act == 9) return launch_fast2<C, true, 9>(A, lda, B, ldb, M, N, K, epi, slots, s);
+    if (epi.act == 10) {
+        // instantiated for the two tiles the N <= 1024 residual GEMMs of a tower run on (256 x 256 rounds + 128 x 128 tail); gemm_dispatch sends every other choice the two-launch way
+        if constexpr (std::is_same_v<C, CfgBig> || std::is_same_v<C, CfgSmall>) return launch_fast2<C, true, 10>(A, lda, B, ldb, M, N, K, epi, slots, s);
+        else { pclip_set_error("pclip_gemm_res_ln_f16: no fused form for this tile"); return PCLIP_E_INVALID; }
+    }
     if (epi.act == 7) return launch_fast2<C, false, 7>(A, lda, B, ldb, M, N, K, epi, slots, s);
     if (epi.act == 8) return launch_fast2<C, false, 8>(A, lda, B, ldb, M, N, K, epi, slots, s);
     if (epi.bias) {
@@ -650,7 +966,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
             const int d = c * 512 + lane * 8;
             if (d < D) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const float t = v[c][j] - mean; q += t * t; }
+                for (int j = 0; j < 8; ++j) { const float t = v[c][j] - mean; q = ln_sq_acc(t, q); }
             }
         }
         const float rstd = 1.f / sqrtf(wave_sum(q) / (float)D + eps);
@@ -663,7 +979,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
                 if (MODE == 1) rh = ld_half8(res + (size_t)row * D + d);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    float o = (v[c][j] - mean) * rstd * (float)gamma[d + j] + (float)beta[d + j];
+                    float o = ln_affine(v[c][j], mean, rstd, (float)gamma[d + j], (float)beta[d + j]);
                     o = r16(o);
                     if (MODE == 1) o = r16(r16(ratio * o) + r16(omr * (float)rh[j]));
                     v[c][j] = o;
@@ -737,42 +1053,14 @@ __global__ __launch_bounds__(256) void layernorm_pf_kernel(const half_t* __restr
     if (row < R) load(cur, row);
     for (; row < R; row += stride) {
         if (row + stride < R) load(nxt, row + stride);
-        float v[NCH][8];
-        float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            if (c * 512 + lane * 8 < D) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { v[c][j] = (float)cur[c][j]; s += v[c][j]; }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
-            }
-        }
-        const float mean = wave_sum(s) / (float)D;
-        float q = 0.f;
+        half8_t o[NCH];
+        ln_row_pf<NCH>(cur, D, lane, eps, [&](int c, int j) {
+            return GB_LDS ? float2_t{gb_s[0][j >> 2][c * 256 + lane * 4 + (j & 3)], gb_s[1][j >> 2][c * 256 + lane * 4 + (j & 3)]}
+                          : float2_t{gamma[c * 512 + lane * 8 + j], beta[c * 512 + lane * 8 + j]};
+        }, o);
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
-            if (c * 512 + lane * 8 < D) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { const float t = v[c][j] - mean; q += t * t; }
-            }
-        const float rstd = 1.f / sqrtf(wave_sum(q) / (float)D + eps);
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int d = c * 512 + lane * 8;
-            if (d < D) {
-                half8_t o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float t = (v[c][j] - mean) * rstd * (GB_LDS ? gb_s[0][j >> 2][c * 256 + lane * 4 + (j & 3)] : gamma[d + j]) +
-                              (GB_LDS ? gb_s[1][j >> 2][c * 256 + lane * 4 + (j & 3)] : beta[d + j]);
-                    t = r16(t);
-                    o[j] = (half_t)t;
-                }
-                st_half8(y + (size_t)row * D + d, o);
-            }
-        }
+            if (c * 512 + lane * 8 < D) st_half8(y + (size_t)row * D + c * 512 + lane * 8, o[c]);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) cur[c] = nxt[c];
     }
@@ -912,7 +1200,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const half_t* __rest
             const int d = c * 512 + lane * 8;
             if (d < D) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const float t = v[c][j] - mean; q += t * t; }
+                for (int j = 0; j < 8; ++j) { const float t = v[c][j] - mean; q = ln_sq_acc(t, q); }
             }
         }
         const float rstd = 1.f / sqrtf(wave_sum(q) / (float)D + eps);
@@ -925,8 +1213,8 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const half_t* __rest
                 half8_t o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    o[j] = (half_t)((v[c][j] - mean) * rstd * g0[j] + b0[j]);
-                    o[j + 4] = (half_t)((v[c][j + 4] - mean) * rstd * g1[j] + b1[j]);
+                    o[j] = (half_t)ln_affine(v[c][j], mean, rstd, g0[j], b0[j]);
+                    o[j + 4] = (half_t)ln_affine(v[c][j + 4], mean, rstd, g1[j], b1[j]);
                 }
                 st_half8(y + (size_t)row * D + d, o);
             }
@@ -1180,7 +1468,6 @@ __device__ __forceinline__ void attn_query_tile(const half_t* Ks, const half_t* 
 // split across the two half-waves in 8-byte pieces.  v_permlane32_swap pairs the pieces of column groups (2k, 2k+1) so that every
 // lane owns 16 contiguous bytes: four dwordx4 stores per lane instead of sixteen dwordx2 (the store tail is issue-bound; guide T21).
 // `orow` = this lane's output row (+ head offset); every lane executes the swaps, `valid` only predicates the stores.
-typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void attn_store_tile(half_t* orow, const float16_t (&o)[2], float lrun, int hi, bool valid) {
     const float inv = 1.f / lrun;
 #pragma unroll
@@ -1509,7 +1796,7 @@ __device__ __forceinline__ void ln_row_inplace(float (&v)[NCH][8], int D, int la
     for (int c = 0; c < NCH; ++c)
         if (c * 512 + lane * 8 < D) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float t = v[c][j] - mean; q += t * t; }
+            for (int j = 0; j < 8; ++j) { const float t = v[c][j] - mean; q = ln_sq_acc(t, q); }
         }
     const float rstd = 1.f / sqrtf(wave_sum(q) / (float)D + eps);
 #pragma unroll
@@ -1518,7 +1805,7 @@ __device__ __forceinline__ void ln_row_inplace(float (&v)[NCH][8], int D, int la
         if (d < D) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float o = (v[c][j] - mean) * rstd * (float)gamma[d + j] + (float)beta[d + j];
+                float o = ln_affine(v[c][j], mean, rstd, (float)gamma[d + j], (float)beta[d + j]);
                 v[c][j] = r16(o);
             }
         }
@@ -1672,9 +1959,21 @@ int launch_small_one(const half_t* A, int lda, const half_t* B, int ldb, int M, 
 int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int N, int K, LinearEpi epi, int cus, int forced,
                   bool may_split, hipStream_t s) {
     struct MinBn { int old; MinBn(int v) : old(g_min_bn) { g_min_bn = v; } ~MinBn() { g_min_bn = old; } } min_bn(epi.act == 9 ? 64 : 0);
-    const bool aligned = (!epi.residual || ((epi.act == 5 || epi.act == 6 || epi.act == 9) && ((uintptr_t)epi.residual & 15) == 0)) && epi.ldc % 8 == 0 && ((uintptr_t)epi.C & 15) == 0 &&
+    const bool aligned = (!epi.residual || ((epi.act == 5 || epi.act == 6 || epi.act == 9 || epi.act == 10) && ((uintptr_t)epi.residual & 15) == 0)) && epi.ldc % 8 == 0 && ((uintptr_t)epi.C & 15) == 0 &&
                          (!epi.bias || ((uintptr_t)epi.bias & 15) == 0);
     static const bool small_on = !(getenv("PCLIP_GEMM_SMALL") && getenv("PCLIP_GEMM_SMALL")[0] == '0');
+    // act 10 where the panel LayerNorm has no fused form (ring / generic / other tiles, a single K-tile, N not 512 ... 1024 in steps of 128, 32-bit panel offsets): the residual GEMM, then the
+    // LayerNorm pass over the same rows — the same bits either way (ln_row_pf)
+    auto two_launches = [&](int forced_, bool may_split_) {
+        LinearEpi e6 = epi;
+        e6.act = 6;
+        const int rc = gemm_dispatch(A, lda, B, ldb, M, N, K, e6, cus, forced_, may_split_, s);
+        if (rc != PCLIP_OK) return rc;
+        return pclip_layernorm_f16(epi.C, epi.ldc, epi.ln_gamma, epi.ln_beta, epi.ln_eps, epi.ln_y, M, N, (pclip_stream_t)s);
+    };
+    if (epi.act == 10 && (!aligned || !epi.ln_cnt || K < 2 * pgemm::BK || N < 512 || N > 1024 || N % 128 || (long)pgemm::Cfg<256, 256, 2, 4>::BM * epi.ldc * 2 >= 0x7fffffffL ||
+                          (forced == -1 && small_on && small_applies(M, N, cus))))
+        return two_launches(forced, may_split);
     if (aligned && forced == -1 && small_on && (epi.act <= 1 || epi.act == 6 || epi.act == 9 || (((uintptr_t)epi.scale | (uintptr_t)epi.shift) & 15) == 0) && small_applies(M, N, cus))
         return launch_small_one(A, lda, B, ldb, M, N, K, epi, s);
     double cost = 1e30;
@@ -1709,9 +2008,14 @@ int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int
             if (epi.residual) tail.residual = epi.residual + (size_t)split_rows * epi.ldc;   // act 5 / 6: same row stride as C
             if (epi.rowstats) tail.rowstats = epi.rowstats + (size_t)split_rows * 2;         // act 7 / 8 (split_rows is a multiple of 128: 16-byte aligned)
             if (epi.partials) tail.partials = epi.partials + (size_t)split_rows * (N / 64) * 2;   // act 9
+            if (epi.act == 10) {                                                                  // the first launch's panels are at most split_rows / 128
+                tail.ln_y = epi.ln_y + (size_t)split_rows * N;
+                tail.ln_cnt = epi.ln_cnt + split_rows / 128;
+            }
             return gemm_dispatch(A + (size_t)split_rows * lda, lda, B, ldb, M - (int)split_rows, N, K, tail, cus, -1, true, s);
         }
     }
+    if (epi.act == 10 && pick != 2 && pick != 0) return two_launches(pick < 0 ? -2 : pick, false);
     ++g_gemm_launches;
     if (pick < 0 && epi.act == 6) epi.act = 0;                  // generic kernel: bias + residual operands, same roundings
     if (pick == 2) return launch_fast<CfgBig>(A, lda, B, ldb, M, N, K, epi, cus, s);
@@ -1762,6 +2066,29 @@ extern "C" int pclip_gemm_res_stats_f16(const void* A, int lda, const void* B, i
     PCLIP_REQUIRE((((uintptr_t)C | (uintptr_t)residual | (uintptr_t)bias | (uintptr_t)partials) & 15) == 0, "pclip_gemm_res_stats_f16: operands must be 16-byte aligned");
     if (M == 0) return PCLIP_OK;
     LinearEpi epi{(const half_t*)bias, (const half_t*)residual, (half_t*)C, ldc, 9, nullptr, nullptr, nullptr, partials};
+    int cus = pclip_device_cus();
+    if (cus <= 0) cus = 256;
+    static const bool nosplit = getenv("PCLIP_GEMM_NOSPLIT") != nullptr;
+    return gemm_dispatch((const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, cus, -1, !nosplit, (hipStream_t)stream);
+}
+
+// x += A W^T + bias in place, and y = LayerNorm(x) of the updated rows without a pass of its own (linear_fast_kernel act 10): `panel_counters` = one int per 128 rows
+// of x (+ 2), zero on entry and zero again on return (the kernel resets what it counted); NULL, or PCLIP_RES_LN=0, selects the two launches it replaces — same bits.
+extern "C" int pclip_gemm_res_ln_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* bias,
+                                     const float* gamma, const float* beta, float eps, void* y, int32_t* panel_counters, pclip_stream_t stream) {
+    PCLIP_REQUIRE(A && B && C && bias && gamma && beta && y, "pclip_gemm_res_ln_f16: null pointer");
+    PCLIP_REQUIRE(M >= 0 && N > 0 && K > 0, "pclip_gemm_res_ln_f16: bad shape M=%d N=%d K=%d", M, N, K);
+    PCLIP_REQUIRE(K % pgemm::BK == 0 && N % 8 == 0 && N <= 4096, "pclip_gemm_res_ln_f16: K=%d must be a multiple of 64, N=%d of 8 (<= 4096)", K, N);
+    PCLIP_REQUIRE(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0, "pclip_gemm_res_ln_f16: bad leading dims");
+    PCLIP_REQUIRE((((uintptr_t)y | (uintptr_t)panel_counters) & 15) == 0, "pclip_gemm_res_ln_f16: y / panel_counters must be 16-byte aligned");
+    if (M == 0) return PCLIP_OK;
+    static const bool fused = !(getenv("PCLIP_RES_LN") && getenv("PCLIP_RES_LN")[0] == '0');
+    LinearEpi epi{(const half_t*)bias, (const half_t*)C, (half_t*)C, ldc, 10, nullptr, nullptr};
+    epi.ln_gamma = gamma;
+    epi.ln_beta = beta;
+    epi.ln_y = (half_t*)y;
+    epi.ln_cnt = fused ? panel_counters : nullptr;
+    epi.ln_eps = eps;
     int cus = pclip_device_cus();
     if (cus <= 0) cus = 256;
     static const bool nosplit = getenv("PCLIP_GEMM_NOSPLIT") != nullptr;

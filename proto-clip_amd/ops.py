@@ -32,11 +32,14 @@ def evict_workspace(stream_obj):
     """Forget the scratch buffer cached for `stream_obj` (a torch.cuda.Stream that will not be used again)."""
     for key in [k for k in _ws_cache if k[1] == stream_obj.cuda_stream]:
         del _ws_cache[key]
+    for key in [k for k in _panel_counters if k[1] == stream_obj.cuda_stream]:
+        del _panel_counters[key]
 
 
 def release_workspaces():
     """Drop the cached scratch buffers (e.g. after a warm-up on a side stream that will not be used again)."""
     _ws_cache.clear()
+    _panel_counters.clear()
 
 
 def _f16c(t: torch.Tensor) -> torch.Tensor:
@@ -444,6 +447,41 @@ def gemm_res_stats(a, w, bias, x, eps: float = 1e-5):
         gemm(a, w, bias, residual=x, out=x)
         return None
     return finalize_stats(gemm_res_partials(a, w, bias, x), eps)
+
+
+_panel_counters = {}
+
+
+def _counters(n: int, device) -> torch.Tensor:
+    """Zeroed int32 arrival counters for pclip_gemm_res_ln_f16: the kernel leaves them zero, so one array per (device, stream) serves every call
+    on that stream (calls on one stream are ordered).  During a hipGraph capture: a fresh zeroed array of the capture's own pool."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros(n, dtype=torch.int32, device=device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _panel_counters.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.zeros(max(n, 4096), dtype=torch.int32, device=device)
+        _panel_counters[key] = buf
+    return buf
+
+
+def gemm_res_ln(a, w, bias, x, gamma, beta, eps: float = 1e-5, out=None):
+    """x += a @ w^T + bias IN PLACE (clip/model.py:188-189) and returns r16(LayerNorm(x)) of the updated rows (the ln_2 / next ln_1 the following
+    linear reads) from the SAME launch (pclip_gemm_res_ln_f16: the workgroup that completes a row panel normalises it) — bit-identical to
+    `gemm(a, w, bias, residual=x, out=x)` followed by `layernorm(x, gamma, beta)`, which is also what the library runs for shapes without a fused form."""
+    require_cuda(a, w, bias, x, gamma, beta)
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float16, device=x.device)
+    if gamma.dtype != torch.float32 or beta.dtype != torch.float32 or x.stride(0) % 8 or a.stride(0) % 8 or w.stride(0) % 8 or N % 8 or N > 4096 or \
+            not out.is_contiguous():
+        gemm(a, w, bias, residual=x, out=x)
+        return layernorm(x, gamma, beta, eps, out=out)
+    cnt = _counters(M // 128 + 2, x.device)
+    check(_lib.load().pclip_gemm_res_ln_f16(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(x), x.stride(0), M, N, K, ptr(bias), ptr(gamma), ptr(beta),
+                                            eps, ptr(out), ptr(cnt), stream()), "pclip_gemm_res_ln_f16")
+    return out
 
 
 def gemm_ln(x, stats, wf, colsum, bfold, act: int = 0, out=None):

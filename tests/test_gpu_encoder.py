@@ -317,6 +317,36 @@ def test_gemm_res_stats_epilogue(ops, M, N, K):
     assert torch.equal(x1[0], ref[r]) and torch.equal(s1[0], st[r])
 
 
+@pytest.mark.parametrize("M,N,K", [(201728, 768, 768), (50432 + 77, 768, 3072), (65792, 1024, 1024), (9000, 512, 512), (5120, 768, 768), (5000, 768, 128),
+                                   (600, 768, 768), (1, 768, 3072), (3000, 768, 64), (2600, 192, 256), (40000, 1024, 4096), (12345, 2048, 128)])
+def test_gemm_res_ln_equals_two_launches(ops, M, N, K):
+    """pclip_gemm_res_ln_f16 (x += a W^T + b and y = LN(x), the LayerNorm done inside the GEMM launch by the workgroup that completes a row panel) against the two
+    launches it replaces: x and y EQUAL bit for bit, at the bench's own size (201 728 rows: 788 panels x 3 tiles in nine persistent rounds + the 128 x 128 tail launch,
+    panels that straddle two XCDs), with a partial last panel, on 2 / 3 / 4 column tiles, and for the shapes that have no fused form (ring kernel, N > 1024, K = 64).
+    Repeated: a panel normalised before all of its tiles were visible would differ in some repetition.  The arrival counters are zero again afterwards."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = (torch.randn(M, K, device="cuda", generator=g) * 0.7).half()
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).half()
+    b = (torch.randn(N, device="cuda", generator=g) * 0.1).half()
+    x0 = (torch.randn(M, N, device="cuda", generator=g) * 1.5 + 0.4).half()
+    gam, bet = 1 + 0.3 * torch.randn(N, device="cuda", generator=g), 0.2 * torch.randn(N, device="cuda", generator=g)
+    ref = x0.clone()
+    ops.gemm(a, w, b, residual=ref, out=ref)
+    yref = ops.layernorm(ref, gam, bet)
+    for rep in range(4 if M > 40000 else 2):
+        x = x0.clone()
+        y = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda")
+        out = ops.gemm_res_ln(a, w, b, x, gam, bet, out=y)
+        assert out is y and torch.equal(x, ref), rep
+        assert torch.equal(y, yref), (rep, int((y != yref).any(1).sum()))
+    for buf in ops._panel_counters.values():
+        assert int(buf.abs().sum()) == 0
+    r = M // 2                                               # a row alone == the row in the batch
+    x1 = x0[r:r + 1].clone()
+    y1 = ops.gemm_res_ln(a[r:r + 1].contiguous(), w, b, x1, gam, bet)
+    assert torch.equal(x1[0], ref[r]) and torch.equal(y1[0], yref[r])
+
+
 def test_vit_embed_stats_matches_row_stats(ops):
     """pclip_vit_embed_ln_f16 in its statistics form (first block's ln_1 folded): x0 identical to the ln_1 form, statistics
     identical to pclip_row_stats_f16 of x0."""
