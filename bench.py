@@ -411,7 +411,19 @@ def run(args, hooks, out=None):
     device = hooks.device(local)
     if launched:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(hooks.backend, **({"device_id": device} if device.type == "cuda" else {}))
+        # RCCL prints a version banner on STDOUT when its first communicator is created; stdout carries exactly one JSON line (the contract), so file descriptor 1
+        # points at stderr while the process group and its communicator come up
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(hooks.backend, **({"device_id": device} if device.type == "cuda" else {}))
+            dist.barrier()
+            hooks.sync()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world} under torch.distributed.run: pass the same N to both")
     step, BATCH = hooks.step, hooks.batch
