@@ -214,10 +214,6 @@ int pclip_row_stats_finalize(const float* partials, int R, int D, float eps, flo
  * there is no LayerNorm pass over x (620 MB of HBM traffic per call at the bench's size).  Bit-identical to pclip_gemm_f16(.., residual = C) followed by
  * pclip_layernorm_f16 — which is what runs when the shape has no fused form (few tiles, N > 1024, K = 64), when panel_counters is NULL, or under PCLIP_RES_LN=0.
  * panel_counters: M / 128 + 2 ints of device memory, ZERO on entry, zero again when the call has executed (one array per stream that calls this). */
-/* Rows the row-split dispatch of pclip_gemm_f16 gives its first launch for an [M, N] output (0: a single launch).  pclip_gemm_f16 on rows [0, split) and
- * on [split, M) runs the same kernels as the one call; the caller may put the short second part on another stream beside work that only needs the first
- * (the LayerNorm pass over those rows: clip/model.py `_run_blocks`). */
-int pclip_gemm_split_rows(int M, int N);
 int pclip_gemm_res_ln_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* bias,
                           const float* gamma, const float* beta, float eps, void* y, int32_t* panel_counters, pclip_stream_t stream);
 int pclip_ln_fold_weights_f16(const void* W, int ldw, int N, int K, const float* gamma, const float* beta, const void* bias,

@@ -54,7 +54,6 @@ _SIGS = {
     "pclip_row_stats_f16": [_P, c_int, c_float, _P, c_int, c_int, _P],
     "pclip_gemm_res_stats_f16": [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P],
     "pclip_row_stats_finalize": [_P, c_int, c_int, c_float, _P, _P],
-    "pclip_gemm_split_rows": [c_int, c_int],
     "pclip_gemm_res_ln_f16": [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P],
     "pclip_gemm_ln_f16": [_P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P],
     "pclip_add_layernorm_f16": [_P, _P, c_int, _P, _P, _P, c_float, _P, c_int, c_int, _P],

@@ -187,9 +187,6 @@ def _run_blocks(x, blocks, B, L, heads, causal, select=None, first_token=False, 
         if ln is not None and RES_LN and not LN_FOLD:
             # the residual add and the LayerNorm behind it in one launch (ops.gemm_res_ln): no pass over x between the two linears
             return x_, _Norm(x_, ln, h=ops.gemm_res_ln(a_, lin.weight, lin.bias, x_, ln.weight, ln.bias))
-        if ln is not None and not LN_FOLD:
-            # the residual GEMM and the LayerNorm pass behind it; the GEMM's short second launch runs beside the pass (ops.gemm_res_then_layernorm)
-            return x_, _Norm(x_, ln, h=ops.gemm_res_then_layernorm(a_, lin.weight, lin.bias, x_, ln.weight, ln.bias))
         ops.gemm(a_, lin.weight, lin.bias, residual=x_, out=x_)
         return x_, norm_of(x_, ln)
 

@@ -1952,24 +1952,6 @@ inline int best_cfg(long M, int N, int cus, double* cost_out) {
     return pick;
 }
 
-// Row split of an [M, N] output whose one-launch cost is `cost`: rows given to the full rounds of configuration *cfg (-1: no split pays)
-inline long plan_split(long M, int N, int cus, double cost, int* cfg) {
-    long split_rows = 0;
-    *cfg = -1;
-    for (int i = 0; i < kNumCfgs; ++i) {
-        const TileCfg& c = kTileCfgs[i];
-        if (N % c.bn) continue;
-        const long slots = (long)c.wg_per_cu * cus, tiles_n = N / c.bn, nt = ((M + c.bm - 1) / c.bm) * tiles_n;
-        const long full_rows = (nt / slots) * slots / tiles_n * c.bm;
-        if (nt <= slots || nt % slots == 0 || full_rows >= M) continue;
-        double rest = 1e30;
-        best_cfg(M - full_rows, N, cus, &rest);
-        const double split = tile_cost(c, full_rows, N, cus) + rest + kLaunchCost;
-        if (split < cost) { cost = split; *cfg = i; split_rows = full_rows; }
-    }
-    return split_rows;
-}
-
 // fewer 128x64 tiles than CUs: the latency-oriented ring kernel (defined below), bit-identical to the persistent kernels
 bool small_applies(int M, int N, int cus);
 int launch_small_one(const half_t* A, int lda, const half_t* B, int ldb, int M, int N, int K, const LinearEpi& epi, hipStream_t s);
@@ -2005,8 +1987,19 @@ int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int
         if (aligned && forced < kNumCfgs && N % kTileCfgs[forced].bn == 0) pick = forced;
     }
     if (pick >= 0 && may_split) {
+        long split_rows = 0;                                   // rows given to the full rounds of configuration split_cfg
         int split_cfg = -1;
-        const long split_rows = plan_split(M, N, cus, cost, &split_cfg);
+        for (int i = 0; i < kNumCfgs; ++i) {
+            const TileCfg& c = kTileCfgs[i];
+            if (N % c.bn) continue;
+            const long slots = (long)c.wg_per_cu * cus, tiles_n = N / c.bn, nt = ((M + c.bm - 1) / c.bm) * tiles_n;
+            const long full_rows = (nt / slots) * slots / tiles_n * c.bm;
+            if (nt <= slots || nt % slots == 0 || full_rows >= M) continue;
+            double rest = 1e30;
+            best_cfg(M - full_rows, N, cus, &rest);
+            const double split = tile_cost(c, full_rows, N, cus) + rest + kLaunchCost;
+            if (split < cost) { cost = split; split_cfg = i; split_rows = full_rows; }
+        }
         if (split_cfg >= 0) {
             int rc = gemm_dispatch(A, lda, B, ldb, (int)split_rows, N, K, epi, cus, split_cfg, false, s);
             if (rc != PCLIP_OK) return rc;
@@ -2061,23 +2054,6 @@ extern "C" int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, vo
         nosplit = getenv("PCLIP_GEMM_NOSPLIT") != nullptr;
     }
     return gemm_dispatch((const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, cus, forced, !nosplit, (hipStream_t)stream);
-}
-
-// Rows the row-split dispatch of pclip_gemm_f16 gives its FIRST launch for an [M, N] output of 16-byte-aligned operands (0: one launch).  A caller that has
-// independent work for the rows of the first launch (the LayerNorm pass behind a residual GEMM) can issue the two parts itself — pclip_gemm_f16 on rows
-// [0, split) and on [split, M) chooses the same kernels as the one call — and run the short second part on another stream beside that work.
-extern "C" int pclip_gemm_split_rows(int M, int N) {
-    if (M <= 0 || N <= 0) return 0;
-    int cus = pclip_device_cus();
-    if (cus <= 0) cus = 256;
-    static const bool nosplit = getenv("PCLIP_GEMM_NOSPLIT") != nullptr;
-    static const bool small_on = !(getenv("PCLIP_GEMM_SMALL") && getenv("PCLIP_GEMM_SMALL")[0] == '0');
-    if (nosplit || (small_on && small_applies(M, N, cus))) return 0;
-    double cost = 1e30;
-    if (best_cfg(M, N, cus, &cost) < 0) return 0;
-    int cfg = -1;
-    const long rows = plan_split(M, N, cus, cost, &cfg);
-    return cfg >= 0 ? (int)rows : 0;
 }
 
 // x += A W^T + bias in place of C = residual (pclip_gemm_f16 with `residual`), and the statistics partials of the updated rows.

@@ -449,40 +449,6 @@ def gemm_res_stats(a, w, bias, x, eps: float = 1e-5):
     return finalize_stats(gemm_res_partials(a, w, bias, x), eps)
 
 
-_side_streams = {}
-
-
-def gemm_split_rows(M: int, N: int) -> int:
-    """Rows `gemm`'s row-split dispatch gives its first launch for an [M, N] output (0: one launch) — pclip_gemm_split_rows."""
-    return int(_lib.load().pclip_gemm_split_rows(M, N))
-
-
-def gemm_res_then_layernorm(a, w, bias, x, gamma, beta, eps: float = 1e-5):
-    """x += a @ w^T + bias in place and returns LayerNorm(x) — `gemm(.., residual=x, out=x)` + `layernorm`, the same kernels on the same rows, with the
-    SHORT second launch of the row-split GEMM (the rows of its partial last round, as 128 x 128 tiles: latency-bound, a fifth of the matrix pipe) on a side
-    stream beside the LayerNorm pass over the rows of the first launch (HBM-bound, no matrix work): they share the chip instead of queueing.
-    Falls back to the two plain calls when the GEMM is a single launch or a hipGraph is being captured."""
-    M, N = a.shape[0], w.shape[0]
-    split = 0 if torch.cuda.is_current_stream_capturing() else gemm_split_rows(M, N)
-    if split <= 0 or split >= M or SIDE_TAIL is False:
-        gemm(a, w, bias, residual=x, out=x)
-        return layernorm(x, gamma, beta, eps)
-    h = torch.empty(M, N, dtype=torch.float16, device=x.device)
-    cur = torch.cuda.current_stream(x.device)
-    side = _side_streams.get(x.device)
-    if side is None:
-        side = _side_streams[x.device] = torch.cuda.Stream(device=x.device)
-    gemm(a[:split], w, bias, residual=x[:split], out=x[:split])
-    side.wait_stream(cur)                               # the second part starts when the first launch has finished: beside the LayerNorm pass, not in front of it
-    layernorm(x[:split], gamma, beta, eps, out=h[:split])
-    with torch.cuda.stream(side):
-        gemm(a[split:], w, bias, residual=x[split:], out=x[split:])
-        layernorm(x[split:], gamma, beta, eps, out=h[split:])
-    cur.wait_stream(side)
-    return h
-
-
-SIDE_TAIL = os.environ.get("PCLIP_SIDE_TAIL", "1") != "0"
 _panel_counters = {}
 
 

@@ -347,32 +347,6 @@ def test_gemm_res_ln_equals_two_launches(ops, M, N, K):
     assert torch.equal(x1[0], ref[r]) and torch.equal(y1[0], yref[r])
 
 
-@pytest.mark.parametrize("M,N,K", [(201728, 768, 768), (50432 + 77, 768, 3072), (65792, 1024, 1024), (600, 768, 768)])
-def test_gemm_res_then_layernorm_side_stream(ops, M, N, K):
-    """ops.gemm_res_then_layernorm (the residual GEMM's short second launch on a side stream beside the LayerNorm pass over the first launch's rows) == the two
-    plain calls, bit for bit, repeated (a missing dependency between the streams would show as stale rows in some repetition); and the split it asks the
-    library for is the one the library's own dispatch takes (same launch count)."""
-    g = torch.Generator(device="cuda").manual_seed(M + N + K + 1)
-    a = (torch.randn(M, K, device="cuda", generator=g) * 0.7).half()
-    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).half()
-    b = (torch.randn(N, device="cuda", generator=g) * 0.1).half()
-    x0 = (torch.randn(M, N, device="cuda", generator=g) * 1.5 + 0.4).half()
-    gam, bet = 1 + 0.3 * torch.randn(N, device="cuda", generator=g), 0.2 * torch.randn(N, device="cuda", generator=g)
-    ref = x0.clone()
-    n0 = ops._lib.load().pclip_gemm_kernel_launches()
-    ops.gemm(a, w, b, residual=ref, out=ref)
-    one_call = ops._lib.load().pclip_gemm_kernel_launches() - n0
-    yref = ops.layernorm(ref, gam, bet)
-    split = ops.gemm_split_rows(M, N)
-    assert (split > 0) == (one_call > 1) and 0 <= split < M and split % 128 == 0
-    for rep in range(4):
-        x = x0.clone()
-        n0 = ops._lib.load().pclip_gemm_kernel_launches()
-        y = ops.gemm_res_then_layernorm(a, w, b, x, gam, bet)
-        assert ops._lib.load().pclip_gemm_kernel_launches() - n0 == one_call
-        assert torch.equal(x, ref) and torch.equal(y, yref), rep
-
-
 def test_vit_embed_stats_matches_row_stats(ops):
     """pclip_vit_embed_ln_f16 in its statistics form (first block's ln_1 folded): x0 identical to the ln_1 form, statistics
     identical to pclip_row_stats_f16 of x0."""
