@@ -274,7 +274,111 @@ void run_w3(const char* name, const char* src, size_t region, float* sink) {
     printf("%-110s %8.1f ns per iteration, %8.1f ns per 256 x 256 K-tile equivalent\n", name, ms * 1e6 / iters, 2 * ms * 1e6 / iters);
 }
 
-int main() {
+// ---- "B direct": what a K-loop would issue whose B fragments go from L2 straight to registers (per wave: its own 32 columns, 4 global_load_dwordx4 per K-tile, no
+// duplicates in a 1 x 8 wave arrangement) and whose A tile alone goes through LDS (4 pieces per wave, 32 KB per K-tile: FOUR stages fit the 128 KB the two 64 KB stages
+// take now, i.e. three K-tiles of lead and ONE barrier per K-tile) — at the price of every wave reading the whole A tile: 32 ds_read_b128 per wave and K-tile instead of 24.
+// FORM 0: the present loop's pattern WITH its 24 fragment reads (3 barriers, roles, 8 pieces per wave); FORM 1: B direct (1 barrier, 4 pieces + 4 register loads + 32 reads).
+template <int FORM, int INFLIGHT, int BLOAD = 1>
+__global__ __launch_bounds__(512, 2) void bd_probe(const char* __restrict__ src, size_t region, const char* __restrict__ wsrc, float* __restrict__ sink, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    half8_t a = {1, 2, 3, 4, 5, 6, 7, 8}, b = {8, 7, 6, 5, 4, 3, 2, 1};
+    for (int i = 0; i < 8; ++i) { a[i] += (_Float16)(lane & 3); b[i] -= (_Float16)(lane & 1); }
+    float4_t acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = float4_t{0.f, 0.f, 0.f, 0.f};
+    const unsigned mask = (unsigned)(region - 1), cu_off = (unsigned)(((size_t)blockIdx.x * 8 + wave) * (region / 2048)) & mask;
+    constexpr int NP = FORM ? 4 : 8;
+    auto burst = [&](int it) {
+#pragma unroll
+        for (int g = 0; g < NP; ++g) {
+            const unsigned off = (cu_off + ((unsigned)(it * NP + g) * 64 + lane) * 16) & mask;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + off), (lds_ptr_t)(smem + (wave * 8 + g) * 1024), 16, 0, 0);
+        }
+    };
+    // B fragments of a wave: 16 rows of W (row stride 1536 B) x 64 B per instruction, two column blocks x two k-steps; the weights are a 4 MB L2-resident panel set
+    half8_t bf[4];
+    auto bload = [&](int it) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            // (the workgroup's weight panel: one of 12 column tiles of a 3072 x 768 weight, as neighbouring workgroups of a c_fc launch read them)
+            const char* ptr = wsrc + ((size_t)((blockIdx.x % 12) * 256 + wave * 32 + (g & 1) * 16 + (lane & 15)) * 1536 + (lane >> 4) * 16 + (size_t)((it * 2 + (g >> 1)) % 24) * 64);
+            if (BLOAD) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bf[g]) : "v"(ptr));
+        }
+    };
+    half8_t fr[4];
+    const unsigned lbase = (unsigned)(size_t)smem;    // (generic -> the low 32 bits are the LDS offset on this target)
+    auto reads = [&](int n, int salt) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < n) {
+                const unsigned addr = lbase + (((wave * 7 + salt * 4 + k) * 1024 + lane * 16) & (128 * 1024 - 1));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(fr[k]) : "v"(addr));
+            }
+    };
+    auto mf = [&](int n8) {
+        for (int k = 0; k < n8; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[i], 0, 0, 0);
+    };
+    for (int it = 0; it < iters; ++it) {
+        __builtin_amdgcn_s_waitcnt((INFLIGHT & 15) | (7 << 4) | (15 << 8) | ((INFLIGHT >> 4) << 14));
+        __builtin_amdgcn_s_barrier();
+        if (FORM == 1) {
+            bload(it);
+            burst(it);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) { reads(4, g); mf(1); }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { reads(3, g); mf(1); }
+            __builtin_amdgcn_s_barrier();
+            if (wave < 4) burst(it);
+            reads(3, 4); mf(1); reads(3, 5); mf(1);
+            __builtin_amdgcn_s_barrier();
+            if (wave >= 4) burst(it);
+            reads(3, 6); mf(1); reads(3, 7); mf(1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int g = 0; g < 4; ++g) s += (float)bf[g][0] + (float)fr[g][0];
+    sink[blockIdx.x * 512 + tid] = s;
+}
+template <int FORM, int INFLIGHT, int BLOAD = 1>
+void run_bd(const char* name, const char* src, size_t region, float* sink) {
+    const int iters = 2000, grid = 256;
+    hipFuncSetAttribute((const void*)bd_probe<FORM, INFLIGHT, BLOAD>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    bd_probe<FORM, INFLIGHT, BLOAD><<<grid, 512, 128 * 1024>>>(src, region, src, sink, 50);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    bd_probe<FORM, INFLIGHT, BLOAD><<<grid, 512, 128 * 1024>>>(src, region, src, sink, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-118s %8.1f ns per iteration\n", name, ms * 1e6 / iters);
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'b') {
+        const size_t big = (size_t)512 << 20, small = (size_t)4 << 20;
+        char* src; float* sink;
+        hipMalloc(&src, big); hipMalloc(&sink, 256 * 512 * 4);
+        hipMemset(src, 1, big);
+        setvbuf(stdout, NULL, _IONBF, 0);
+        printf("---- the present loop's issue pattern with its fragment reads (F0) against a B-direct loop's (F1); 64 MFMAs per wave and iteration either way\n");
+        run_bd<0, 8>("F0  present: 3 barriers, roles, 8 pieces + 24 reads per wave; 4 MB source, one K-tile in flight", src, small, sink);
+        run_bd<0, 8>("F0  present, 64 MB source (Infinity Cache)", src, (size_t)64 << 20, sink);
+        run_bd<1, 8, 0>("F1a B direct WITHOUT its register loads: 1 barrier, 4 pieces + 32 reads per wave; 4 MB source, one K-tile in flight", src, small, sink);
+        run_bd<1, 24, 0>("F1a 4 MB, three in flight", src, small, sink);
+        run_bd<1, 8, 0>("F1a 64 MB (Infinity Cache), one in flight", src, (size_t)64 << 20, sink);
+        run_bd<1, 24, 0>("F1a 64 MB, three in flight", src, (size_t)64 << 20, sink);
+        run_bd<1, 8>("F1  B direct: + 4 register loads per wave (16 rows x 64 B each, from a 4 MB weight set); 4 MB source, one K-tile in flight", src, small, sink);
+        run_bd<1, 16>("F1  4 MB, two K-tiles in flight", src, small, sink);
+        run_bd<1, 24>("F1  4 MB, three K-tiles in flight", src, small, sink);
+        return 0;
+    }
+
     const size_t big = (size_t)512 << 20, small = (size_t)4 << 20;
     char *src, *dst; unsigned long long* cyc; float* sink;
     hipMalloc(&src, big); hipMalloc(&dst, big); hipMalloc(&cyc, 1024 * 8); hipMalloc(&sink, 256 * 512 * 4);
