@@ -1301,6 +1301,9 @@ __device__ __forceinline__ float half_wave_sum(float v) { float a, b; half_wave_
 // arithmetic instead of in front of every MFMA (+64 VGPRs).  Same operations in the same order per accumulator: same bits.
 // VBAR: the caller has only made K visible so far (V is still landing); the first pair of key tiles waits for V — own pieces, then a workgroup barrier —
 // between its softmax and its second contraction, so V's arrival passes under the first scores.  Every wave of the workgroup must pass that barrier once.
+#ifndef PCLIP_ATT_EDGE
+#define PCLIP_ATT_EDGE 1          // a lone last key tile with at most 24 valid keys skips its fully masked groups (tile_edge below; 0: A/B)
+#endif
 template <bool DEEP = false, int VAR = 0, bool VBAR = false>
 __device__ __forceinline__ void attn_query_tile(const half_t* Ks, const half_t* Vs, const half8_t (&qf)[4], int q, int qb, int L, int causal,
                                                 int NT, int hi, int ql, const int (&voff)[2], float16_t (&o)[2], float& lrun_out) {
@@ -1457,10 +1460,104 @@ __device__ __forceinline__ void attn_query_tile(const half_t* Ks, const half_t* 
 #endif
             }
     };
+    // A LAST key tile on its own whose keys beyond L are masked (non-causal; ViT-B/16: keys 192 .. 196 of tile 6, ViT-L/14: key 256 alone in tile 8): the groups of
+    // eight keys (elements 4g .. 4g + 3 of both half-waves) without a single valid key are not computed at all — no mask, maximum, exponential, sum or conversion
+    // for them, and no second contraction over keys 16 .. 31 when those are all masked.  Their probabilities are exact zeros in `tiles` (exp2(-inf)), which add
+    // nothing to the sum and to O: same bits (the valid elements keep their order in the maximum chains and the partial sums).
+    auto tile_edge = [&](int t0) {
+        const int ng = (L - t0 * 32 + 7) >> 3;                          // groups with a valid key: 1 .. 3 (wave-uniform)
+        float16_t st;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (VAR & 8) __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) st = __builtin_amdgcn_mfma_f32_32x32x16_f16(k_frag(t0, sidx), qf[sidx], st, 0, 0, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (VAR & 8) __builtin_amdgcn_s_setprio(0);
+#endif
+        const int lim = L - t0 * 32 - 4 * hi;
+        float m4[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+            if (g < ng) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (!(r + 8 * g < lim)) st[4 * g + r] = -__builtin_inff();
+                    m4[r] = fmaxf(m4[r], st[4 * g + r]);
+                }
+            }
+        float tmax = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+        tmax = half_wave_max(tmax) * kScale;
+        const bool moved = (VAR & 1) ? tmax > mrun + kAttDefer : fmaxf(mrun, tmax) != mrun;
+        const float mnew = ((VAR & 1) && !moved) ? mrun : fmaxf(mrun, tmax);
+        const bool grow = __any(moved);
+        float psum = 0.f;
+        float2_t ps2 = {0.f, 0.f};
+        const float2_t ks2 = {kScale, kScale}, nm2 = {-mnew, -mnew};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3 && g < ng) {
+#pragma unroll
+                for (int e = 4 * g; e < 4 * g + 4; e += 2) {
+                    float2_t v = {st[e], st[e + 1]};
+                    if (VAR & 6) {
+                        if (VAR & 4) {
+                            v = v * ks2 + nm2;
+                            v = float2_t{__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])};
+                        } else
+                            v = float2_t{__builtin_amdgcn_exp2f(fmaf(v[0], kScale, -mnew)), __builtin_amdgcn_exp2f(fmaf(v[1], kScale, -mnew))};
+                        if (VAR & 2) ps2 += v;
+                        else { psum += v[0]; psum += v[1]; }
+                    } else {
+                        v[0] = __builtin_amdgcn_exp2f(fmaf(v[0], kScale, -mnew)); psum += v[0];
+                        v[1] = __builtin_amdgcn_exp2f(fmaf(v[1], kScale, -mnew)); psum += v[1];
+                    }
+                    st[e] = v[0];
+                    st[e + 1] = v[1];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[4 * g + r] = 0.f;
+            }
+        }
+        if (VAR & 6) psum += ps2[0] + ps2[1];
+        psum = half_wave_sum(psum);
+        if (grow) {
+            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+            lrun *= alpha;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[j][e] *= alpha;
+        }
+        lrun += psum;
+        mrun = mnew;
+        if (VBAR && t0 == 0) { pgemm::wait_vm<0>(); pgemm::lds_barrier(); }
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx)
+            if (sidx == 0 || ng > 2) {
+                half8_t pf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[e] = (half_t)st[sidx * 8 + e];
+#if defined(__HIP_DEVICE_COMPILE__)
+                if (VAR & 8) __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+                for (int j = 0; j < 2; ++j) o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v_frag(t0, sidx, j), pf, o[j], 0, 0, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+                if (VAR & 8) __builtin_amdgcn_s_setprio(0);
+#endif
+            }
+    };
     int t = 0;
     if (DEEP) k_prefetch(0);
     for (; t + 1 < tend; t += 2) tiles(std::integral_constant<int, 2>{}, t);
-    if (t < tend) tiles(std::integral_constant<int, 1>{}, t);
+    if (t < tend) {
+        if (PCLIP_ATT_EDGE && VBAR && !DEEP && !causal && L - t * 32 <= 24) tile_edge(t);      // (the query-first kernels only: measured neutral to - 2 % in the looping eight-wave kernel at L = 257)
+        else tiles(std::integral_constant<int, 1>{}, t);
+    }
     lrun_out = lrun;
 }
 
