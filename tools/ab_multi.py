@@ -27,9 +27,14 @@ if mode == "attn":
     for name, B, L, H, causal in (("ViT-B/16", 1024, 197, 12, 0), ("ViT-L/14", 256, 257, 16, 0), ("ViT-B/32", 1024, 50, 12, 0), ("text", 7000, 77, 8, 1)):
         g = torch.Generator(device="cuda").manual_seed(L)
         qkv = torch.randn(B * L, 3 * H * 64, device="cuda", generator=g).half()
-        out = {x: torch.zeros(B * L, H * 64, device="cuda", dtype=torch.float16) for x in libs}
+        # ONE output buffer for every build (results are copied out once for the comparison): with a buffer per build the first-listed build read ~ 4 % slow — the
+        # same library listed first and second differed by that much — i.e. the placement of the buffer was being measured, not the code
+        buf = torch.zeros(B * L, H * 64, device="cuda", dtype=torch.float16)
         def call(x):
-            assert libs[x].pclip_attention_f16(P(qkv.data_ptr()), P(out[x].data_ptr()), B, L, H, 64, causal, st()) == 0
+            assert libs[x].pclip_attention_f16(P(qkv.data_ptr()), P(buf.data_ptr()), B, L, H, 64, causal, st()) == 0
+        out = {}
+        for x in libs:
+            buf.zero_(); call(x); out[x] = buf.clone()
         med = rounds(call)
         # accuracy on a slice: fp32 softmax attention of the first 8 images
         nb = min(B, 8)
