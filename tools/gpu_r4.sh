@@ -19,4 +19,4 @@ cd $R; python tools/pmc_summary.py 2>&1 | tail -25; cp profiles/r04_pmc_traffic.
   echo "== train_bench (MFMA adapter backward)"; python tools/train_bench.py; echo "== train_bench PCLIP_ADAPTER_MFMA=0"; PCLIP_ADAPTER_MFMA=0 python tools/train_bench.py;
   echo "== small_bench"; python tools/small_bench.py; echo "== encoder_bench"; python tools/encoder_bench.py ) 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_tool_benches_$TAG.txt
 tail -30 gpurun_out/r04_tool_benches_$TAG.txt
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extra > gpurun_out/r04_bench_torchrun_$TAG.json 2> gpurun_out/r04_bench_torchrun_$TAG.err; python -c "import json; d=json.load(open('gpurun_out/r04_bench_torchrun_$TAG.json')); print('TORCHRUN', round(d['value']), d['rccl_world_size'], d['self_check'])"
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-extra > gpurun_out/r04_bench_torchrun_$TAG.json 2> gpurun_out/r04_bench_torchrun_$TAG.err; python -c "import json; d=json.load(open('gpurun_out/r04_bench_torchrun_$TAG.json')); print('TORCHRUN', round(d['value']), d['rccl_world_size'], d['self_check'])"
