@@ -20,7 +20,11 @@ ODD = dict(embed_dim=64, image_resolution=70, vision_layers=2, vision_width=192,
            vocab_size=300, transformer_width=64, transformer_heads=1, transformer_layers=1)   # L=26, K=588 (ViT-L/14-like pad)
 ENCODERS = {"tiny": TINY, "small": SMALL, "odd": ODD}
 # full-size towers through the reference itself (make_golden.make_encoder_full): the architecture the bench times (VERDICT r3 missing #1)
-ENCODERS_FULL = {"vitb16": dict(backbone="ViT-B/16", n_img=8, n_txt=8, sd_seed=11)}
+ENCODERS_FULL = {"vitb16": dict(backbone="ViT-B/16", n_img=8, n_txt=8, sd_seed=11),
+                 # the other backbones of BASELINE.json's configurations (C1 RN50, C2 ViT-B/32, C5 ViT-L/14), round 4
+                 "vitb32": dict(backbone="ViT-B/32", n_img=8, n_txt=4, sd_seed=12),
+                 "rn50": dict(backbone="RN50", n_img=4, n_txt=4, sd_seed=14),
+                 "vitl14": dict(backbone="ViT-L/14", n_img=4, n_txt=4, sd_seed=15)}
 # image -> logits chain (make_golden.make_e2e): the SMALL towers with CLIP's real vocabulary, so that clip.tokenize feeds them
 E2E = dict(SMALL, vocab_size=49408)
 E2E_CASE = dict(N=6, K=4, Q_val=24, Q_test=48, augment_epoch=2, alpha=0.5, beta=12.0, adapter="conv-3x", n_templates=3, seed=31)

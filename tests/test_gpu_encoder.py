@@ -718,15 +718,17 @@ def test_full_size_vit_b16_against_oracle():
     assert torch.equal(f1[0], f[2])
 
 
-def test_full_size_vit_b16_against_reference():
-    """The real ViT-B/16 architecture through the REFERENCE's own towers (tests/golden/encoder_vitb16.npz: make_golden.make_encoder_full runs
-    /root/reference's build_model at the hyper-parameters OpenAI's ViT-B/16 checkpoint resolves to — 12 x 768, 197 tokens, 12 heads; text
-    12 x 512 — on 8 images and 8 prompts, fp16-weight and fp32): encode_image / encode_text of the HIP path within max(2 x the reference's own
-    fp16 <-> fp32 gap, 3e-3), the bound of the toy-tower fixtures (clip/model.py:221-238, 338-354, 397-434)."""
+@pytest.mark.parametrize("tag", ["vitb16", "vitb32", "rn50", "vitl14"])
+def test_full_size_towers_against_reference(tag):
+    """The real architectures of BASELINE.json's configurations through the REFERENCE's own towers (tests/golden/encoder_<tag>.npz: make_golden.make_encoder_full
+    runs /root/reference's build_model at the hyper-parameters OpenAI's checkpoints resolve to — ViT-B/16: 12 x 768, 197 tokens, 12 heads; ViT-B/32; RN50:
+    ModifiedResNet (3, 4, 6, 3) + attention pool; ViT-L/14: 24 x 1024, 257 tokens; text 12 x 512 / 768 — on 4 - 8 images and prompts, fp16-weight and fp32):
+    encode_image / encode_text of the HIP path within max(2 x the reference's own fp16 <-> fp32 gap, 3e-3), the bound of the toy-tower fixtures
+    (clip/model.py:10-152, 221-238, 338-354, 397-434)."""
     from proto_clip_amd.clip.model import BACKBONES
     from spec import ENCODERS_FULL
-    g = golden("encoder_vitb16")
-    spec_ = ENCODERS_FULL["vitb16"]
+    g = golden("encoder_" + tag)
+    spec_ = ENCODERS_FULL[tag]
     kw = BACKBONES[spec_["backbone"]]
     sd = random_state_dict(seed=spec_["sd_seed"], **kw)
     model = build_model({k: v.clone() for k, v in sd.items()}).cuda()
@@ -734,12 +736,13 @@ def test_full_size_vit_b16_against_reference():
     toks = torch.from_numpy(g["tokens"]).long()
     with torch.no_grad():
         fi, ft = model.encode_image(imgs.cuda()), model.encode_text(toks.cuda())
+    name = spec_["backbone"]
     for key, out in (("img", fi), ("txt", ft)):
         r16_, r32_ = torch.from_numpy(g[key + "_f16"]), torch.from_numpy(g[key + "_f32"])
         gap = rel_err(r16_, r32_)
-        observe(f"full-size ViT-B/16 {key}: reference fp16<->fp32 gap (yard-stick)", gap, gap)
-        assert observe(f"full-size ViT-B/16 {key}: rel err vs REFERENCE fp32", rel_err(out, r32_), max(2.0 * gap, 3e-3)) <= max(2.0 * gap, 3e-3)
-        assert observe(f"full-size ViT-B/16 {key}: rel err vs REFERENCE fp16", rel_err(out, r16_), max(2.0 * gap, 3e-3)) <= max(2.0 * gap, 3e-3)
+        observe(f"full-size {name} {key}: reference fp16<->fp32 gap (yard-stick)", gap, gap)
+        assert observe(f"full-size {name} {key}: rel err vs REFERENCE fp32", rel_err(out, r32_), max(2.0 * gap, 3e-3)) <= max(2.0 * gap, 3e-3)
+        assert observe(f"full-size {name} {key}: rel err vs REFERENCE fp16", rel_err(out, r16_), max(2.0 * gap, 3e-3)) <= max(2.0 * gap, 3e-3)
 
 
 @pytest.mark.parametrize("fold", [False, True])
