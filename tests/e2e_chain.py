@@ -13,7 +13,7 @@ if os.path.dirname(HERE) not in sys.path:
     sys.path.insert(0, os.path.dirname(HERE))
 if HERE not in sys.path:
     sys.path.insert(0, HERE)
-from golden.spec import E2E, E2E_VARIANTS, e2e_images, e2e_state_dict  # noqa: E402
+from golden.spec import E2E, E2E_VARIANTS, e2e_arch, e2e_images, e2e_state_dict, e2e_variant_images  # noqa: E402
 
 STAGES = ("test_features", "text_bank", "adapted", "proto_img", "proto_txt")
 
@@ -32,9 +32,9 @@ def run_variant(name, tmp_dir=None):
     from proto_clip_amd.utils import build_cache_model, clip_classifier, pre_load_features
     g = np.load(os.path.join(HERE, "golden", name + ".npz"), allow_pickle=False)
     c = E2E_VARIANTS[name]["case"]
-    N, K, D = c["N"], c["K"], E2E["embed_dim"]
+    N, K, D = c["N"], c["K"], e2e_arch(name)["embed_dim"]
     model = build_model(e2e_state_dict(name)).cuda()
-    (sup_x, sup_y), _, (test_x, test_y) = e2e_images(c)
+    (sup_x, sup_y), _, (test_x, test_y) = e2e_variant_images(name)
     tmp_dir = tmp_dir or tempfile.mkdtemp(prefix="pclip_e2e_")
     cfg = dict(cache_dir=str(tmp_dir), backbone="ViT-B/16", shots=K, augment_epoch=c["augment_epoch"], dataset="synthetic_" + name)
     classnames, templates = [str(x) for x in g["classnames"]], [str(x) for x in g["templates"]]

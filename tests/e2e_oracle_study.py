@@ -14,7 +14,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
-from golden.spec import E2E_VARIANTS, e2e_images, e2e_state_dict  # noqa: E402
+from golden.spec import E2E_VARIANTS, e2e_images, e2e_state_dict, e2e_variant_images  # noqa: E402
 from oracle import clip_oracle as co, proto_oracle as po  # noqa: E402
 
 
@@ -26,7 +26,7 @@ def oracle_chain(name, half):
     c = E2E_VARIANTS[name]["case"]
     N, K = c["N"], c["K"]
     sd = e2e_state_dict(name)
-    (sup_x, sup_y), _, (test_x, _) = e2e_images(c)
+    (sup_x, sup_y), _, (test_x, _) = e2e_variant_images(name)
     classnames, templates = [str(x) for x in g["classnames"]], [str(x) for x in g["templates"]]
     tok = pclip.tokenize([t.format(cn.replace("_", " ")) for cn in classnames for t in templates])
     ad_sd = {str(k): torch.from_numpy(g["adapter__" + str(k)]) for k in g["adapter_keys"]}

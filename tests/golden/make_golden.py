@@ -28,7 +28,7 @@ sys.path.insert(0, REPO)
 from proto_clip_amd import synth                                   # noqa: E402
 from proto_clip_amd.clip.model import random_state_dict            # noqa: E402
 sys.path.insert(0, HERE)
-from spec import (E2E, E2E_CASE, E2E_VARIANTS, ENCODERS, ENCODERS_FULL, FEWSHOT, RESNETS, TRAIN, e2e_images, e2e_jitter, e2e_state_dict, fewshot_inputs,   # noqa: E402
+from spec import (E2E, E2E_CASE, E2E_VARIANTS, ENCODERS, ENCODERS_FULL, FEWSHOT, RESNETS, TRAIN, e2e_arch, e2e_images, e2e_jitter, e2e_state_dict, e2e_variant_images, fewshot_inputs,   # noqa: E402
                   randomize_adapter_, train_inputs)
 
 
@@ -361,8 +361,8 @@ def make_e2e(name, ref_main, ref_utils, ref_model, ref_clip_model, scratch):
     classnames = [imagenet_classes[i] for i in (0, 1, 2, 21, 15, 43)][:N]
     templates = imagenet_templates[:c["n_templates"]]
     sd = e2e_state_dict(name)
-    (sup_x, sup_y), (val_x, val_y), (test_x, test_y) = e2e_images(c)
-    ad = adapter_state(ref_model, c["adapter"], E2E["embed_dim"], seed=var["adapter_seed"])
+    (sup_x, sup_y), (val_x, val_y), (test_x, test_y) = e2e_variant_images(name)
+    ad = adapter_state(ref_model, c["adapter"], e2e_arch(name)["embed_dim"], seed=var["adapter_seed"])
     out = {}
     clean = (sup_x, val_x, test_x)
     for tag in ("f16", "f32", "f16_jitter"):

@@ -49,6 +49,9 @@ E2E_VARIANTS = {
     "e2e_trained4": dict(sd_seed=61, case=dict(E2E_CASE, seed=247), adapter_seed=71, trained=True),
     # the same chain behind the ModifiedResNet tower (RN50's channel widths, one bottleneck per stage, attention pool; RESNET below)
     "e2e_rn": dict(sd_seed=23, case=dict(E2E_CASE, seed=73), adapter_seed=15, trained=False, arch="rn"),
+    # the chain at the BENCH's architecture: the real ViT-B/16 hyper-parameters (12 x 768 vision / 12 x 512 text, 224 x 224 images, 512-wide embedding, the conv-3x
+    # adapter on 512 features), trained-like LayerNorm statistics and outlier channels (round 4, last session)
+    "e2e_vitb16": dict(sd_seed=62, case=dict(E2E_CASE, seed=254), adapter_seed=72, trained=True, arch="vitb16"),
 }
 
 
@@ -94,8 +97,17 @@ def e2e_state_dict(variant):
 
 
 def e2e_arch(variant):
-    """Tower hyper-parameters of an image -> logits fixture (embed_dim 128 and 64 x 64 images either way)."""
-    return dict(RESNET, vocab_size=49408) if E2E_VARIANTS[variant].get("arch") == "rn" else E2E
+    """Tower hyper-parameters of an image -> logits fixture (embed_dim 128 and 64 x 64 images, except the full-size ViT-B/16 one: 512 / 224 x 224)."""
+    arch = E2E_VARIANTS[variant].get("arch")
+    if arch == "vitb16":
+        from proto_clip_amd.clip.model import BACKBONES
+        return dict(BACKBONES["ViT-B/16"])
+    return dict(RESNET, vocab_size=49408) if arch == "rn" else E2E
+
+
+def e2e_variant_images(variant):
+    """e2e_images of a fixture at its tower's resolution."""
+    return e2e_images(E2E_VARIANTS[variant]["case"], res=e2e_arch(variant)["image_resolution"])
 
 
 def e2e_images(case=E2E_CASE, res=64):
