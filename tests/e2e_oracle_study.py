@@ -30,7 +30,7 @@ def oracle_chain(name, half):
     classnames, templates = [str(x) for x in g["classnames"]], [str(x) for x in g["templates"]]
     tok = pclip.tokenize([t.format(cn.replace("_", " ")) for cn in classnames for t in templates])
     ad_sd = {str(k): torch.from_numpy(g["adapter__" + str(k)]) for k in g["adapter_keys"]}
-    enc = co.encode_image_resnet if E2E_VARIANTS[name].get("arch") == "rn" else co.encode_image
+    enc = co.encode_image_resnet if E2E_VARIANTS[name].get("arch") in ("rn", "rn50") else co.encode_image
     order = torch.from_numpy(np.argsort(np.asarray(sup_y), kind="stable"))
     T = len(templates)
     if half:        # fp16 towers: every normalisation / mean is fp16 arithmetic on fp16 tensors (the reference's GPU precision)

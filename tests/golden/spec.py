@@ -52,6 +52,8 @@ E2E_VARIANTS = {
     # the chain at the BENCH's architecture: the real ViT-B/16 hyper-parameters (12 x 768 vision / 12 x 512 text, 224 x 224 images, 512-wide embedding, the conv-3x
     # adapter on 512 features), trained-like LayerNorm statistics and outlier channels (round 4, last session)
     "e2e_vitb16": dict(sd_seed=62, case=dict(E2E_CASE, seed=254), adapter_seed=72, trained=True, arch="vitb16"),
+    # ... and behind the full RN50 (ModifiedResNet (3, 4, 6, 3), attention pool, 1024-wide features: the conv-3x adapter on 32 x 32 maps; BASELINE configuration C1's backbone)
+    "e2e_rn50": dict(sd_seed=63, case=dict(E2E_CASE, seed=261), adapter_seed=73, trained=False, arch="rn50"),
 }
 
 
@@ -99,9 +101,9 @@ def e2e_state_dict(variant):
 def e2e_arch(variant):
     """Tower hyper-parameters of an image -> logits fixture (embed_dim 128 and 64 x 64 images, except the full-size ViT-B/16 one: 512 / 224 x 224)."""
     arch = E2E_VARIANTS[variant].get("arch")
-    if arch == "vitb16":
+    if arch in ("vitb16", "rn50"):
         from proto_clip_amd.clip.model import BACKBONES
-        return dict(BACKBONES["ViT-B/16"])
+        return dict(BACKBONES["ViT-B/16" if arch == "vitb16" else "RN50"])
     return dict(RESNET, vocab_size=49408) if arch == "rn" else E2E
 
 
