@@ -28,7 +28,7 @@ sys.path.insert(0, REPO)
 from proto_clip_amd import synth                                   # noqa: E402
 from proto_clip_amd.clip.model import random_state_dict            # noqa: E402
 sys.path.insert(0, HERE)
-from spec import (E2E, E2E_CASE, E2E_VARIANTS, ENCODERS, ENCODERS_FULL, FEWSHOT, RESNETS, TRAIN, e2e_arch, e2e_images, e2e_jitter, e2e_state_dict, e2e_variant_images, fewshot_inputs,   # noqa: E402
+from spec import (E2E, E2E_CASE, E2E_VARIANTS, ENCODERS, ENCODERS_FULL, FEWSHOT, RESNETS, TRAIN, TRAIN_QT, e2e_arch, e2e_images, e2e_jitter, e2e_state_dict, e2e_variant_images, fewshot_inputs,   # noqa: E402
                   randomize_adapter_, train_inputs)
 
 
@@ -247,6 +247,103 @@ def make_train(name, ref_main, ref_utils, scratch):
     savez("train_" + name, **arrays)
 
 
+def make_train_qt(name, ref_utils, ref_model, ref_clip_model, scratch):
+    """The reference's Proto-CLIP-F-Q^T loop (main.qt.py:75-330) itself: queries = clip_model.encode_image(batch) of a training image loader (main.qt.py:198-201),
+    both memory banks and the adapter learnable, prototypes over every class.  Towers: the small ViT of the image -> logits fixtures with a 256-wide embedding (the fc adapter's kernels take multiples of 256; fp16 weights); banks from the
+    reference's own builders on seeded images; the loader = the support images in fixed batches.  Recorded: the banks / features the run starts from, the adapter as
+    initialised, and for the first three optimizer steps the encoded query features, labels, loss terms, gradients and updated parameters."""
+    import importlib.util
+    import builtins
+    from datasets.imagenet import imagenet_classes, imagenet_templates
+    spec_ = importlib.util.spec_from_file_location("ref_main_qt", os.path.join(REF, "main.qt.py"))
+    qt = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(qt)
+    qt.plot_tsne = lambda *a, **k: None
+    c = TRAIN_QT[name]
+    N, K = c["N"], c["K"]
+    case = dict(E2E_CASE, N=N, K=K, seed=c["seed"])
+    sd = random_state_dict(seed=c["sd_seed"], **dict(E2E, embed_dim=c["embed_dim"]))
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = ref_clip_model.build_model({k: v.clone() for k, v in sd.items()})
+    (sup_x, sup_y), (val_x, val_y), (test_x, test_y) = e2e_images(case)
+    classnames = [imagenet_classes[i] for i in (0, 1, 2, 21, 15, 43, 7, 99)][:N]
+    cfg = dict(shots=K, backbone="ViT-B/16", dataset="synthetic_" + name, only_test=False, lr=c["lr"], augment_epoch=1, train_epoch=c["epochs"], alpha=c["alpha"],
+               beta=c["beta"], adapter=c["adapter"], train_vis_mem_only=False, losses=c["losses"], cache_dir=os.path.join(scratch, "caches", name), logs_dir_path="logs")
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        keys, values = ref_utils.build_cache_model(cfg, m, [(sup_x, sup_y)])
+        val_f, val_l = ref_utils.pre_load_features(cfg, "val", m, [(val_x, val_y)])
+        test_f, test_l = ref_utils.pre_load_features(cfg, "test", m, [(test_x, test_y)])
+        _, text_bank = ref_utils.clip_classifier(classnames, imagenet_templates[:2], m)
+    keys, val_f, test_f, text_bank = keys.half(), val_f.half(), test_f.half(), text_bank.half()
+    bs = c["batch"]
+    loader = [(sup_x[i:i + bs], sup_y[i:i + bs]) for i in range(0, len(sup_y), bs)]
+    feats, episodes, steps, holder = [], [], [], {}
+    real_enc = m.encode_image
+
+    def spy_enc(images):
+        f = real_enc(images)
+        feats.append(f.detach().clone())
+        return f
+
+    m.encode_image = spy_enc
+    real_clm = qt.compute_loss_and_matches
+
+    def spy_clm(p, target, zi, zt, cc):
+        out = real_clm(p, target, zi, zt, cc)
+        l1 = float(torch.nn.NLLLoss()(torch.log(p), target))
+        episodes.append((target.clone(), float(out[0]), float(out[1]), l1, float(out[3]), float(out[4])))
+        return out
+
+    real_step = torch.optim.AdamW.step
+
+    def spy_step(self, *a, **k):
+        params = [p for g in self.param_groups for p in g["params"]]
+        holder["opt"] = self
+        if len(steps) < 3:
+            before = [p.detach().clone() for p in params]
+            grads = [None if p.grad is None else p.grad.detach().clone() for p in params]
+            r = real_step(self, *a, **k)
+            steps.append((before, grads, [p.detach().clone() for p in params]))
+            return r
+        return real_step(self, *a, **k)
+
+    qt.compute_loss_and_matches = spy_clm
+    torch.optim.AdamW.step = spy_step
+    real_input = builtins.input
+    builtins.input = lambda *a, **k: ""
+    buf = io.StringIO()
+    torch.manual_seed(1)
+    np.random.seed(1)
+    try:
+        with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+            qt.run_proto_clip(cfg, keys, values, val_f, val_l, test_f, test_l, text_bank, m, classnames, loader)
+    finally:
+        torch.optim.AdamW.step = real_step
+        builtins.input = real_input
+    import re
+    log = buf.getvalue()
+    val_acc = [float(x) for x in re.findall(r"val accuracy: ([0-9.]+)%", log)]
+    ad_names = ["fc.0.weight", "fc.1.weight", "fc.1.bias", "fc.2.weight", "fc.3.weight", "fc.3.bias"] if c["adapter"] == "fc" else \
+        ["conv1.weight", "bn1.weight", "bn1.bias", "conv2.weight", "bn2.weight", "bn2.bias", "conv3.weight", "bn3.weight", "bn3.bias"]
+    names = ["visual", "textual"] + ad_names                     # parameter order of main.qt.py:98-99
+    params = [p for g in holder["opt"].param_groups for p in g["params"]]
+    assert len(names) == len(params), (len(names), len(params))
+    arrays = dict(names=np.array(names), keys=keys, values=values.to(torch.int16), text_bank=text_bank, val_acc=np.array(val_acc), n_steps=len(episodes),
+                  ep_matches=np.array([e[1] for e in episodes]), ep_loss=np.array([e[2] for e in episodes]), ep_l1=np.array([e[3] for e in episodes]),
+                  ep_l2=np.array([e[4] for e in episodes]), ep_l3=np.array([e[5] for e in episodes]))
+    for si, (before, grads, after) in enumerate(steps):
+        arrays[f"zq{si}"] = feats[si]
+        arrays[f"labels{si}"] = episodes[si][0].to(torch.int16)
+        for n, b, g, a in zip(names, before, grads, after):
+            if si == 0:
+                arrays[f"init__{n}"] = b
+            if g is not None:
+                arrays[f"grad{si}__{n}"] = g
+            arrays[f"after{si}__{n}"] = a
+    print("%s: %d steps, val acc per epoch %s, loss %.4f -> %.4f" % (name, len(episodes), val_acc, episodes[0][2], episodes[-1][2]))
+    savez("train_" + name, **arrays)
+
+
 # ---------------------------------------------------------------- shipped checkpoints ---------------
 def make_shipped(ref_model):
     """The two adapter checkpoints the reference ships on seeded inputs: real trained weights."""
@@ -429,6 +526,9 @@ def main():
     for name in TRAIN:
         if todo(name):
             make_train(name, ref_main, ref_utils, scratch)
+    for name in TRAIN_QT:
+        if todo(name):
+            make_train_qt(name, ref_utils, ref_model, ref_clip_model, scratch)
     if todo("shipped"):
         make_shipped(ref_model)
     for tag, kw in ENCODERS.items():

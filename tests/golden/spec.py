@@ -148,6 +148,10 @@ TRAIN = {
 }
 
 
+# a run of the reference's main.qt.py (Proto-CLIP-F-Q^T: the queries of a step are encode_image of a training batch; BASELINE configuration C5 runs it with the fc adapter)
+TRAIN_QT = {"TQ_fc": dict(N=6, K=4, embed_dim=256, sd_seed=64, seed=268, adapter="fc", alpha=0.5, beta=6.0, losses=["L1", "L2", "L3"], epochs=2, lr=0.001, batch=8)}
+
+
 def train_inputs(name):
     """Seeded inputs of training case `name` and the cfg run_proto_clip receives (only_test False)."""
     from proto_clip_amd import synth

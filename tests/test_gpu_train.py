@@ -479,6 +479,50 @@ def test_one_shot_episode_and_feature_step_match_autograd():
             assert rel_l2(got.reshape(g_ref.shape), g_ref) <= tol, (name, rel_l2(got.reshape(g_ref.shape), g_ref))
 
 
+def test_qt_steps_match_the_reference_run():
+    """tests/golden/train_TQ_fc.npz = /root/reference's main.qt.py run itself (make_golden.make_train_qt: small ViT towers, queries = encode_image of the loader's
+    batches, both banks + the fc adapter learnable — BASELINE configuration C5's variant).  For its first three optimizer steps the HIP step (`step_features`, the
+    main.qt.py entry: explicit query features, prototypes over every class) starts from the reference's state and receives the reference's own encoded queries:
+    matches exactly, loss terms to 2e-5, gradients to 3e-3 (banks) / 2e-2 (adapter) in relative l2, and the parameters after the first AdamW step (moments zero)
+    within one fp16 ulp of the update scale for all but 0.5 % of the elements (the fp16 AdamW outliers of test_first_steps_match_reference_and_oracle)."""
+    from proto_clip_amd.main import make_adapter
+    from proto_clip_amd.train import ProtoClipTrainer
+    from golden.spec import TRAIN_QT
+    c = TRAIN_QT["TQ_fc"]
+    g = golden("train_TQ_fc")
+    names = [str(n) for n in g["names"]]
+    cfg = dict(shots=c["K"], lr=c["lr"], train_epoch=c["epochs"], adapter=c["adapter"], train_vis_mem_only=False, losses=c["losses"], alpha=c["alpha"], beta=c["beta"])
+    keys, text_bank = torch.from_numpy(g["keys"]), torch.from_numpy(g["text_bank"])
+    for ep in range(3):
+        before = {n: torch.from_numpy(g[f"init__{n}"] if ep == 0 else g[f"after{ep - 1}__{n}"]) for n in names}
+        ad = make_adapter(cfg, keys.shape[0])
+        ad.load_state_dict({k: v for k, v in before.items() if k not in ("visual", "textual")})
+        gpu = ProtoClipTrainer(cfg, keys.cuda(), text_bank.cuda(), ad, c["alpha"], c["beta"])
+        with torch.no_grad():
+            gpu.visual.copy_(before["visual"].cuda())
+            gpu.textual.copy_(before["textual"].cuda())
+        zq, lab = torch.from_numpy(g[f"zq{ep}"]).cuda(), torch.from_numpy(g[f"labels{ep}"]).long()
+        matches, loss, l1, l2, l3, _, _ = gpu.step_features(zq, lab)
+        assert float(matches.item()) == g["ep_matches"][ep]
+        for got, key in ((loss, "ep_loss"), (l1, "ep_l1"), (l2, "ep_l2"), (l3, "ep_l3")):
+            want = float(g[key][ep])
+            assert observe(f"main.qt.py run step {ep}: {key} |d|", abs(got.item() - want), 2e-5 * max(1.0, abs(want))) <= 2e-5 * max(1.0, abs(want)), (ep, key)
+        params = dict(gpu.adapter.named_parameters())
+        for n in names:
+            p = gpu.visual if n == "visual" else gpu.textual if n == "textual" else params[n]
+            got = gpu.last_grads.get(id(p))
+            refg = torch.from_numpy(g[f"grad{ep}__{n}"]).float()
+            tol = 3e-3 if n in ("visual", "textual") else 2e-2
+            e = rel_l2(got.reshape(refg.shape), refg)
+            assert observe(f"main.qt.py run step {ep}: grad {n} rel l2", e, tol) <= tol, (ep, n, e)
+            if ep == 0:
+                after = torch.from_numpy(g[f"after0__{n}"]).float()
+                cur = (p.data if isinstance(p, torch.nn.Parameter) else p).float().cpu().reshape(after.shape)
+                diff = (cur - after).abs()
+                big = 2.5 * cfg["lr"] + 2.0 ** -10 * after.abs().max().item()
+                assert (diff > big).float().mean().item() < 5e-3, (n, (diff > big).float().mean().item())
+
+
 def test_compute_loss_and_matches_dropin():
     """utils.compute_loss_and_matches / P on fp32 operands (the training-path call of main.py:281-285) against the oracle."""
     from proto_clip_amd import utils as U
