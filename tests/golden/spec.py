@@ -54,6 +54,8 @@ E2E_VARIANTS = {
     "e2e_vitb16": dict(sd_seed=62, case=dict(E2E_CASE, seed=254), adapter_seed=72, trained=True, arch="vitb16"),
     # ... and behind the full RN50 (ModifiedResNet (3, 4, 6, 3), attention pool, 1024-wide features: the conv-3x adapter on 32 x 32 maps; BASELINE configuration C1's backbone)
     "e2e_rn50": dict(sd_seed=63, case=dict(E2E_CASE, seed=261), adapter_seed=73, trained=False, arch="rn50"),
+    # ... and behind the full ViT-L/14 (24 x 1024, 257 tokens, 768-wide features -> 28 x 28 adapter maps: the one-workgroup-per-CU form of the adapter kernels; C5's backbone)
+    "e2e_vitl14": dict(sd_seed=65, case=dict(E2E_CASE, seed=275), adapter_seed=74, trained=True, arch="vitl14"),
 }
 
 
@@ -101,9 +103,9 @@ def e2e_state_dict(variant):
 def e2e_arch(variant):
     """Tower hyper-parameters of an image -> logits fixture (embed_dim 128 and 64 x 64 images, except the full-size ViT-B/16 one: 512 / 224 x 224)."""
     arch = E2E_VARIANTS[variant].get("arch")
-    if arch in ("vitb16", "rn50"):
+    if arch in ("vitb16", "rn50", "vitl14"):
         from proto_clip_amd.clip.model import BACKBONES
-        return dict(BACKBONES["ViT-B/16" if arch == "vitb16" else "RN50"])
+        return dict(BACKBONES[{"vitb16": "ViT-B/16", "rn50": "RN50", "vitl14": "ViT-L/14"}[arch]])
     return dict(RESNET, vocab_size=49408) if arch == "rn" else E2E
 
 
