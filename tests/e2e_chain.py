@@ -28,7 +28,7 @@ def run_variant(name, tmp_dir=None):
     distances to the reference's chain.  Returns a dict of tensors and numbers."""
     from proto_clip_amd import ops
     from proto_clip_amd.clip.model import build_model
-    from proto_clip_amd.model import Adapter
+    from proto_clip_amd.model import Adapter, Adapter_FC
     from proto_clip_amd.utils import build_cache_model, clip_classifier, pre_load_features
     g = np.load(os.path.join(HERE, "golden", name + ".npz"), allow_pickle=False)
     c = E2E_VARIANTS[name]["case"]
@@ -43,7 +43,7 @@ def run_variant(name, tmp_dir=None):
         keys, values = build_cache_model(cfg, model, [(sup_x[:10], sup_y[:10]), (sup_x[10:], sup_y[10:])])      # utils.py:284-332
         test_f, test_l = pre_load_features(cfg, "test", model, [(test_x[:20], test_y[:20]), (test_x[20:], test_y[20:])])   # 335-361
         _, text_bank = clip_classifier(classnames, templates, model)                                          # 256-273, real tokenizer
-        adapter = Adapter(D, c["adapter"], dtype=torch.half)
+        adapter = Adapter_FC(D, dtype=torch.half) if c["adapter"] == "fc" else Adapter(D, c["adapter"], dtype=torch.half)
         adapter.load_state_dict(ad_sd)
         adapter = adapter.cuda()
         zi = ops.proto_build(ops.transpose(keys), N, K)                                  # main.py:399-402

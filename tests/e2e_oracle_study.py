@@ -46,7 +46,7 @@ def oracle_chain(name, half):
         text_bank = n32(e).half()                                                              # [N, D] = clip_weights.t()
     zi = po.proto_build(keys, N, K)
     zt = po.proto_build(txt, N, T) if half else po.l2norm_rows(text_bank)
-    zq = po.l2norm_rows(po.adapter_conv(tf, ad_sd, c["adapter"]))
+    zq = po.l2norm_rows(po.adapter_fc(tf, ad_sd) if c["adapter"] == "fc" else po.adapter_conv(tf, ad_sd, c["adapter"]))
     p = po.P(zq, zi, zt, c["alpha"], c["beta"])
     return g, dict(test_features=tf, proto_img=zi, proto_txt=zt, adapted=zq, p=p)
 

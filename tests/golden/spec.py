@@ -56,6 +56,8 @@ E2E_VARIANTS = {
     "e2e_rn50": dict(sd_seed=63, case=dict(E2E_CASE, seed=261), adapter_seed=73, trained=False, arch="rn50"),
     # ... and behind the full ViT-L/14 (24 x 1024, 257 tokens, 768-wide features -> 28 x 28 adapter maps: the one-workgroup-per-CU form of the adapter kernels; C5's backbone)
     "e2e_vitl14": dict(sd_seed=65, case=dict(E2E_CASE, seed=275), adapter_seed=74, trained=True, arch="vitl14"),
+    # ... and configuration C2's pair: the full ViT-B/32 with the fc (MLP) adapter
+    "e2e_vitb32_fc": dict(sd_seed=66, case=dict(E2E_CASE, seed=282, adapter="fc"), adapter_seed=75, trained=True, arch="vitb32"),
 }
 
 
@@ -103,9 +105,9 @@ def e2e_state_dict(variant):
 def e2e_arch(variant):
     """Tower hyper-parameters of an image -> logits fixture (embed_dim 128 and 64 x 64 images, except the full-size ViT-B/16 one: 512 / 224 x 224)."""
     arch = E2E_VARIANTS[variant].get("arch")
-    if arch in ("vitb16", "rn50", "vitl14"):
+    if arch in ("vitb16", "rn50", "vitl14", "vitb32"):
         from proto_clip_amd.clip.model import BACKBONES
-        return dict(BACKBONES[{"vitb16": "ViT-B/16", "rn50": "RN50", "vitl14": "ViT-L/14"}[arch]])
+        return dict(BACKBONES[{"vitb16": "ViT-B/16", "rn50": "RN50", "vitl14": "ViT-L/14", "vitb32": "ViT-B/32"}[arch]])
     return dict(RESNET, vocab_size=49408) if arch == "rn" else E2E
 
 

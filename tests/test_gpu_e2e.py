@@ -2,7 +2,7 @@
 (tests/golden/make_golden.py::make_e2e: build_cache_model + clip_classifier + pre_load_features on the reference's CLIP
 towers, then main.py:383-441 with a spy on P).  north_star's bar: logits within 1e-3, top-1 exactly.
 
-Twenty-four fixtures (tests/golden/spec.py::E2E_VARIANTS): sixteen seeded draws on random-init ViT towers, four with TRAINED-like statistics, one at the FULL ViT-B/16 architecture of the bench (trained-like, 224 x 224 images, 512-wide features), one behind the full RN50 (1024-wide features), one behind the full ViT-L/14 (768-wide),
+Twenty-five fixtures (tests/golden/spec.py::E2E_VARIANTS): sixteen seeded draws on random-init ViT towers, four with TRAINED-like statistics, one at the FULL ViT-B/16 architecture of the bench (trained-like, 224 x 224 images, 512-wide features), one behind the full RN50 (1024-wide features), one behind the full ViT-L/14 (768-wide), one behind the full ViT-B/32 with the fc adapter,
 (LayerNorm gains over a factor 25, LayerNorm biases, ~50 sigma outlier channels in the residual stream), one ModifiedResNet tower.
 
 The comparator is fp16-noisy, and each fixture carries the reference's own yard-sticks: the chain on its fp16-weight towers
