@@ -1301,6 +1301,9 @@ __device__ __forceinline__ float half_wave_sum(float v) { float a, b; half_wave_
 // arithmetic instead of in front of every MFMA (+64 VGPRs).  Same operations in the same order per accumulator: same bits.
 // VBAR: the caller has only made K visible so far (V is still landing); the first pair of key tiles waits for V — own pieces, then a workgroup barrier —
 // between its softmax and its second contraction, so V's arrival passes under the first scores.  Every wave of the workgroup must pass that barrier once.
+#ifndef PCLIP_ATT_QF4
+#define PCLIP_ATT_QF4 1           // query-first form of the four-wave kernel for short non-causal sequences (0: A/B)
+#endif
 #ifndef PCLIP_ATT_EDGE
 #define PCLIP_ATT_EDGE 1          // a lone last key tile with at most 24 valid keys skips its fully masked groups (tile_edge below; 0: A/B)
 #endif
@@ -2732,7 +2735,8 @@ extern "C" int pclip_attention_q_f16(const void* q, int ldq, long q_batch_stride
     static DevOnce attr_set;
     if (!attr_set.done()) {
         const void* fns[] = {(const void*)attention_kernel<8, PCLIP_ATT_VAR_LONG>, (const void*)attention_kernel<4, PCLIP_ATT_VAR_LONG>,
-                             (const void*)attention_kernel<4, PCLIP_ATT_VAR_SHORT>, (const void*)attention_kernel<8, PCLIP_ATT_VAR_LONG, true>};
+                             (const void*)attention_kernel<4, PCLIP_ATT_VAR_SHORT>, (const void*)attention_kernel<8, PCLIP_ATT_VAR_LONG, true>,
+                             (const void*)attention_kernel<4, PCLIP_ATT_VAR_SHORT, true>};
         for (const void* f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) {
                 pclip_set_error("pclip_attention_f16: cannot raise the dynamic LDS limit");
@@ -2747,7 +2751,12 @@ extern "C" int pclip_attention_q_f16(const void* q, int ldq, long q_batch_stride
     attention_kernel<NW, VAR><<<B * H, NW * 64, lds, (hipStream_t)stream>>>((const half_t*)q, ldq, q_batch_stride, (const half_t*)kv, ldkv, k_off, \
                                                                              v_off, (half_t*)out, L, Lq, H, causal, NT, LV)
     static const bool qfirst = !(getenv("PCLIP_ATT_QFIRST") && getenv("PCLIP_ATT_QFIRST")[0] == '0');      // A/B switch
-    if ((Lq + 31) / 32 > 4 && (Lq + 31) / 32 <= 8 && qfirst)
+    // short NON-causal sequences (ViT-B/32: 50 tokens = 2 tiles): every wave of the four-wave workgroup has at most one tile too: 71.9 -> 68.0 us (B = 1024), same bits;
+    // the causal text sequences (77 tokens) lose 14 % in this form (489 -> 558 us: their waves' work is triangular) and keep the looping kernel
+    if (PCLIP_ATT_QF4 && qfirst && NT <= 4 && Lq == L && !causal)
+        attention_kernel<4, PCLIP_ATT_VAR_SHORT, true><<<B * H, 4 * 64, lds, (hipStream_t)stream>>>((const half_t*)q, ldq, q_batch_stride, (const half_t*)kv, ldkv, k_off,
+                                                                                                     v_off, (half_t*)out, L, Lq, H, causal, NT, LV);
+    else if ((Lq + 31) / 32 > 4 && (Lq + 31) / 32 <= 8 && qfirst)
         attention_kernel<8, PCLIP_ATT_VAR_LONG, true><<<B * H, 8 * 64, lds, (hipStream_t)stream>>>((const half_t*)q, ldq, q_batch_stride, (const half_t*)kv, ldkv, k_off,
                                                                                                     v_off, (half_t*)out, L, Lq, H, causal, NT, LV);
     else if ((Lq + 31) / 32 > 4) PCLIP_ATT_LAUNCH(8, PCLIP_ATT_VAR_LONG);

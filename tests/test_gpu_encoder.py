@@ -366,7 +366,8 @@ def test_vit_embed_stats_matches_row_stats(ops):
 # pieces a wave stages (2 - 4 by L): every class of it is here (129 / 160: 2 | 3 pieces, 161 / 192: 3, 193 / 197 / 224: 3 | 4, 225 / 256: 4), causal too
 @pytest.mark.parametrize("B,L,H,causal", [(2, 50, 2, False), (3, 197, 12, False), (2, 77, 8, True), (1, 257, 16, False),
                                           (4, 26, 3, False), (1, 1, 1, False), (2, 33, 1, True), (2, 129, 2, False), (3, 160, 3, False), (2, 161, 2, True),
-                                          (2, 192, 4, False), (2, 193, 2, False), (3, 224, 2, True), (2, 225, 3, False), (2, 256, 2, False), (5, 200, 7, False)])
+                                          (2, 192, 4, False), (2, 193, 2, False), (3, 224, 2, True), (2, 225, 3, False), (2, 256, 2, False), (5, 200, 7, False),
+                                          (3, 32, 2, False), (2, 64, 3, False), (2, 65, 2, False), (3, 100, 2, False), (2, 128, 4, False)])      # the query-first four-wave form: 1 - 4 tiles
 def test_attention(ops, B, L, H, causal):
     W = H * 64
     qkv = (torch.from_numpy(synth.normal((B, L, 3 * W), 23, 0)).float() * 1.5).half()
