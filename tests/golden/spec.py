@@ -149,6 +149,8 @@ TRAIN = {
     "T_c2": (9, 4, 104, 64, 64, 0.5, 8.0, "conv-2x", 4.5, False, ["L1"], 2, 0.002),
     # the conv-3x adapter at the feature width of the ViT-B towers (512 -> 23 x 23 maps: the width the MFMA forward / backward kernels of round 4 run at in the bench)
     "T_c3_512": (20, 8, 512, 80, 80, 0.5, 6.0, "conv-3x", 5.0, False, ["L1", "L2", "L3"], 2, 0.001),
+    # every loss term of utils.compute_loss_and_matches, the inter-cluster ones (L4) included, in a run of the reference itself
+    "T_fc_l4": (8, 4, 256, 48, 48, 0.5, 6.0, "fc", 5.0, False, ["L1", "L2", "L3", "L4"], 1, 0.001),
 }
 
 
