@@ -382,6 +382,30 @@ def test_attention(ops, B, L, H, causal):
     assert rel_err(out.reshape(-1, W), ref.reshape(-1, W)) < 2e-3
 
 
+@pytest.mark.parametrize("L,H", [(17, 4), (26, 3), (32, 2), (33, 2), (50, 12), (64, 2), (100, 2), (128, 4), (197, 12), (256, 2)])
+def test_attention_counted_waits_under_load(ops, L, H):
+    """The query-first kernels go through their first barrier on a COUNTED s_waitcnt (K landed, V in flight): a count one too high lets a wave multiply against K rows
+    that have not arrived — which single small launches rarely show (the four-wave form at L <= 32 did exactly that and passed the shapes above; an image -> logits
+    fixture on 17-token towers failed in two of four runs).  Here: a batch large enough to fill the chip several times over (HBM-cold K / V for most workgroups), repeated,
+    every repetition EQUAL to the first and close to fp32 attention."""
+    B = max(64, 60000 // (L * H))
+    W = H * 64
+    g = torch.Generator(device="cuda").manual_seed(L * 131 + H)
+    qkv = (torch.randn(B * L, 3 * W, device="cuda", generator=g) * 1.5).half()
+    first = None
+    for rep in range(12):
+        junk = torch.empty(64 << 20, dtype=torch.uint8, device="cuda").random_(0, 255)        # push K / V out of the caches between repetitions
+        out = ops.attention(qkv, B, L, H, causal=False)
+        if first is None:
+            first = out.clone()
+            q, k, v = (t.view(B, L, H, 64).transpose(1, 2).float() for t in qkv.split(W, dim=-1))
+            ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).transpose(1, 2).reshape(B * L, W)
+            assert (first.float() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
+        else:
+            assert torch.equal(out, first), (rep, int((out != first).any(1).sum()))
+        del junk
+
+
 @pytest.mark.parametrize("B,L,H,causal,grid", [(40, 197, 12, False, 0), (9, 197, 3, False, 5), (30, 50, 12, False, 7), (16, 77, 8, True, 6),
                                                 (5, 256, 2, False, 3), (7, 225, 2, False, 4), (3, 33, 1, True, 2), (2, 1, 1, False, 0),
                                                 (6, 128, 2, True, 4), (3, 129, 2, False, 1)])
