@@ -80,9 +80,12 @@ elif mode == "ln":
     for R, D in ((201728, 768), (70001, 768), (7000 * 77, 512), (257 * 256, 1024)):
         x = (torch.randn(R, D, device="cuda") * 1.3 + 0.2).half()
         g, b = 1 + 0.1 * torch.randn(D, device="cuda"), 0.1 * torch.randn(D, device="cuda")
-        out = {t: torch.zeros(R, D, device="cuda", dtype=torch.float16) for t in libs}
+        buf = torch.zeros(R, D, device="cuda", dtype=torch.float16)          # one output buffer for every build (see the attention mode)
         def call(t):
-            assert libs[t].pclip_layernorm_f16(P(x.data_ptr()), D, P(g.data_ptr()), P(b.data_ptr()), 1e-5, P(out[t].data_ptr()), R, D, st()) == 0
+            assert libs[t].pclip_layernorm_f16(P(x.data_ptr()), D, P(g.data_ptr()), P(b.data_ptr()), 1e-5, P(buf.data_ptr()), R, D, st()) == 0
+        out = {}
+        for t in libs:
+            buf.zero_(); call(t); out[t] = buf.clone()
         med = rounds(call, n=6, iters=10)
         base = next(iter(libs))
         print(f"layernorm [{R},{D}] " + " | ".join(f"{t} {med[t]:7.1f} us ({4.0 * R * D / med[t] / 1e6:5.2f} TB/s{'' if torch.equal(out[t], out[base]) else ' DIFF'})" for t in libs), flush=True)
@@ -91,13 +94,16 @@ else:
         l.pclip_gemm_f16.argtypes = [P, ctypes.c_int, P, ctypes.c_int, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, P, ctypes.c_int, P, P]
     for m, n, k in [(201728, 3072, 768), (201728, 2304, 768), (201728, 768, 768), (201728, 768, 3072)]:
         a = torch.randn(m, k, device="cuda").half(); w = (torch.randn(n, k, device="cuda") * k ** -0.5).half()
-        bias = torch.randn(n, device="cuda").half(); out = {x: torch.empty(m, n, device="cuda", dtype=torch.float16) for x in libs}
+        bias = torch.randn(n, device="cuda").half(); buf = torch.empty(m, n, device="cuda", dtype=torch.float16)       # one output buffer for every build
         resid = torch.randn(m, n, device="cuda").half() if n <= 1024 else None
         cases = {"bias+gelu": (bias, 1, None)} if n == 3072 else ({"bias+res": (bias, 0, resid)} if resid is not None else {"bias": (bias, 0, None)})
         for name, (b, act, rs) in cases.items():
             def call(x):
-                assert libs[x].pclip_gemm_f16(P(a.data_ptr()), k, P(w.data_ptr()), k, P(out[x].data_ptr()), n, m, n, k, P(b.data_ptr()), act,
+                assert libs[x].pclip_gemm_f16(P(a.data_ptr()), k, P(w.data_ptr()), k, P(buf.data_ptr()), n, m, n, k, P(b.data_ptr()), act,
                                               P(rs.data_ptr()) if rs is not None else None, st()) == 0
+            out = {}
+            for x in libs:
+                call(x); out[x] = buf.clone()
             med = rounds(call, n=6, iters=6)
             base = next(iter(libs))
             print(f"{m}x{n}x{k} {name:9s} " + " | ".join(f"{x} {med[x]:7.1f} us ({2.0 * m * n * k / med[x] / 1e6:5.0f} TF{'' if torch.equal(out[x], out[base]) else ' DIFF'})" for x in libs), flush=True)
