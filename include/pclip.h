@@ -148,6 +148,14 @@ int pclip_adapter_conv_f16(const void* x, int B, int D, int three_x, const void*
 int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                    const void* bias, int act, const void* residual, pclip_stream_t stream);
 
+/* The same linear on the FOUR-wave 256 x 256 tile with the hand-scheduled (inline-asm) K-loop of csrc/pclip_gemm4w.hip: one wave per
+ * SIMD, 128 x 128 accumulators per wave, one barrier per K-tile over a ring of five 32 KB half-tile slots.  Bit-identical to
+ * pclip_gemm_f16 (same MFMA, operand roles and k order).  Requires N % 256 == 0, K % 64 == 0, K >= 192, 16-byte aligned rows;
+ * a residual needs a bias and act == 0.  PCLIP_E_INVALID otherwise (pclip_gemm_f16 routes to it by itself where it is faster:
+ * PCLIP_GEMM_4W=0 / 1 overrides).  Replaces the same call sites as pclip_gemm_f16 (clip/model.py:176-190). */
+int pclip_gemm4w_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                     const void* bias, int act, const void* residual, pclip_stream_t stream);
+
 /* The same linear for SMALL M (a serving request: M = 197 x batch rows; the class-token tail of the last block: M = batch),
  * where pclip_gemm_f16 has a dozen tiles for 256 CUs and a K-loop of 12 - 48 dependent round trips: the K range is cut into
  * up to 8 slices (a function of K only), one workgroup per (128 x 64 tile, slice) writing an fp32 slab into ws; a second launch

@@ -3,6 +3,7 @@
 // bias / QuickGELU / residual epilogues, fp32-statistics LayerNorm, and a whole-sequence attention
 // kernel (the CLIP sequences, 50..257 tokens, fit one workgroup, so no online softmax is needed).
 #include "pclip_gemm.h"
+#include "pclip_epilogue.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -14,7 +15,6 @@ using CfgBigT = pgemm::Cfg<256, 256, 2, 4>;
 // ---- nn.Linear on MFMA ------------------------------------------------------------------------
 // Rounding points follow the reference's fp16 tensors: r16(acc + bias); QuickGELU as three fp16
 // elementwise ops (clip/model.py:166); residual add rounds once more (clip/model.py:188-189).
-typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
 struct LinearEpi {
     const half_t* __restrict__ bias;
@@ -105,36 +105,6 @@ __device__ __forceinline__ float2_t stats_from_sums(float s, float q, int D, flo
     return float2_t{mean, 1.f / sqrtf(var + eps)};
 }
 
-// QuickGELU with the reference's three fp16 roundings.  exp / reciprocal use the hardware approximations
-// (v_exp_f32, v_rcp_f32: ~1-2 ulp in fp32), far inside the fp16 rounding that follows each step.
-__device__ __forceinline__ float quick_gelu16(float v) {
-    const float t = r16(1.702f * v);
-    const float s = r16(__builtin_amdgcn_rcpf(1.f + __expf(-t)));
-    return r16(v * s);
-}
-
-// Four at a time with packed fp16 instructions where the arithmetic IS fp16: the two conversions are v_cvt_pk_f16_f32 and the
-// final product h * s of two fp16 values is one correctly rounded v_pk_mul_f16 (= r16 of the exact fp32 product).
-__device__ __forceinline__ half4_t quick_gelu16x4(float4_t v) {
-    const half2_t h01 = __builtin_convertvector(float2_t{v[0], v[1]}, half2_t), h23 = __builtin_convertvector(float2_t{v[2], v[3]}, half2_t);
-    const half_t h[4] = {h01[0], h01[1], h23[0], h23[1]};
-    // The activation arithmetic is what the c_fc epilogue is bound by (VALU: tools/trace_tile.py), so every instruction counts: the exponent's argument
-    // as ONE v_fma_mix_f32 on the fp16 value t (fma(t, -log2 e, 0) == the fp32 product t * -log2 e that __expf(-t) forms, without the separate
-    // v_cvt_f32_f16), the "1 +" of two elements as one v_pk_add_f32: 48 instead of 54 issue slots per four elements, same bits.
-    float ex[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const half_t t = (half_t)(1.702f * (float)h[e]);
-        ex[e] = __builtin_amdgcn_exp2f(__builtin_fmaf((float)t, -1.4426950408889634f, 0.f));
-    }
-    const float2_t one = {1.f, 1.f};
-    const float2_t d01 = float2_t{ex[0], ex[1]} + one, d23 = float2_t{ex[2], ex[3]} + one;
-    const float s[4] = {__builtin_amdgcn_rcpf(d01[0]), __builtin_amdgcn_rcpf(d01[1]), __builtin_amdgcn_rcpf(d23[0]), __builtin_amdgcn_rcpf(d23[1])};
-    const half2_t s01 = __builtin_convertvector(float2_t{s[0], s[1]}, half2_t), s23 = __builtin_convertvector(float2_t{s[2], s[3]}, half2_t);
-    const half2_t y01 = h01 * s01, y23 = h23 * s23;
-    return half4_t{y01[0], y01[1], y23[0], y23[1]};
-}
-
 // The two places of a LayerNorm row where a multiply is followed by an add: hipcc contracted them into an fma in some instantiations and not in others (NCH = 1 and
 // NCH = 2 of the SAME source differed — one fp16 ulp on 1e-5 of the elements — as soon as the code around them changed), and "a row alone == the row in a batch"
 // needs every LayerNorm kernel to round alike.  Spelled out, contraction off: the squared deviations accumulate by fma, the affine is two rounded multiplies and a
@@ -220,20 +190,6 @@ __device__ __forceinline__ void ln_row_pf(const half8_t (&cur)[NCH], int D, int 
             }
         }
     }
-}
-
-// Output rows of the persistent linear kernels: non-temporal 16-byte stores (A/B switch PCLIP_NT_STORE) — a c_fc launch writes
-// 1.2 GB that nobody re-reads before it has left the 4 MiB L2 anyway; keeping it out leaves the L2 to the operand panels.
-#ifndef PCLIP_NT_STORE
-#define PCLIP_NT_STORE 1
-#endif
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void st_out(half_t* p, half8_t v) {
-#if PCLIP_NT_STORE
-    __builtin_nontemporal_store(__builtin_bit_cast(f32x4_t, v), reinterpret_cast<f32x4_t*>(p));
-#else
-    st_half8(p, v);
-#endif
 }
 
 // act 10: the updated residual rows are read again by ANOTHER workgroup (possibly on another XCD, whose L2 is not coherent with this one's) inside the same launch:
@@ -2025,6 +1981,9 @@ inline int flat_grid(size_t n) { size_t g = (n + 255) / 256; return (int)(g < 1 
 // 256x256 on 256 slots = 2.31 rounds, paid as 3) the rows of the partial round are split off and dispatched again,
 // where a smaller tile spreads them over every CU.  Estimated time of a configuration = rounds x tile area x
 // (slots / CUs) / relative K-loop rate (measured on MI355X, tools/ab_cfg.py), in units of 128x128 tile areas.
+#ifndef PCLIP_GEMM_4W_DEFAULT
+#define PCLIP_GEMM_4W_DEFAULT 0
+#endif
 static long g_gemm_launches = 0;
 extern "C" long pclip_gemm_kernel_launches(void) { return g_gemm_launches; }
 
@@ -2058,6 +2017,12 @@ inline int best_cfg(long M, int N, int cus, double* cost_out) {
 bool small_applies(int M, int N, int cus);
 int launch_small_one(const half_t* A, int lda, const half_t* B, int ldb, int M, int N, int K, const LinearEpi& epi, hipStream_t s);
 
+}  // namespace
+// four-wave 256 x 256 tile with the asm K-loop (pclip_gemm4w.hip)
+bool pclip_gemm4w_supports(int M, int N, int K, int lda, int ldb, int ldc, const void* C, const void* bias, const void* residual, int act);
+int pclip_gemm4w_launch(const half_t* A, int lda, const half_t* B, int ldb, int M, int N, int K, const half_t* bias, half_t* C, int ldc, int act,
+                        const half_t* residual, int slots, int rev, hipStream_t s);
+namespace {
 int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int N, int K, LinearEpi epi, int cus, int forced,
                   bool may_split, hipStream_t s) {
     struct MinBn { int old; MinBn(int v) : old(g_min_bn) { g_min_bn = v; } ~MinBn() { g_min_bn = old; } } min_bn(epi.act == 9 ? 64 : 0);
@@ -2120,7 +2085,18 @@ int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int
     if (epi.act == 10 && pick != 2 && pick != 0) return two_launches(pick < 0 ? -2 : pick, false);
     ++g_gemm_launches;
     if (pick < 0 && epi.act == 6) epi.act = 0;                  // generic kernel: bias + residual operands, same roundings
-    if (pick == 2) return launch_fast<CfgBig>(A, lda, B, ldb, M, N, K, epi, cus, s);
+    if (pick == 2) {
+        // the same tile on four waves with the hand-scheduled K-loop (bit-identical): PCLIP_GEMM_4W=1 (default: see DESIGN §3)
+        static bool live4 = getenv("PCLIP_GEMM_CFG_LIVE") != nullptr;
+        static int use4w = -1;
+        if (use4w < 0 || live4) { const char* e = getenv("PCLIP_GEMM_4W"); use4w = e ? atoi(e) : PCLIP_GEMM_4W_DEFAULT; }
+        if (use4w && pclip_gemm4w_supports(M, N, K, lda, ldb, epi.ldc, epi.C, epi.bias, epi.residual, epi.act)) {
+            const TileOrder& order = tile_order();
+            const bool rev = order.rev == 1 || (order.rev == 2 && K <= 1024);
+            return pclip_gemm4w_launch(A, lda, B, ldb, M, N, K, epi.bias, epi.C, epi.ldc, epi.act, epi.residual, cus, rev ? 1 : 0, s);
+        }
+        return launch_fast<CfgBig>(A, lda, B, ldb, M, N, K, epi, cus, s);
+    }
     if (pick == 1) return launch_fast<CfgWide>(A, lda, B, ldb, M, N, K, epi, cus, s);
     if (pick == 0) return launch_fast<CfgSmall>(A, lda, B, ldb, M, N, K, epi, 2 * cus, s);
     if (pick == 3) return launch_fast<CfgNarrow>(A, lda, B, ldb, M, N, K, epi, cus, s);

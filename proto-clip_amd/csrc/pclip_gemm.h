@@ -99,6 +99,17 @@ struct Acc {
     float16_t v[C::TM][C::TN];
 };
 
+// Four consecutive-column accumulators (quad g of 32x32 tile (i, j)) of either accumulator container: the eight-wave kernels keep 32x32 tiles of 16 registers
+// (Acc), the four-wave kernel (pclip_gemm4w.hip) one float4 per 16x16 MFMA tile (Acc16: tile (2 i + (g >> 1), 2 j + (g & 1)) — the operands of its asm K-loop).
+struct Acc16 {
+    float4_t q[8][8];
+};
+template <class C>
+__device__ __forceinline__ float4_t acc_quad(const Acc<C>& acc, int i, int j, int g) {
+    return float4_t{acc.v[i][j][4 * g], acc.v[i][j][4 * g + 1], acc.v[i][j][4 * g + 2], acc.v[i][j][4 * g + 3]};
+}
+__device__ __forceinline__ float4_t acc_quad(const Acc16& acc, int i, int j, int g) { return acc.q[2 * i + (g >> 1)][2 * j + (g & 1)]; }
+
 // Stage K-tile 0 of output tile (m0, n0) into buffer p.
 template <class C>
 __device__ __forceinline__ void stage_first(const half_t* __restrict__ A, int lda, const half_t* __restrict__ B, int ldb,
@@ -611,8 +622,8 @@ __device__ __forceinline__ void mainloop_ring(const half_t* __restrict__ A, int 
 //  step 2 (row-major, all waves): `post(row_in_tile, chunk, pass, half8)` receives 8 consecutive columns of a
 //          row (one ds_read_b128; the XOR may swap the two 8-byte halves) — a wave instruction covers whole
 //          512-byte / 256-byte row segments: 16-byte fully coalesced global stores.
-template <class C, bool M16 = false, class Slab, class Pre, class Post>
-__device__ __forceinline__ void epilogue_f16(const Acc<C>& acc, char* stg, const Slab& slab, const Pre& pre, const Post& post) {
+template <class C, bool M16 = false, class AccT, class Slab, class Pre, class Post>
+__device__ __forceinline__ void epilogue_f16(const AccT& acc, char* stg, const Slab& slab, const Pre& pre, const Post& post) {
     // The lane-constant addressing of the epilogue is recomputed per tile from an OPAQUE copy of the thread id: hipcc otherwise hoists
     // it out of the persistent tile loop and keeps ~10 registers live across the K-loop — spilled around it in the residual kernels
     // (scratch reloads beside LDS-DMA drain the vector-memory counter, guide: "recompute per block").
@@ -641,7 +652,7 @@ __device__ __forceinline__ void epilogue_f16(const Acc<C>& acc, char* stg, const
                         const int coff = M16 ? (g & 1) * 16 + 4 * (lane >> 4) : 8 * g + 4 * hi;
                         const int ml = (wm * WROWS) % C::HR + i * 32 + rl;
                         const int nl = wn * (C::BN / C::WN) + j * 32 + coff;
-                        float4_t v = {acc.v[i][j][4 * g], acc.v[i][j][4 * g + 1], acc.v[i][j][4 * g + 2], acc.v[i][j][4 * g + 3]};
+                        const float4_t v = acc_quad(acc, i, j, g);
                         const half4_t hv = pre(i, j, coff, v, rl, g);
                         const int unit = (nl >> 2) ^ (ml & SWZ);
                         *reinterpret_cast<half4_t*>(stg + ml * RB + unit * 8) = hv;
