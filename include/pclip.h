@@ -151,10 +151,17 @@ int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, void* C, int 
 /* The same linear on the FOUR-wave 256 x 256 tile with the hand-scheduled (inline-asm) K-loop of csrc/pclip_gemm4w.hip: one wave per
  * SIMD, 128 x 128 accumulators per wave, one barrier per K-tile over a ring of five 32 KB half-tile slots.  Bit-identical to
  * pclip_gemm_f16 (same MFMA, operand roles and k order).  Requires N % 256 == 0, K % 64 == 0, K >= 192, 16-byte aligned rows;
- * a residual needs a bias and act == 0.  PCLIP_E_INVALID otherwise (pclip_gemm_f16 routes to it by itself where it is faster:
- * PCLIP_GEMM_4W=0 / 1 overrides).  Replaces the same call sites as pclip_gemm_f16 (clip/model.py:176-190). */
+ * a residual needs a bias and act == 0.  PCLIP_E_INVALID otherwise (pclip_gemm_f16 routes its 256 x 256 tiles to it by itself: pclip_gemm4w_config).  Replaces the same call sites as pclip_gemm_f16 (clip/model.py:176-190). */
 int pclip_gemm4w_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                      const void* bias, int act, const void* residual, pclip_stream_t stream);
+/* ... with the build of the K-loop chosen by the caller: 0 = the product loop, 1 = its RACE-STRESS build (an s_sleep pause of one wave, a different one each
+ * time, in front of every counted s_waitcnt and every barrier: a wait that is too weak then reads stale LDS; tests demand bit-identity with variant 0),
+ * 2 .. = schedule experiments (tools/gen_gemm4w.py VARIANTS).  Test / tuning entry. */
+int pclip_gemm4w_var_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                         const void* bias, int act, const void* residual, int var, pclip_stream_t stream);
+/* Routing of pclip_gemm_f16's 256 x 256 tiles: mode 1 = four-wave asm-loop kernel (default; env PCLIP_GEMM_4W), 0 = eight-wave kernel, < 0 = query only.
+ * Returns the previous setting (-1 = not decided yet).  Same bits either way. */
+int pclip_gemm4w_config(int mode);
 
 /* The same linear for SMALL M (a serving request: M = 197 x batch rows; the class-token tail of the last block: M = batch),
  * where pclip_gemm_f16 has a dozen tiles for 256 CUs and a K-loop of 12 - 48 dependent round trips: the K range is cut into

@@ -45,6 +45,8 @@ _SIGS = {
     "pclip_adapter_conv_f16": [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P],
     "pclip_gemm_f16": [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P],
     "pclip_gemm4w_f16": [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P],
+    "pclip_gemm4w_var_f16": [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P],
+    "pclip_gemm4w_config": [c_int],
     "pclip_gemm_splitk_workspace": [c_int, c_int, c_int],
     "pclip_gemm_splitk_f16": [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_size_t, _P],
     "pclip_gemm_bn_f16": [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P],

@@ -1982,9 +1982,15 @@ inline int flat_grid(size_t n) { size_t g = (n + 255) / 256; return (int)(g < 1 
 // where a smaller tile spreads them over every CU.  Estimated time of a configuration = rounds x tile area x
 // (slots / CUs) / relative K-loop rate (measured on MI355X, tools/ab_cfg.py), in units of 128x128 tile areas.
 #ifndef PCLIP_GEMM_4W_DEFAULT
-#define PCLIP_GEMM_4W_DEFAULT 0
+#define PCLIP_GEMM_4W_DEFAULT 1
 #endif
 static long g_gemm_launches = 0;
+static int g_use4w = -1;                    // 256 x 256 tiles on the four-wave asm-loop kernel: -1 = PCLIP_GEMM_4W / the default, decided at the first launch
+extern "C" int pclip_gemm4w_config(int mode) {
+    const int before = g_use4w;
+    if (mode >= 0) g_use4w = mode != 0;
+    return before;
+}
 extern "C" long pclip_gemm_kernel_launches(void) { return g_gemm_launches; }
 
 namespace {
@@ -2087,10 +2093,8 @@ int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int
     if (pick < 0 && epi.act == 6) epi.act = 0;                  // generic kernel: bias + residual operands, same roundings
     if (pick == 2) {
         // the same tile on four waves with the hand-scheduled K-loop (bit-identical): PCLIP_GEMM_4W=1 (default: see DESIGN §3)
-        static bool live4 = getenv("PCLIP_GEMM_CFG_LIVE") != nullptr;
-        static int use4w = -1;
-        if (use4w < 0 || live4) { const char* e = getenv("PCLIP_GEMM_4W"); use4w = e ? atoi(e) : PCLIP_GEMM_4W_DEFAULT; }
-        if (use4w && pclip_gemm4w_supports(M, N, K, lda, ldb, epi.ldc, epi.C, epi.bias, epi.residual, epi.act)) {
+        if (g_use4w < 0) { const char* e = getenv("PCLIP_GEMM_4W"); g_use4w = e ? (atoi(e) != 0) : PCLIP_GEMM_4W_DEFAULT; }
+        if (g_use4w && pclip_gemm4w_supports(M, N, K, lda, ldb, epi.ldc, epi.C, epi.bias, epi.residual, epi.act)) {
             const TileOrder& order = tile_order();
             const bool rev = order.rev == 1 || (order.rev == 2 && K <= 1024);
             return pclip_gemm4w_launch(A, lda, B, ldb, M, N, K, epi.bias, epi.C, epi.ldc, epi.act, epi.residual, cus, rev ? 1 : 0, s);

@@ -293,6 +293,30 @@ def gemm(a, w, bias=None, act: int = 0, residual=None, out=None):
     return out
 
 
+def gemm4w(a, w, bias=None, act: int = 0, residual=None, out=None, var: int = 0):
+    """ops.gemm on the four-wave asm-loop kernel explicitly (csrc/pclip_gemm4w.hip; ops.gemm routes its 256 x 256 tiles there by itself).  var: 0 product loop,
+    1 race-stress build, 2 .. schedule experiments.  Raises PclipError for shapes outside the kernel (N % 256, K % 64, K >= 192)."""
+    require_cuda(a, w)
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float16, device=a.device)
+    check(_lib.load().pclip_gemm4w_var_f16(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(out), out.stride(0), M, N, K, ptr(bias), act, ptr(residual), var,
+                                           stream()), "pclip_gemm4w_f16")
+    return out
+
+
+class gemm_eight_wave:
+    """`with ops.gemm_eight_wave():` — ops.gemm's 256 x 256 tiles on the eight-wave kernel (the four-wave kernel's bit-identity reference)."""
+    def __enter__(self):
+        self.before = _lib.load().pclip_gemm4w_config(0)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().pclip_gemm4w_config(1 if self.before != 0 else 0)
+        return False
+
+
 # split-K for small M (serving requests).  Opt-in (`with ops.low_latency():`, or PCLIP_GEMM_SPLITK=1): a split call sums K in
 # slices, so its last fp16 bit can differ from the unsplit kernel's — the batch paths keep one arithmetic for every batch size,
 # the serving entry takes the latency.

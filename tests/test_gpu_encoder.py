@@ -166,6 +166,56 @@ def test_gemm_ring_kernel_every_k_tile_count(ops, M, N, K):
     assert ulp_diff(ops.gemm(af, wf, bias, act=1).cpu(), gelu.half()) <= 3
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 192), (1000, 512, 256), (777, 768, 320), (40000, 768, 448), (33333, 1024, 832), (20000, 2304, 768),
+                                   (20000, 768, 3072), (70001, 768, 768)])
+def test_gemm4w_is_the_eight_wave_kernel_bit_for_bit(ops, M, N, K):
+    """The four-wave kernel with the hand-scheduled asm K-loop (csrc/pclip_gemm4w.hip) against the eight-wave persistent kernel it replaces
+    for 256 x 256 tiles: torch.equal for every epilogue — same MFMA, operand roles and k order per accumulator.  The shapes cover every tail variant of the
+    loop (3, 4, 5 K-tiles ...), every phase of the five-slot ring across consecutive output tiles of a workgroup (2 nt mod 5 with several tiles per workgroup),
+    ragged last row tiles and a guard row behind the output; the RACE-STRESS build of the same loop (variant 1: one wave paused in front of every counted wait
+    and barrier) must produce the same bits again, and an exact integer-valued product pins both to the mathematical result."""
+    g = torch.Generator(device="cuda").manual_seed(M + 3 * N + K)
+    a = (torch.randn(M, K, device="cuda", generator=g) * 0.5).half()
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).half()
+    bias = torch.randn(N, device="cuda", generator=g).half()
+    res = torch.randn(M, N, device="cuda", generator=g).half()
+    for act, b, r in ((0, None, None), (0, bias, None), (1, bias, None), (0, bias, res)):
+        with ops.gemm_eight_wave():
+            ref = ops.gemm(a, w, b, act, r)
+        for var in (0, 1):
+            out = torch.full((M + 1, N), 7.0, device="cuda", dtype=torch.float16)
+            ops.gemm4w(a, w, b, act, r, out[:M], var)
+            assert torch.equal(out[:M], ref), (act, var)
+            assert bool((out[M] == 7.0).all())
+        assert torch.equal(ops.gemm(a, w, b, act, r), ref)                     # the default route (four-wave for these shapes)
+    ai = torch.randint(-3, 4, (M, K), device="cuda", generator=g).half()
+    wi = torch.randint(-2, 3, (N, K), device="cuda", generator=g).half()
+    bi = torch.randint(-4, 5, (N,), device="cuda", generator=g).half()
+    exact = (ai[:4096].float() @ wi.float().t() + bi.float()).half()
+    for var in (0, 1):
+        for _ in range(2):
+            assert torch.equal(ops.gemm4w(ai, wi, bi, var=var)[:4096], exact)
+
+
+def test_gemm4w_in_place_residual_and_refusals(ops):
+    a = torch.randn(5000, 768, device="cuda").half()
+    w = (torch.randn(768, 768, device="cuda") * 0.03).half()
+    bias = torch.randn(768, device="cuda").half()
+    x = torch.randn(5000, 768, device="cuda").half()
+    with ops.gemm_eight_wave():
+        ref = ops.gemm(a, w, bias, 0, x)
+    y = x.clone()
+    ops.gemm4w(a, w, bias, 0, y, y)                                            # residual stream updated in place
+    assert torch.equal(y, ref)
+    from proto_clip_amd._lib import PclipError
+    for bad in (lambda: ops.gemm4w(a[:, :128], w[:, :128]),                     # K < 192
+                lambda: ops.gemm4w(a, w[:700]),                                # N % 256
+                lambda: ops.gemm4w(a, w, None, 0, x),                          # residual without bias
+                lambda: ops.gemm4w(a, w, bias, 1, x)):                         # residual with an activation
+        with pytest.raises(PclipError):
+            bad()
+
+
 def test_gemm_splitk_refusals(ops):
     lib = ops._lib.load()
     assert lib.pclip_gemm_splitk_workspace(50432, 768, 768) == 0        # plenty of tiles: the persistent kernel's shape

@@ -9,19 +9,15 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("PCLIP_GEMM_4W", "0")          # pclip_gemm_f16 = the eight-wave reference inside this tool
 from proto_clip_amd import _lib  # noqa: E402
 from proto_clip_amd import ops  # noqa: E402
 
+_lib.load().pclip_gemm4w_config(0)                    # ops.gemm = the eight-wave reference inside this tool
+VAR = 1 if os.environ.get("PCLIP_RACE_STRESS") == "1" else 0
 
-def gemm4w(a, w, bias, act, residual, out):
-    lib = _lib.load()
-    M, K = a.shape
-    N = w.shape[0]
-    rc = lib.pclip_gemm4w_f16(_lib.ptr(a), a.stride(0), _lib.ptr(w), w.stride(0), _lib.ptr(out), out.stride(0), M, N, K, _lib.ptr(bias), act,
-                              _lib.ptr(residual), _lib.stream())
-    _lib.check(rc, "pclip_gemm4w_f16")
-    return out
+
+def gemm4w(a, w, bias, act, residual, out, var=None):
+    return ops.gemm4w(a, w, bias, act, residual, out, VAR if var is None else var)
 
 
 def case(M, N, K, act, use_bias, use_res, seed=0):
@@ -64,12 +60,38 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
+def variants(args):
+    vs = [0] + [int(v) for v in args.variants.split(",")]
+    M = args.imgs * 197
+    shapes = {"in_proj": (M, 2304, 768, 0, True, False), "out_proj": (M, 768, 768, 0, True, True), "c_fc": (M, 3072, 768, 1, True, False),
+              "c_proj": (M, 768, 3072, 0, True, True), "sq8192": (8192, 8192, 8192, 0, True, False)}
+    for name, (m, n, k, act, ub, ur) in shapes.items():
+        a, w, bias, res = case(m, n, k, act, ub, ur)
+        outs = {v: torch.empty(m, n, device="cuda", dtype=torch.float16) for v in vs}
+        def run(v):
+            gemm4w(a, w, bias, act, res, outs[v], v)
+        for v in vs:
+            run(v); run(v)
+        ts = {v: [] for v in vs}
+        for _ in range(args.rounds):
+            for v in vs:
+                ts[v].append(timeit(lambda: run(v), 10))
+        med = {v: sorted(ts[v])[len(ts[v]) // 2] for v in vs}
+        same = all(torch.equal(outs[0], outs[v]) for v in vs)
+        fl = 2.0 * m * n * k
+        print(f"variants {name:9s}: " + " | ".join(f"V{v} {med[v] * 1e6:7.1f} us {fl / med[v] / 1e12:5.0f} TF ({med[0] / med[v]:5.3f})" for v in vs) + f" identical={same}", flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--no-bench", action="store_true")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--imgs", type=int, default=1024)
+    ap.add_argument("--variants", default="", help="comma list of PCLIP_GEMM4W_VAR values timed against variant 0 (same process, interleaved rounds)")
     args = ap.parse_args()
+    if args.variants:
+        return variants(args)
     ok = True
     # ring edge cases: nt = 3, 4, 5, 6 (zero to three steady iterations), ragged M, every epilogue
     for K in (192, 256, 320, 384, 768):

@@ -49,20 +49,24 @@ class Ops:
 
 
 class Gen:
-    def __init__(self, dma_spread=4, dma_first=1, read_stride=2, sleep=0, cold=False):
+    def __init__(self, dma_spread=6, dma_first=9, read_stride=2, sleep=0, cold=False, b1=False, b1_early=False):
         self.lines = []
         self.dma_spread = dma_spread      # MFMAs between two LDS-DMA pieces of a block
         self.dma_first = dma_first        # MFMA index behind which the first piece's M0 write sits
         self.read_stride = read_stride    # MFMAs between two fragment reads
         self.sleep = sleep                # race-stress build: s_sleep jitter around waits (0 = off)
-        self.cold = cold
+        self.cold = cold or b1                # statements without MFMAs: the first tile's prefetch (cold) / the next tile's B'(1) out of the epilogue (b1)
+        self.b1 = b1
+        self.b1_early = b1_early              # B(1) is requested by the PREVIOUS tile's epilogue (PCLIP_GEMM4W_B1), not by this statement's first block
+        cold = self.cold
         o = Ops()
         if not cold:
             for i in range(8):
                 for j in range(8): o.out(f"acc{i}_{j}", "+a", f"acc.q[{i}][{j}]")
             for k in range(32): o.out(f"fr{k}", "=&v", f"fr[{k}]")
             for k in range(4): o.out(f"vr{k}", "=&v", f"vr[{k}]")
-        for k in range(8): o.out(f"nb{k}", "=&v", f"nb[{k}]")
+        if not b1:
+            for k in range(8): o.out(f"nb{k}", "=&v", f"nb[{k}]")
         for k in range(8): o.out(f"so{k}", "=&s", f"so[{k}]")
         for n in ("cnt", "tmp", "scr"): o.out(n, "=&s", f"st_{n}")
         for n in ("wr", "rda", "rdb"): o.out(n, "+s", f"ring_{n}")
@@ -73,7 +77,7 @@ class Gen:
         if not cold: o.inp("nt", "s", "nt")
         o.inp("wbase", "s", "wbase")
         for n in ("voffa0", "voffa1", "voffb0", "voffb1"): o.inp(n, "v", n)
-        o.inp("biasp", "v", "biasp")
+        if not b1: o.inp("biasp", "v", "biasp")
         if not cold:
             o.inp("lanea", "v", "lanea"); o.inp("laneb", "v", "laneb")
         self.ops = o
@@ -131,14 +135,17 @@ class Gen:
         f = {}
         if read_buf is not None:
             for n, ins in enumerate(self.reads(read_buf, read_ks)): self.place(f, n * self.read_stride, ins)
-        g = self.dma_first
+        # two half-tiles in one block (the first block of a statement) fit with four gaps per piece, starting at the first gap
+        g = self.dma_first if len(dmas) < 2 else 1
+        spread = self.dma_spread if len(dmas) < 2 else min(self.dma_spread, 4)
         for op, nxt, pre in dmas:
             for ins in list(pre) + [self.m0_base()]: self.place(f, g, ins)
             for p in range(8):
                 assert g + 2 <= 63, "a piece must not share its gap with its M0 write (one wait state between them)"
                 self.place(f, g, self.dma_m0(p))
                 self.place(f, g + 2, self.dma_load(op, p, nxt))
-                g += self.dma_spread
+                g += spread
+            g = max(g, g - spread + 4)                          # first gap behind the last piece
             for ins in self.ring_next_wr() + self.advance_k(op): self.place(f, g - 1, ins)
         for ins in salu: self.place(f, max(g, 33), ins)
         self.mfma_block(buf, f)
@@ -196,7 +203,21 @@ class Gen:
         self.jitter(7)
         e("s_waitcnt vmcnt(8)")
 
+    def b1_plain(self):
+        """B'(1) of the next output tile into the slot the epilogue has just finished with (issued from the epilogue, one interval before it ends)"""
+        e = self.e
+        e("s_nop 4")
+        for ins in self.reset_k('B', 1): e(ins)
+        e(self.m0_base())
+        for p in range(8):
+            e(self.dma_m0(p)); e("s_nop 0"); e(self.dma_load('B', p, nxt=True))
+        for ins in self.ring_next_wr(): e(ins)
+
     def generate(self):
+        self.lines = []
+        if self.b1:
+            self.b1_plain()
+            return self.lines
         if self.cold:
             self.prefetch_plain()
             return self.lines
@@ -204,13 +225,13 @@ class Gen:
         e("s_nop 4")                                            # SGPR operands fresh from v_readfirstlane -> buffer / global instructions
         # next tile's bias fragment (the caller turns it into the next accumulators' initial value): older than every wait below
         self.bias_loads()
-        # A(0), B(0), A(1) were requested by the previous statement: B continues at K-tile 1, A at K-tile 2
-        for ins in self.reset_k('A', 2) + self.reset_k('B', 1): e(ins)
+        # A(0), B(0), A(1) were requested by the previous statement (and B(1) by the epilogue behind it): B continues at K-tile 1 (2), A at K-tile 2
+        for ins in self.reset_k('A', 2) + self.reset_k('B', 2 if self.b1_early else 1): e(ins)
         self.set_read_addresses()
         for ins in self.reads(0, 0): e(ins)
         for ins in self.ring_next_rd("rda") + self.ring_next_rd("rdb"): e(ins)            # -> K-tile 1
         e("s_waitcnt lgkmcnt(0)")
-        self.block(buf=0, read_buf=1, read_ks=1, dmas=[('B', False, []), ('A', False, [])], salu=[])
+        self.block(buf=0, read_buf=1, read_ks=1, dmas=[('A', False, [])] if self.b1_early else [('B', False, []), ('A', False, [])], salu=[])
         self.jitter(5)
         e("s_waitcnt vmcnt(8) lgkmcnt(0)")                      # K-tile 1 landed (and everything older: the previous tile's output stores), A(2) may fly
         self.jitter(6)
@@ -246,17 +267,31 @@ class Gen:
                 f"#define {name}() \\\n    asm volatile( \\\n{body}\n        : {outs} \\\n        : {ins} \\\n        : \"memory\", \"scc\")\n")
 
 
+# Variants compiled side by side (linear4w_kernel<ACT, HAS_BIAS, VAR>, selected per launch by PCLIP_GEMM4W_VAR): 0 = the product loop, 1 = its race-stress build
+# (s_sleep jitter in front of every counted wait and barrier), 2 .. = schedule experiments measured in the same process (tools/gemm4w_check.py --variants)
+# Measured (profiles/r05_gemm4w_variants.txt, same process, interleaved rounds, bit-identical): pieces behind most of the block's fragment reads (first at MFMA 9, every
+# sixth) +0.5 ... +1.7 % over pieces from the first gap; a burst in the first sixteen gaps -2 ... -3 %; spread over the whole block +-0; B'(1) requested out of the previous
+# tile's epilogue (one interval of lead instead of half a K-tile) -0.9 ... -1.5 %.
+VARIANTS = {
+    0: dict(),
+    1: dict(sleep=3),
+    2: dict(b1_early=True),
+    3: dict(dma_spread=4, dma_first=1),
+    4: dict(dma_spread=5, dma_first=17),
+    5: dict(read_stride=1),
+}
+B1_EARLY = {v: kw.get("b1_early", False) for v, kw in VARIANTS.items()}
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("-o", default="proto-clip_amd/csrc/pclip_gemm4w_loop.inc")
-    ap.add_argument("--dma-spread", type=int, default=4)
-    ap.add_argument("--dma-first", type=int, default=1)
-    ap.add_argument("--read-stride", type=int, default=2)
     a = ap.parse_args()
-    kw = dict(dma_spread=a.dma_spread, dma_first=a.dma_first, read_stride=a.read_stride)
-    txt = Gen(**kw).emit_statement("PCLIP_GEMM4W_LOOP")
-    txt += "\n" + Gen(sleep=3, **kw).emit_statement("PCLIP_GEMM4W_LOOP_STRESS")
-    txt += "\n" + Gen(cold=True, **kw).emit_statement("PCLIP_GEMM4W_COLD")
-    txt += "\n" + Gen(cold=True, sleep=3, **kw).emit_statement("PCLIP_GEMM4W_COLD_STRESS")
+    txt = ""
+    for v, kw in VARIANTS.items():
+        txt += Gen(**kw).emit_statement(f"PCLIP_GEMM4W_LOOP_V{v}") + "\n"
+    txt += Gen(cold=True).emit_statement("PCLIP_GEMM4W_COLD") + "\n" + Gen(cold=True, sleep=3).emit_statement("PCLIP_GEMM4W_COLD_STRESS")
+    txt += "\n" + Gen(b1=True).emit_statement("PCLIP_GEMM4W_B1")
+    txt += "\n#define PCLIP_GEMM4W_NVAR %d\n" % len(VARIANTS)
+    txt += "#define PCLIP_GEMM4W_B1_EARLY(v) (%s)\n" % " || ".join(f"(v) == {v}" for v, on in B1_EARLY.items() if on)
     open(a.o, "w").write(txt)
     print("wrote", a.o)
