@@ -205,20 +205,33 @@ def c2_kernels(device):
             "classify_gb_per_s": byts / t_cl / 1e9, "classify_frac_of_hbm_8tb": byts / t_cl / 8e12}
 
 
-PMC_TRAFFIC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")     # newest committed summary first
+PMC_TRAFFIC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")     # newest committed summary first
 
 
 def pmc_traffic():
     """HBM bytes per GEMM launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE x2 + WRITE_SIZE,
     separate passes, gfx950 correction) — counters cannot be read from inside the process, so the committed summary
-    profiles/rNN_pmc_traffic.json (tools/gpu_pmc.sh) is reported; null when it is absent.  Returns (bytes, file name)."""
+    profiles/rNN_pmc_traffic.json (tools/gpu_r5.sh runs the passes LAST, on the tree that is timed) is reported — but only if it is a summary OF THIS
+    LIBRARY: every GEMM kernel symbol it lists must be a symbol of the libpclip.so that was just timed (round 4 reported counters of an earlier
+    tree).  Returns (bytes or None, file name, note)."""
+    try:
+        from proto_clip_amd._lib import LIB_PATH
+        with open(LIB_PATH, "rb") as f:
+            blob = f.read()
+    except Exception:
+        blob = b""
     for name in PMC_TRAFFIC_FILES:
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
-                return float(json.load(f)["linear_kernel_hbm_bytes_per_launch"]), name
+                d = json.load(f)
+            syms = [k.split(" grid=")[0] for k in d["kernels"] if "linear" in k]
+            stale = [k for k in syms if k.encode() not in blob]
+            if not syms or stale:
+                return None, name, f"stale: {len(stale)} of {len(syms)} GEMM kernel symbols of the summary are not in this libpclip.so (e.g. {stale[0][:60] if stale else '-'}...)"
+            return float(d["linear_kernel_hbm_bytes_per_launch"]), name, "symbols match this libpclip.so"
         except Exception:
             continue
-    return None, None
+    return None, None, "no committed summary"
 
 
 def measure_clock(st, min_steps=40):
@@ -437,12 +450,19 @@ def run(args, hooks, out=None):
             dist.barrier()
         hooks.sync()
 
+    # per-step device times beside the wall clock of the contract: one event per step boundary on the launch stream (recording is asynchronous and costs
+    # nothing inside the timed region) -> median / p10 / p90 (hipEvent median; a box's clock wander is visible as the spread)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if device.type == "cuda" else None
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if evs: evs[i].record()
         step(st)
+    if evs: evs[args.steps].record()
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)) if evs else []
+    pct = lambda q: step_ms[min(len(step_ms) - 1, int(round(q * (len(step_ms) - 1))))] if step_ms else None
     if launched:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -458,7 +478,7 @@ def run(args, hooks, out=None):
     gm = measure_gemm(st) if hooks.instrument else nogm          # every rank runs it: the instrumented step contains the all-gather
     clk = measure_clock(st) if world == 1 and hooks.instrument else {"source": None}
     if rank == 0:
-        traffic, traffic_file = pmc_traffic()
+        traffic, traffic_file, traffic_note = pmc_traffic()
         sclk = (clk.get("sclk_mhz") or {}).get("median")
         power = (clk.get("power_w") or {}).get("median")
         imgs_per_s = args.steps * BATCH * world / dt
@@ -469,7 +489,9 @@ def run(args, hooks, out=None):
             "metric": "query images/sec, ImageNet 16-shot ViT-B/16 (few-shot top-1 parity: tests/)",
             "value": imgs_per_s, "unit": "query images/sec", "n_gpus": world,
             "rccl_world_size": dist.get_world_size() if launched else 1, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * dt / args.steps, "median_ms": pct(0.5), "p10_ms": pct(0.1), "p90_ms": pct(0.9),
+            "step_time_note": "ms_per_step = wall clock over the K steps between the two barriers (the contract); median / p10 / p90 = per-step HIP-event times on rank 0's launch stream inside the same loop",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "sclk_mhz_under_load": sclk, "power_w": power,
             "clock_source": {k: clk.get(k) for k in ("source", "samples", "sclk_mhz", "power_w")},
@@ -477,12 +499,12 @@ def run(args, hooks, out=None):
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "classes": N_CLASS, "shots": SHOTS, "embed_dim": DIM,
                        "alpha": ALPHA, "beta": BETA, "parallelism": f"dp{world} (support rows and queries sharded; all-gather of class sums)"},
             "self_check": check,
-            "roofline": {"bound": "mfma", "kernel": "linear_fast_kernel + linear_small_kernel (fp16 MFMA GEMM: every encoder linear incl. patch embedding and projection, with bias / QuickGELU / residual add in its epilogue"
+            "roofline": {"bound": "mfma", "kernel": "linear4w_kernel (four-wave 256 x 256 tiles, hand-scheduled asm K-loop) + linear_fast_kernel (row-split tails) + linear_small_kernel (fp16 MFMA GEMM: every encoder linear incl. patch embedding and projection, with bias / QuickGELU / residual add in its epilogue"
                                                     + (", the LayerNorms folded into the consuming linears (PCLIP_LN_FOLD=1)" if M.LN_FOLD else "; the LayerNorms are separate passes (default: the reference's rounding points)")
                                                     + "; the class-row tail runs the small-M variant)",
                          "achieved": gm["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gm["tflops"] / MFMA_PEAK_TFLOPS,
                          "frac_at_sustained_clock": (gm["tflops"] / (MFMA_PEAK_TFLOPS * sclk / 2400.0)) if sclk else None,
-                         "traffic": traffic, "traffic_unit": f"HBM bytes per launch (profiles/{traffic_file})",
+                         "traffic": traffic, "traffic_unit": f"HBM bytes per launch (profiles/{traffic_file}: {traffic_note})",
                          "launches_per_step": gm["launches"], "avg_launch_us": gm["avg_us"],
                          "gemm_ms_per_step": gm["total_ms"], "algorithmic_gflop_per_step": gm["flops"] / 1e9},
             "whole_path": {"note": "reference-equivalent = the FLOPs the REFERENCE module spends per image (every token through all 12 blocks); executed = what the HIP path runs "
@@ -501,10 +523,15 @@ def run(args, hooks, out=None):
                 line["extra"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline and hooks.instrument:
             line["cpu_baseline"] = cpu_baseline()
+        if check != "ok":
+            # a step whose rows depend on the batch around them is not the workload: no headline number, and a failing exit status behind the line
+            line["invalid_value"], line["value"] = line["value"], None
         print(json.dumps(line), file=out, flush=True)
     if launched:
         dist.barrier()
         dist.destroy_process_group()
+    if check != "ok":
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

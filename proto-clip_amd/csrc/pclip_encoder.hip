@@ -2738,7 +2738,7 @@ extern "C" int pclip_attention_q_f16(const void* q, int ldq, long q_batch_stride
     if (PCLIP_ATT_QF4 && qfirst && NT <= 4 && Lq == L && !causal)
         attention_kernel<4, PCLIP_ATT_VAR_SHORT, true><<<B * H, 4 * 64, lds, (hipStream_t)stream>>>((const half_t*)q, ldq, q_batch_stride, (const half_t*)kv, ldkv, k_off,
                                                                                                      v_off, (half_t*)out, L, Lq, H, causal, NT, LV);
-    else if ((Lq + 31) / 32 > 4 && (Lq + 31) / 32 <= 8 && qfirst)
+    else if ((Lq + 31) / 32 > 4 && (Lq + 31) / 32 <= 8 && NT <= 8 && qfirst)      // NT <= 8: the kernel's counted waits assume at most four pieces per wave and operand
         attention_kernel<8, PCLIP_ATT_VAR_LONG, true><<<B * H, 8 * 64, lds, (hipStream_t)stream>>>((const half_t*)q, ldq, q_batch_stride, (const half_t*)kv, ldkv, k_off,
                                                                                                     v_off, (half_t*)out, L, Lq, H, causal, NT, LV);
     else if ((Lq + 31) / 32 > 4) PCLIP_ATT_LAUNCH(8, PCLIP_ATT_VAR_LONG);

@@ -501,8 +501,9 @@ def gemm_res_ln(a, w, bias, x, gamma, beta, eps: float = 1e-5, out=None):
     if gamma.dtype != torch.float32 or beta.dtype != torch.float32 or x.stride(0) % 8 or a.stride(0) % 8 or w.stride(0) % 8 or N % 8 or N > 4096 or \
             not out.is_contiguous():
         gemm(a, w, bias, residual=x, out=x)
-        return layernorm(x, gamma, beta, eps, out=out)
+        return layernorm(x, gamma.float(), beta.float(), eps, out=out, rows=M, ld=x.stride(0))   # x may be a row-strided view; the kernel takes fp32 parameters
     cnt = _counters(M // 128 + 2, x.device)
+    cnt.zero_()                      # the kernel leaves them zero only when it runs to completion: a launch that faulted must not poison every later call
     check(_lib.load().pclip_gemm_res_ln_f16(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(x), x.stride(0), M, N, K, ptr(bias), ptr(gamma), ptr(beta),
                                             eps, ptr(out), ptr(cnt), stream()), "pclip_gemm_res_ln_f16")
     return out

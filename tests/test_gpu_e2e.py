@@ -41,6 +41,10 @@ pytestmark = pytest.mark.gpu
 
 # relative L2 per vector against the reference's fp16 chain: 2 x the largest value observed with the LayerNorms unfolded over round 3's
 # six fixtures (profiles/r03_e2e_fold_study.json; the reference's own fp16 <-> fp32 disagreement on the same stages is 0.7 - 1.4e-3)
+FULL_SIZE = ("vitb16", "rn50", "vitl14", "vitb32")        # the backbones of BASELINE's configurations at their real hyper-parameters
+# Absolute criterion beside the rank tests (fixed BEFORE this round's values were looked at: a fifth of the population): at most K_ABOVE of the 20
+# small-tower draws may sit above their tol against the reference's fp16 chain, and at most K_ABOVE against its fp32 chain
+K_ABOVE = 4
 STAGE_BOUNDS = {"test_features": 2.4e-3, "text_bank": 2.4e-3, "adapted": 3.0e-3, "proto_img": 1.8e-3, "proto_txt": 2.4e-3}
 
 
@@ -87,6 +91,11 @@ def test_images_to_logits_against_reference_chain(name, chains):
     for k in STAGES:
         assert r["stage"][k] <= STAGE_BOUNDS[k], (name, k, r["stage"][k])
     assert d16 <= 1.5 * tol and d32 <= 1.5 * tol, (name, d16, d32, tol)               # (i) hard cap; the distribution test below bounds how many sit where
+    if E2E_VARIANTS[name].get("arch") in FULL_SIZE:
+        # north_star's literal bar at the sizes BASELINE names (VERDICT r4 #4a): 1e-3 FLAT against both reference chains, no multiple of the reference's own gap
+        observe(f"image->logits {name}: max|p - p_reference(fp32 towers)| against north_star's flat 1e-3 (full-size architecture)", d32, 1e-3)
+        observe(f"image->logits {name}: max|p - p_reference(fp16 towers)| against north_star's flat 1e-3 (full-size architecture)", d16, 1e-3)
+        assert d32 <= 1e-3 and d16 <= 1e-3, (name, d16, d32)
     assert torch.equal(am[decided], ref_am[decided])                                   # (iii)
     assert agree >= len(am) - int((~decided).sum())
     acc = (am == r["test_y"]).float().mean().item()
@@ -130,6 +139,10 @@ def test_distribution_against_oracle_chain(chains):
     observe("image->logits distribution: 90th percentile d16/tol, HIP over oracle-fp16 chain (recorded)", stats["hip_p90"] / stats["oracle_p90"], 1.25)
     observe("image->logits distribution: 1 - p of 'HIP stochastically larger than oracle' (Wilcoxon signed-rank)", 1.0 - p_rank, 0.95)
     observe("image->logits distribution: 1 - p of 'more fixtures above tol than the oracle' (Fisher exact)", 1.0 - p_tail, 0.95)
+    above32 = sum(1 for n in names if chains(n)["d32"] > _decided(chains(n))[0])
+    observe("image->logits distribution: fixtures above tol vs the reference fp16 chain (absolute count, of 20)", float(stats["hip_above_tol"]), float(K_ABOVE))
+    observe("image->logits distribution: fixtures above tol vs the reference fp32 chain (absolute count, of 20)", float(above32), float(K_ABOVE))
+    assert stats["hip_above_tol"] <= K_ABOVE and above32 <= K_ABOVE, (stats, above32)
     assert stats["hip_mean"] <= 1.25 * stats["oracle_mean"], stats
     assert p_rank >= 0.05, (p_rank, stats)
     assert p_tail >= 0.05, (p_tail, stats)

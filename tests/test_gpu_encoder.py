@@ -395,6 +395,19 @@ def test_gemm_res_ln_equals_two_launches(ops, M, N, K):
     x1 = x0[r:r + 1].clone()
     y1 = ops.gemm_res_ln(a[r:r + 1].contiguous(), w, b, x1, gam, bet)
     assert torch.equal(x1[0], ref[r]) and torch.equal(y1[0], yref[r])
+    if M <= 5000:
+        # a ROW-STRIDED view of x (every second row of a wider buffer), through the fused form and through the Python-side fallback (fp16 LayerNorm parameters):
+        # the LayerNorm must read the rows the GEMM updated (the fallback used to assume contiguous rows)
+        for gm_, bt_ in ((gam, bet), (gam.half(), bet.half())):
+            wide = torch.zeros(M, 2 * N, device="cuda", dtype=torch.float16)
+            xs = wide[:, :N]
+            xs.copy_(x0)
+            ys = ops.gemm_res_ln(a, w, b, xs, gm_, bt_)
+            assert torch.equal(xs, ref) and bool((wide[:, N:] == 0).all())
+            if gm_.dtype == torch.float32:
+                assert torch.equal(ys, yref)
+            else:
+                assert torch.equal(ys, ops.layernorm(ref, gm_.float(), bt_.float()))
 
 
 def test_vit_embed_stats_matches_row_stats(ops):

@@ -230,8 +230,11 @@ def test_fuse_probs_edge_cases(ops):
 
 
 @pytest.mark.parametrize("name", ["C2", "C6", "C5", "C1", "C3"])
-def test_zero_shot_grid_identical_to_reference(ops, name, tmp_path):
-    """main.py:172-199: all three [319, 3] grids of the zero-shot search, identical to the reference's."""
+def test_zero_shot_grid_equals_reference_up_to_proven_ties(ops, name, tmp_path):
+    """main.py:172-199: all three [319, 3] grids of the zero-shot search against the reference's.  Identical — except at grid points where a query's two best
+    classes TIE in the reference's own fp32 arithmetic: there the fp32 summation order of the 512-long dot products decides (MFMA tile vs CPU BLAS).  That is
+    PROVEN, not budgeted (VERDICT r4 #4b): for every grid point that differs, every query whose GPU top-1 differs from the oracle's (the reference's P restated,
+    pinned to it) must have a reference top-2 margin below 1e-6 in p, and the accuracy difference must be exactly what those queries account for."""
     from proto_clip_amd import main as pm
     g = golden("fewshot_" + name)
     split, emb_v, emb_t, cfg = fewshot_inputs(name)
@@ -244,9 +247,27 @@ def test_zero_shot_grid_identical_to_reference(ops, name, tmp_path):
     train_y = split.visual_memory_values.argmax(1)
     for s, f, y in (("val", split.val_features, split.val_labels), ("test", split.test_features, split.test_labels),
                     ("train", split.visual_memory_keys.t().contiguous(), train_y)):
-        got = pm.grid_accuracy(ops.l2norm_rows(dev(f)), dev(y), zi, zt, al, bl)
-        np.testing.assert_array_equal(got[:, :2], g["zs_" + s][:, :2])
-        assert_grid_close(got[:, 2], g["zs_" + s][:, 2], len(y), exact=True, tag=f"zero-shot grid {name}")
+        fq = ops.l2norm_rows(dev(f))
+        got = pm.grid_accuracy(fq, dev(y), zi, zt, al, bl)
+        ref = g["zs_" + s]
+        np.testing.assert_array_equal(got[:, :2], ref[:, :2])
+        differ = np.nonzero(got[:, 2] != ref[:, 2])[0]
+        assert len(differ) <= 0.02 * len(ref), (name, s, len(differ))             # a handful of grid points at most (observed: <= 4 per split)
+        for gi in differ:
+            alpha, beta = float(ref[gi, 0]), float(ref[gi, 1])
+            _, am, _, _ = ops.classify(fq, zi, zt, alpha, beta, want_p=False, want_argmax=True)
+            p_or = po.P(fq.cpu(), zi.cpu(), zt.cpu(), alpha, beta).double()
+            am_or = p_or.max(1)[1]
+            flipped = (am.cpu().long() != am_or).nonzero().flatten()
+            top2 = p_or.topk(2, dim=1).values
+            margin = (top2[:, 0] - top2[:, 1])[flipped]
+            observe(f"zero-shot grid {name}/{s}: reference top-2 margin of a query whose top-1 differs (tie proof)", margin.max().item() if len(flipped) else 0.0, 1e-6)
+            assert len(flipped) >= 1 and bool((margin < 1e-6).all()), (name, s, alpha, beta, flipped.tolist(), margin.tolist())
+            # ... and those ties account for the whole difference at this grid point: the oracle's count is the reference's
+            acc_or = (am_or == y.long()).double().mean().item() * 100.0
+            assert abs(acc_or - float(ref[gi, 2])) <= 100.0 * len(flipped) / len(y) + 1e-9
+            assert abs(float(got[gi, 2]) - float(ref[gi, 2])) <= 100.0 * len(flipped) / len(y) + 1e-9
+        assert_grid_close(got[:, 2], ref[:, 2], len(y), exact=True, tag=f"zero-shot grid {name}")
 
 
 # ---------------------------------------------------------------- adapters -----------------------------
