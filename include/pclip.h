@@ -106,6 +106,16 @@ int pclip_classify_f16(const void* q, const void* zi, const void* zt, int Q, int
                        float one_minus_alpha, float beta, float* p, int32_t* argmax, float* topk_p,
                        int32_t* topk_i, int k, void* ws, size_t ws_bytes, pclip_stream_t stream);
 
+/* Test entry of the fused large-N classification (csrc/pclip_classify_panel.hip; pclip_classify_f16 takes that path by itself for N > 32 when only the argmax is
+ * asked for): the distances it forms for its first tile — dump [2][256][128] fp32 = d2 of query rows 0..255 x classes 0..127, visual bank then textual bank —
+ * with exact != 0 (torch.cdist's sqrt -> square round trip kept: PCLIP_CLASSIFY_PANEL_EXACT=1) they must be the bits pclip_sqdist_f16 writes (utils.py:230-233),
+ * with exact == 0 (the product's arithmetic: max(v, 0), a third faster) within one fp32 ulp of them.  ws as for pclip_classify_f16. */
+/* Routing of pclip_classify_f16's argmax-only calls with N > 32: mode 1 = fused row-panel kernel where the call has at least half a 256-query panel per CU (default; env
+ * PCLIP_CLASSIFY_PANEL), 2 = for every shape it can run (tests), 0 = the two stages, < 0 = query only.  Returns the previous setting (-1 = not decided yet). */
+int pclip_classify_panel_config(int mode);
+int pclip_classify_panel_dump_f16(const void* q, const void* zi, const void* zt, int Q, int N, int D, float* dump, int exact,
+                                  void* ws, size_t ws_bytes, pclip_stream_t stream);
+
 /* (alpha, beta) grid, main.py:142-146, 187-199, 419-430: from the two distance matrices evaluate all
  * na*nb pairs and accumulate correct[ia*nb + ib] += #{q : argmax_n p == labels[q]} (int32, the
  * caller zeroes it; lowest-index tie rule).  Replaces 3*na*nb `P` calls + host syncs. */

@@ -5,6 +5,12 @@
 #include "pclip_gemm.h"
 #include <stdlib.h>
 
+// fused row-panel classification for large class counts (pclip_classify_panel.hip)
+size_t pclip_classify_panel_workspace(int Q, int N, int D);
+bool pclip_classify_panel_applies(int Q, int N, int D, float beta);
+int pclip_classify_panel_launch(const void* q, const void* zi, const void* zt, int Q, int N, int D, const float* q_sq, const float* zi_sq, const float* zt_sq,
+                                float alpha, float oma, float beta, int32_t* argmax, float* dump, bool dump_exact, void* ws, hipStream_t s);
+
 namespace {
 
 // ---- stage 1: squared distances on MFMA ---------------------------------------------------------
@@ -753,12 +759,36 @@ extern "C" int pclip_classify_f16(const void* q, const void* zi, const void* zt,
         }
     }
     SqWs w = carve_sq(ws, Q, N);
+    // large class counts, argmax only: the fused row-panel kernel (pclip_classify_panel.hip) — no distance rows in HBM.  PCLIP_CLASSIFY_PANEL=0: two stages.
+    if (zt && argmax && !p && !topk_p && !topk_i && q && zi && pclip_classify_panel_applies(Q, N, D, beta) &&
+        ws_bytes >= w.bytes + pclip_classify_panel_workspace(Q, N, D)) {
+        int e;
+        if (!q_sq) { if ((e = pclip_row_sqnorm_f16(q, Q, D, w.q_sq, stream))) return e; q_sq = w.q_sq; }
+        if (!zi_sq) { if ((e = pclip_row_sqnorm_f16(zi, N, D, w.zi_sq, stream))) return e; zi_sq = w.zi_sq; }
+        if (!zt_sq) { if ((e = pclip_row_sqnorm_f16(zt, N, D, w.zt_sq, stream))) return e; zt_sq = w.zt_sq; }
+        return pclip_classify_panel_launch(q, zi, zt, Q, N, D, q_sq, zi_sq, zt_sq, alpha, one_minus_alpha, beta, argmax, nullptr, false, (char*)ws + w.bytes, (hipStream_t)stream);
+    }
     const int ldd = padded_ld(N);
     float* d2i = (float*)((char*)ws + w.bytes);
     float* d2t = zt ? (float*)((char*)d2i + align_up((size_t)Q * ldd * 4, 256)) : nullptr;
     int e = pclip_sqdist_f16(q, zi, zt, Q, N, D, q_sq, zi_sq, zt_sq, d2i, d2t, ldd, ws, w.bytes, stream);
     if (e) return e;
     return pclip_fuse_probs(d2i, d2t, Q, N, ldd, alpha, one_minus_alpha, beta, p, argmax, topk_p, topk_i, k, stream);
+}
+
+// Test entry: the distances the fused row-panel kernel forms for its first tile (query rows 0 .. 255 x classes 0 .. 127 of both banks, [2][256][128] fp32): exact != 0
+// — with torch.cdist's sqrt -> square round trip — they must be the bits pclip_sqdist_f16 writes, exact == 0 (the product's arithmetic) within one fp32 ulp of them.
+extern "C" int pclip_classify_panel_dump_f16(const void* q, const void* zi, const void* zt, int Q, int N, int D, float* dump, int exact, void* ws, size_t ws_bytes,
+                                             pclip_stream_t stream) {
+    PCLIP_REQUIRE(q && zi && zt && dump && ws, "pclip_classify_panel_dump_f16: null pointer");
+    PCLIP_REQUIRE(N > 32 && D >= 128 && D % 64 == 0 && D <= 4096 && Q >= 1, "pclip_classify_panel_dump_f16: shape outside the fused kernel");
+    SqWs w = carve_sq(ws, Q, N);
+    if (ws_bytes < w.bytes + pclip_classify_panel_workspace(Q, N, D)) { pclip_set_error("pclip_classify_panel_dump_f16: workspace too small"); return PCLIP_E_WORKSPACE; }
+    int e;
+    if ((e = pclip_row_sqnorm_f16(q, Q, D, w.q_sq, stream))) return e;
+    if ((e = pclip_row_sqnorm_f16(zi, N, D, w.zi_sq, stream))) return e;
+    if ((e = pclip_row_sqnorm_f16(zt, N, D, w.zt_sq, stream))) return e;
+    return pclip_classify_panel_launch(q, zi, zt, Q, N, D, w.q_sq, w.zi_sq, w.zt_sq, 0.5f, 0.5f, 1.f, nullptr, dump, exact != 0, (char*)ws + w.bytes, (hipStream_t)stream);
 }
 
 extern "C" int pclip_hp_sweep(const float* d2i, const float* d2t, const int32_t* labels, int Q, int N, int ldd,

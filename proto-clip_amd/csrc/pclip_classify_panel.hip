@@ -1,0 +1,277 @@
+// Fused classification for LARGE class counts, argmax only (utils.py:225-244 `P` + main.py:190 `.max(1)[1]`).
+// The two-stage path (pclip_sqdist_f16 -> fp32 [Q, ldd] x 2 in HBM -> pclip_fuse_probs) moves ~800 MB of distance rows for an ImageNet test split whose
+// algorithmic traffic is 53 MB.  Here a workgroup owns a PANEL of 256 query rows and walks every class tile of both prototype banks TWICE on the matrix pipe:
+//   pass 1: per query and bank the running minimum distance and the sum of exp(-beta (d2 - min)) (online softmax, in registers)
+//   pass 2: the same distances again -> p = alpha e_i / S_i + (1 - alpha) e_t / S_t -> running (best p, class) per query
+// No distance leaves the chip; the 2 MB of prototypes stay L2-resident.  The second contraction costs as many FLOPs again (2 x 102 GFLOP for ImageNet); what it
+// buys is the 800 MB round trip and the second launch.
+// Layout trick: both banks travel as ONE operand of 2 N rows, row 2 n = visual prototype n, row 2 n + 1 = textual prototype n (`interleave_kernel`, 2 MB, into the
+// caller's workspace): in the (operand-swapped) accumulator layout a lane then holds BOTH banks' distances of a class in adjacent registers, so pass 2 mixes them
+// without exchanging anything.  d2 is the expression of sqdist_kernel — (sqrt(max(||q||^2 + ||z||^2 - 2 q.z, 0)))^2 with the same fp32 norms and the same MFMA k
+// order — i.e. bit-identical distances (tests/test_gpu_parity.py: a sampled tile); the softmax arithmetic is the online form (exp2 with beta log2 e folded in), so p
+// agrees with pclip_fuse_probs to fp32 rounding and the argmax wherever the top-2 margin exceeds that.
+#include "pclip_gemm.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+using CP = pgemm::Cfg<256, 256, 4, 2>;                   // 4 x 2 waves: a lane owns 4 query rows x 32 interleaved columns (16 classes x 2 banks) of a tile
+constexpr float BIG_D2 = 1e30f;                           // squared norm of the padding prototypes: never the minimum, exp() == 0
+
+// zz[2 n + b] = z_b[n] (zero rows beyond N), zz_sq likewise (BIG_D2 beyond N).  One wave per output row.
+__global__ __launch_bounds__(256) void interleave_kernel(const half_t* __restrict__ zi, const half_t* __restrict__ zt, const float* __restrict__ zi_sq,
+                                                         const float* __restrict__ zt_sq, int N, int D, int rows, half_t* __restrict__ zz,
+                                                         float* __restrict__ zz_sq) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int n = r >> 1, b = r & 1;
+    const half_t* src = (b ? zt : zi) + (size_t)n * D;
+    for (int c = lane * 8; c < D; c += 512) st_half8(zz + (size_t)r * D + c, n < N ? ld_half8(src + c) : half8_t{});
+    if (lane == 0) zz_sq[r] = n < N ? (b ? zt_sq : zi_sq)[n] : BIG_D2;
+}
+
+// padded copy of the query norms (whole 256-row panels: the strips are fetched by LDS-DMA without bounds)
+__global__ __launch_bounds__(256) void pad_norms_kernel(const float* __restrict__ src, int Q, int Qp, float* __restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < Qp) dst[i] = i < Q ? src[i] : 0.f;
+}
+
+template <bool EXACT>
+__device__ __forceinline__ float d2_of(float acc, float qs, float zs) {
+    const float v = __fadd_rn(__fadd_rn(-2.f * acc, qs), zs);          // sqdist_kernel's expression, operation for operation
+    if (!EXACT) return fmaxf(v, 0.f);
+    const float d = sqrtf(fmaxf(v, 0.f));
+    return __fmul_rn(d, d);
+}
+
+// DUMP (tests): instead of classifying, the distances of panel 0 / tile 0 are written as sqdist_kernel would ([256][128] per bank) — the bit-identity check
+template <bool EXACT, bool DUMP>
+__global__ __launch_bounds__(512, 2) void classify_panel_kernel(const half_t* __restrict__ q, const half_t* __restrict__ zz, int Q, int rows2, int D,
+                                                                const float* __restrict__ q_sqp, const float* __restrict__ zz_sq, float alpha, float oma,
+                                                                float w, int32_t* __restrict__ argmax, float* __restrict__ dump, int npanels) {
+    using C = CP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* strips = reinterpret_cast<float*>(smem + C::LDS_BYTES);        // [2][256] prototype norms of a tile | [2][256] query norms of a panel
+    float* zstrip = strips;
+    float* qstrip = strips + 512;
+    float* rowc = strips + 1024;                                          // [256][4] per-row constants of pass 2
+    const int G = gridDim.x;
+    int panel = pgemm::xcd_remap(blockIdx.x, G);
+    if (panel >= npanels) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    const int tiles_n = rows2 / C::BN, nt = D / pgemm::BK;
+    using TP = pgemm::TilePairR<C>;
+    TP tp;
+    int p = 0, zpar = 0, qpar = 0;
+    // request K-tile 0 of tile (m0, tn) into buffer p, with the tile's norm strip (every wave copies the strip: uniform vmcnt bookkeeping)
+    auto issue = [&](int m0, int tn, int zp) {
+        __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(zz_sq + tn * C::BN + 4 * lane), (pgemm::lds_ptr_t)(zstrip + zp * 256), 16, 0, 0);
+        tp.prepare(q, D, zz, D, Q, rows2, m0, tn * C::BN, wave, lane);
+        tp.stage(0, smem + p * C::STAGE_BYTES, wave);
+    };
+    auto issue_q = [&](int m0, int qp) {
+        __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(q_sqp + m0 + 4 * lane), (pgemm::lds_ptr_t)(qstrip + qp * 256), 16, 0, 0);
+    };
+    issue_q(panel * C::BM, qpar);
+    issue(panel * C::BM, 0, zpar);
+    for (; panel < npanels; panel += G) {
+        const int m0 = panel * C::BM;
+        const int next_panel = panel + G;
+        // One pass over the panel's class tiles; PASS 0: statistics, PASS 1: argmax.  Separate instantiations (and scopes) per pass: the per-row state of one pass is
+        // not alive during the other's K-loops (all of it at once spilled 29 registers).  `tile_fn(tn, k, d, rowconst)` consumes the lane's distances of row k.
+        auto walk = [&](auto pass_tag, auto&& tile_fn) {
+            constexpr int PASS = decltype(pass_tag)::value;
+#pragma unroll 1
+            for (int tn = 0; tn < tiles_n; ++tn) {
+                pgemm::Acc<C> acc;
+                pgemm::mainloop_sr<C, 0, true, TP>(tp, nt, smem, acc, p, false, wave, lane);
+                const int zp = zpar;
+                // the next tile's K-tile 0 (this panel's next tile, the first tile of its second pass, or the next panel's first) under this tile's arithmetic
+                {
+                    const bool last = tn + 1 == tiles_n;
+                    zpar ^= 1;
+                    if (!last) issue(m0, tn + 1, zpar);
+                    else if (PASS == 0) issue(m0, 0, zpar);
+                    else if (next_panel < npanels) { issue_q(next_panel * C::BM, qpar ^ 1); issue(next_panel * C::BM, 0, zpar); }
+                }
+                const float* zn = zstrip + zp * 256 + wn * 128;
+                const float* qn = qstrip + qpar * 256 + wm * 64;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = k >> 1, a = k & 1;
+                    const float qs = qn[i * 32 + a * 16 + (lane & 15)];
+                    float d[2][16];                        // [bank][class]: class index inside the lane = j * 4 + b * 2 + (e >> 1)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            const float4_t zs = *reinterpret_cast<const float4_t*>(zn + j * 32 + b * 16 + 4 * (lane >> 4));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) d[e & 1][j * 4 + b * 2 + (e >> 1)] = d2_of<EXACT>(acc.v[i][j][(a * 2 + b) * 4 + e], qs, zs[e]);
+                        }
+                    tile_fn(tn, k, d);
+                }
+            }
+        };
+        auto row_of = [&](int k) { return wm * 64 + (k >> 1) * 32 + (k & 1) * 16 + (lane & 15); };     // the lane's four query rows
+        const int slot = wn * 4 + (lane >> 4);                                                         // 0 .. 7: the lanes x waves that share a row
+        if (DUMP) {
+            walk(std::integral_constant<int, 1>{}, [&](int tn, int k, const float (&d)[2][16]) {
+                if (panel != 0 || tn != 0) return;
+#pragma unroll
+                for (int bank = 0; bank < 2; ++bank)
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        const int j = c >> 2, b = (c >> 1) & 1, e2 = c & 1;
+                        const int cls = (wn * 128 + j * 32 + b * 16 + 4 * (lane >> 4)) / 2 + e2;
+                        dump[((size_t)bank * 256 + row_of(k)) * 128 + cls] = d[bank][c];
+                    }
+            });
+            qpar ^= 1;
+            continue;
+        }
+        // ---- pass 1: running minimum / sum of exp2((min - d2) w) per row and bank ----
+        {
+            float mn[4][2], sm[4][2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { mn[k][0] = mn[k][1] = 3e38f; sm[k][0] = sm[k][1] = 0.f; }
+            walk(std::integral_constant<int, 0>{}, [&](int tn, int k, const float (&d)[2][16]) {
+#pragma unroll
+                for (int bank = 0; bank < 2; ++bank) {
+                    float t = d[bank][0];
+#pragma unroll
+                    for (int c = 1; c < 16; ++c) t = fminf(t, d[bank][c]);
+                    const float m2 = fminf(mn[k][bank], t);
+                    float s = sm[k][bank] * __builtin_amdgcn_exp2f((m2 - mn[k][bank]) * w);
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) s += __builtin_amdgcn_exp2f((m2 - d[bank][c]) * w);
+                    mn[k][bank] = m2;
+                    sm[k][bank] = s;
+                }
+            });
+            // combine the partials of the 8 lanes x waves that share a query row through LDS (the buffer of the last K-tile; the prefetch above went to buffer p)
+            float* scr = reinterpret_cast<float*>(smem + (p ^ 1) * C::STAGE_BYTES);
+            pgemm::lds_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<float4_t*>(scr + (row_of(k) * 8 + slot) * 4) = float4_t{mn[k][0], sm[k][0], mn[k][1], sm[k][1]};
+            pgemm::lds_barrier();
+            if (tid < 256) {
+                float m[2] = {3e38f, 3e38f}, s[2] = {0.f, 0.f};
+                float4_t v[8];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) { v[x] = *reinterpret_cast<const float4_t*>(scr + (tid * 8 + x) * 4); m[0] = fminf(m[0], v[x][0]); m[1] = fminf(m[1], v[x][2]); }
+#pragma unroll
+                for (int x = 0; x < 8; ++x) {
+                    s[0] += v[x][1] * __builtin_amdgcn_exp2f((m[0] - v[x][0]) * w);
+                    s[1] += v[x][3] * __builtin_amdgcn_exp2f((m[1] - v[x][2]) * w);
+                }
+                // what pass 2 needs per row: alpha / S_i, min_i, (1 - alpha) / S_t, min_t — in its own LDS strip (the K-tile buffers are about to be refilled)
+                *reinterpret_cast<float4_t*>(rowc + tid * 4) = float4_t{alpha / s[0], m[0], oma / s[1], m[1]};
+            }
+            pgemm::lds_barrier();
+        }
+        // ---- pass 2: p = alpha e_i / S_i + (1 - alpha) e_t / S_t, running (best, class) per row ----
+        {
+            float best[4];
+            int besti[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { best[k] = -1.f; besti[k] = 0x7fffffff; }
+            walk(std::integral_constant<int, 1>{}, [&](int tn, int k, const float (&d)[2][16]) {
+                const float4_t c4 = *reinterpret_cast<const float4_t*>(rowc + row_of(k) * 4);
+                const int cls0 = tn * (C::BN / 2) + (wn * 128 + 4 * (lane >> 4)) / 2;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const int j = c >> 2, b = (c >> 1) & 1, e2 = c & 1;
+                    const float pv = __builtin_fmaf(c4[0], __builtin_amdgcn_exp2f((c4[1] - d[0][c]) * w), c4[2] * __builtin_amdgcn_exp2f((c4[3] - d[1][c]) * w));
+                    if (pv > best[k]) { best[k] = pv; besti[k] = cls0 + j * 16 + b * 8 + e2; }      // ascending class order inside the lane: first maximum kept
+                }
+            });
+            float* scr = reinterpret_cast<float*>(smem + (p ^ 1) * C::STAGE_BYTES);
+            pgemm::lds_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                scr[(row_of(k) * 8 + slot) * 2] = best[k];
+                reinterpret_cast<int*>(scr)[(row_of(k) * 8 + slot) * 2 + 1] = besti[k];
+            }
+            pgemm::lds_barrier();
+            if (tid < 256 && m0 + tid < Q) {
+                float bv = -1.f;
+                int bi = 0x7fffffff;
+#pragma unroll
+                for (int x = 0; x < 8; ++x) {
+                    const float v = scr[(tid * 8 + x) * 2];
+                    const int ix = reinterpret_cast<const int*>(scr)[(tid * 8 + x) * 2 + 1];
+                    if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }           // lowest class among equal maxima (main.py:190 on the CPU)
+                }
+                argmax[m0 + tid] = bi;
+            }
+            pgemm::lds_barrier();                          // the scratch is a K-tile buffer again
+        }
+        qpar ^= 1;
+    }
+}
+}  // namespace
+
+size_t pclip_classify_panel_workspace(int Q, int N, int D) {
+    const size_t rows2 = (size_t)2 * ((N + 127) / 128 * 128), Qp = (size_t)(Q + 255) / 256 * 256;
+    return align_up(rows2 * D * 2, 256) + align_up(rows2 * 4, 256) + align_up(Qp * 4, 256);
+}
+
+static int g_panel_mode = -1;                  // -1: PCLIP_CLASSIFY_PANEL / default (on), decided at the first call
+extern "C" int pclip_classify_panel_config(int mode) {
+    const int before = g_panel_mode;
+    if (mode >= 0) g_panel_mode = mode > 2 ? 1 : mode;
+    return before;
+}
+
+bool pclip_classify_panel_applies(int Q, int N, int D, float beta) {
+    if (g_panel_mode < 0) { const char* e = getenv("PCLIP_CLASSIFY_PANEL"); g_panel_mode = e ? atoi(e) : 1; if (g_panel_mode < 0 || g_panel_mode > 2) g_panel_mode = 1; }
+    // worth it from about half a panel per CU (a panel = 256 queries x every class tile, twice): below that the chip is mostly idle and the two-stage path wins
+    // (FewSOL-198, Q = 666: 112 vs 28 us); mode 2 forces the fused kernel for every shape it can run (tests)
+    int cus = pclip_device_cus();
+    if (cus <= 0) cus = 256;
+    const bool enough = g_panel_mode == 2 || (long)((Q + 255) / 256) * 2 >= cus;
+    return g_panel_mode > 0 && enough && N > 32 && D >= 128 && D % 64 == 0 && D <= 4096 && beta >= 0.f && Q >= 1 && (long)256 * D * 2 < 0x7fffffffL;
+}
+
+// q_sq / zi_sq / zt_sq: device arrays (the caller supplies or has computed them).  dump != nullptr: test mode (distances of panel 0 / tile 0, no argmax; dump_exact:
+// with / without the sqrt round trip).
+int pclip_classify_panel_launch(const void* q, const void* zi, const void* zt, int Q, int N, int D, const float* q_sq, const float* zi_sq, const float* zt_sq,
+                                float alpha, float oma, float beta, int32_t* argmax, float* dump, bool dump_exact, void* ws, hipStream_t s) {
+    const int rows2 = 2 * ((N + 127) / 128 * 128), Qp = (Q + 255) / 256 * 256;
+    char* b = (char*)ws;
+    half_t* zz = (half_t*)b; b += align_up((size_t)rows2 * D * 2, 256);
+    float* zz_sq = (float*)b; b += align_up((size_t)rows2 * 4, 256);
+    float* q_sqp = (float*)b;
+    interleave_kernel<<<ceil_div(rows2, 4), 256, 0, s>>>((const half_t*)zi, (const half_t*)zt, zi_sq, zt_sq, N, D, rows2, zz, zz_sq);
+    pad_norms_kernel<<<ceil_div(Qp, 256), 256, 0, s>>>(q_sq, Q, Qp, q_sqp);
+    int cus = pclip_device_cus();
+    if (cus <= 0) cus = 256;
+    const int npanels = Qp / 256, grid = npanels < cus ? npanels : cus;
+    constexpr int LDS = CP::LDS_BYTES + 8192;
+    // d2 = max(||q||^2 + ||z||^2 - 2 q.z, 0) by default: without torch.cdist's sqrt -> square round trip (<= 1 fp32 ulp from the two-stage path's distances, whose
+    // correctly rounded sqrtf costs twelve VALU instructions per element: 371 vs 250 us on the ImageNet split — the arithmetic this kernel is bound by);
+    // PCLIP_CLASSIFY_PANEL_EXACT=1 keeps the round trip (bit-identical distances)
+    static const bool exact_env = getenv("PCLIP_CLASSIFY_PANEL_EXACT") && getenv("PCLIP_CLASSIFY_PANEL_EXACT")[0] == '1';
+    const bool exact = dump ? dump_exact : exact_env;
+    const float w = beta * 1.4426950408889634f;
+#define PCLIP_PANEL(EX, DU)                                                                                                                      \
+    do {                                                                                                                                         \
+        static DevOnce attr;                                                                                                                     \
+        if (!attr.done()) {                                                                                                                      \
+            if (hipFuncSetAttribute((const void*)classify_panel_kernel<EX, DU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) { \
+                pclip_set_error("pclip_classify_f16: cannot raise the dynamic LDS limit to %d", LDS);                                            \
+                return PCLIP_E_LAUNCH;                                                                                                           \
+            }                                                                                                                                    \
+            attr.set();                                                                                                                          \
+        }                                                                                                                                        \
+        classify_panel_kernel<EX, DU><<<DU ? 1 : grid, 512, LDS, s>>>((const half_t*)q, zz, Q, rows2, D, q_sqp, zz_sq, alpha, oma, w, argmax, dump, DU ? 1 : npanels); \
+    } while (0)
+    if (dump && exact) PCLIP_PANEL(true, true);
+    else if (dump) PCLIP_PANEL(false, true);
+    else if (exact) PCLIP_PANEL(true, false);
+    else PCLIP_PANEL(false, false);
+#undef PCLIP_PANEL
+    return pclip_check_launch("classify (row panels)");
+}

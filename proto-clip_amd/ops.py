@@ -210,6 +210,39 @@ def classify(q, zi, zt, alpha: float, beta: float, want_p=False, want_argmax=Tru
     return p, am, tp, ti
 
 
+class classify_two_stage:
+    """`with ops.classify_two_stage():` — argmax-only classification through pclip_sqdist_f16 + pclip_fuse_probs instead of the fused row-panel kernel (its reference)."""
+    def __enter__(self):
+        self.before = _lib.load().pclip_classify_panel_config(0)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().pclip_classify_panel_config(self.before if self.before >= 0 else 1)
+        return False
+
+
+class classify_fused:
+    """`with ops.classify_fused():` — the fused row-panel kernel for EVERY argmax-only call it can run (by default only calls with enough panels to fill the chip)."""
+    def __enter__(self):
+        self.before = _lib.load().pclip_classify_panel_config(2)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().pclip_classify_panel_config(self.before if self.before >= 0 else 1)
+        return False
+
+
+def classify_panel_distances(q, zi, zt, exact: bool = False):
+    """Test hook: the distances the fused row-panel kernel forms for its first tile, ([256, 128] visual, [256, 128] textual) fp32; exact: with the sqrt round trip."""
+    require_cuda(q, zi, zt)
+    Q, D = q.shape
+    N = zi.shape[0]
+    dump = torch.empty(2, 256, 128, dtype=torch.float32, device=q.device)
+    ws = _workspace(_lib.workspace_bytes(_lib.OP_CLASSIFY, max(Q, 4096), N, D), q.device)
+    check(_lib.load().pclip_classify_panel_dump_f16(ptr(q), ptr(zi), ptr(zt), Q, N, D, ptr(dump), int(exact), ptr(ws), ws.numel(), stream()), "pclip_classify_panel_dump_f16")
+    return dump[0], dump[1]
+
+
 def hp_sweep(d2i, d2t, N: int, labels, alphas, betas) -> torch.Tensor:
     """Correct-counts int32 [na, nb] for every (alpha, beta) pair (main.py:187-199 / 419-430)."""
     require_cuda(d2i, d2t, labels)

@@ -278,7 +278,7 @@ VARIANTS = {
     2: dict(b1_early=True),
     3: dict(dma_spread=4, dma_first=1),
     4: dict(dma_spread=5, dma_first=17),
-    5: dict(read_stride=1),
+    5: dict(),                                # the product loop with an UN-STAGED epilogue: 8-byte stores straight from the accumulator layout (no LDS, no barriers) — experiment
     6: dict(),                                # the product loop WITHOUT the epilogue (nothing is stored): ablation — what a fully hidden epilogue would buy at most
 }
 B1_EARLY = {v: kw.get("b1_early", False) for v, kw in VARIANTS.items()}

@@ -29,3 +29,8 @@ for name, N, K, D, Q in (("EuroSAT C2", 10, 16, 512, 8100), ("OxfordPets", 37, 1
     byts = Q * D * 2 + 2 * N * D * 2 + Q * 4
     print(f"{name:12s} N={N:4d} D={D:4d} Q={Q:5d}: proto_build {t_pb*1e6:6.1f} us | classify(argmax) {t_cl*1e6:7.1f} us "
           f"= {Q/t_cl/1e6:7.1f} M queries/s, {byts/t_cl/1e9:7.1f} GB/s of {byts/1e6:.2f} MB algorithmic", flush=True)
+    if N > 32:
+        with ops.classify_two_stage():
+            t_2s = gpu_time(lambda: ops.classify(q, zi, zt, 0.5, 12.0, want_p=False, want_argmax=True), reps=5)
+        print(f"{'':12s} two-stage path (sqdist + fuse_probs): {t_2s*1e6:7.1f} us -> fused row panels {t_cl*1e6:7.1f} us ({t_2s / t_cl:4.2f} x); "
+              f"{4.0 * Q * N * D * 2 / t_cl / 1e12:6.0f} TFLOP/s executed (two passes x two banks)", flush=True)
