@@ -275,7 +275,7 @@ class Gen:
 VARIANTS = {
     0: dict(),
     1: dict(sleep=3),
-    2: dict(b1_early=True),
+    2: dict(),                                # the product loop with the batched LDS reads on RESIDUAL tiles too (flat addresses): A/B
     3: dict(dma_spread=4, dma_first=1),
     4: dict(dma_spread=5, dma_first=17),
     5: dict(),                                # the product loop with an UN-STAGED epilogue: 8-byte stores straight from the accumulator layout (no LDS, no barriers) — experiment
@@ -293,6 +293,6 @@ if __name__ == "__main__":
     txt += Gen(cold=True).emit_statement("PCLIP_GEMM4W_COLD") + "\n" + Gen(cold=True, sleep=3).emit_statement("PCLIP_GEMM4W_COLD_STRESS")
     txt += "\n" + Gen(b1=True).emit_statement("PCLIP_GEMM4W_B1")
     txt += "\n#define PCLIP_GEMM4W_NVAR %d\n" % len(VARIANTS)
-    txt += "#define PCLIP_GEMM4W_B1_EARLY(v) (%s)\n" % " || ".join(f"(v) == {v}" for v, on in B1_EARLY.items() if on)
+    txt += "#define PCLIP_GEMM4W_B1_EARLY(v) (%s)\n" % (" || ".join(f"(v) == {v}" for v, on in B1_EARLY.items() if on) or "false")
     open(a.o, "w").write(txt)
     print("wrote", a.o)
