@@ -226,6 +226,9 @@ def pmc_traffic():
                 d = json.load(f)
             syms = [k.split(" grid=")[0] for k in d["kernels"] if "linear" in k]
             stale = [k for k in syms if k.encode() not in blob]
+            # ... and it must cover the kernel family that does the work in this library (a round-4 summary knows nothing of linear4w_kernel)
+            if b"linear4w_kernel" in blob and not any("linear4w_kernel" in k for k in syms):
+                stale = stale or ["(no linear4w_kernel entry)"]
             if not syms or stale:
                 return None, name, f"stale: {len(stale)} of {len(syms)} GEMM kernel symbols of the summary are not in this libpclip.so (e.g. {stale[0][:60] if stale else '-'}...)"
             return float(d["linear_kernel_hbm_bytes_per_launch"]), name, "symbols match this libpclip.so"

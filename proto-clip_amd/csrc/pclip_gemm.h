@@ -47,10 +47,32 @@ using CfgSmall = Cfg<128, 128, 2, 2>;
 
 __device__ __forceinline__ int swz_key(int row) { return (row >> 1) & 7; }
 
+// ---- race-stress build (-DPCLIP_RACE_STRESS -> libpclip_stress.so) -------------------------------------------------------------------------
+// Every hand-counted s_waitcnt vmcnt(N) / LDS-only barrier of the library goes through wait_vm / lds_barrier below, and every LDS-DMA piece of the persistent kernels
+// through TileSrc / TilePairR::stage.  In the stress build each of those points first pauses the wave for 0 / 256 / 1024 cycles, pseudo-randomly per wave and call
+// (clock bits ^ hardware wave id ^ call-site salt): a wave that arrives late at a barrier, a piece that is requested late, a wait that returns while the partner wave
+// is far ahead.  A wait that is one piece too weak, or a barrier that does not cover a refill, then reads stale LDS in some launches; tests/test_gpu_stress.py
+// demands the normal library's bits from GEMM (every tile configuration), sqdist_big, the fused classification, attention (every piece-count class) and gemm_res_ln.
+#ifdef PCLIP_RACE_STRESS
+__device__ __forceinline__ void stress_jitter(int salt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned t = (unsigned)__builtin_readcyclecounter();
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 12)" : "=s"(id));
+    const unsigned h = ((t >> 3) ^ (id * 0x9E3779B1u) ^ ((unsigned)salt * 0x85EBCA6Bu)) >> 7;
+    if ((h & 7) == 0) __builtin_amdgcn_s_sleep(16);
+    else if ((h & 7) == 1) __builtin_amdgcn_s_sleep(4);
+#endif
+}
+#else
+__device__ __forceinline__ void stress_jitter(int) {}
+#endif
+
 // Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the vector-memory
 // counter, so global stores and LDS-DMA prefetches stay in flight across it (guide §5 "Pipelining across
 // barriers").  Every LDS read/write issued before it has completed (lgkmcnt(0)) when the wave arrives.
 __device__ __forceinline__ void lds_barrier() {
+    stress_jitter(1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -61,6 +83,7 @@ template <int N>
 __device__ __forceinline__ void wait_vm() {
     // gfx9 s_waitcnt immediate: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]; exp/lgkm left at max
     __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+    stress_jitter(2 + N);
 }
 
 // All waves of the workgroup stage a ROWS x 64 tile: each glds piece is 8 rows x 128 B (64 lanes x 16 B).
@@ -268,6 +291,7 @@ struct TileSrc {
     // AUX: cache-policy bits of the buffer load (0 default, 2 = nt: streamed operand)
     template <int AUX = 0>
     __device__ __forceinline__ void stage(int k_bytes, char* lds_tile, int wave) const {
+        stress_jitter(100);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
         for (int i = 0; i < NL; ++i)
@@ -338,6 +362,7 @@ struct TilePairR {
     }
     // this wave's share of K-tile t into stage buffer `stage_buf` (A image at +0, B image at +A_BYTES)
     __device__ __forceinline__ void stage(int t, char* stage_buf, int wave) const {
+        stress_jitter(101);
 #if defined(__HIP_DEVICE_COMPILE__)
         const int w4 = wave & 3, k = t * (BK * 2);
         if (is_b) {

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Builds profiles/r04_pmc_traffic.json from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes that
+"""Builds profiles/<tag>_pmc_traffic.json (tag = argv[1], default r05) from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes that
 tools/gpu_round.sh leaves under gpurun_out/ (units KB; FETCH_SIZE doubled: gfx950 reports half of wide coalesced
 reads, MI355X_MICROARCH.md §HBM).  Per-launch averages per kernel + the launch-weighted mean over the GEMM kernels."""
 import collections, csv, json, os, sys
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def per_kernel(path, counter):
@@ -25,10 +26,10 @@ for k in sorted(f):
     if k not in w: continue
     hbm = (2.0 * f[k][0] + w[k][0]) * 1024.0
     out["kernels"][k] = {"launches": f[k][1], "fetch_kb_raw": f[k][0], "write_kb": w[k][0], "hbm_bytes_per_launch": hbm}
-    if "linear_fast_kernel" in k or "linear_small_kernel" in k:
+    if "linear_fast_kernel" in k or "linear_small_kernel" in k or "linear4w_kernel" in k:
         gb += hbm * f[k][1]; gn += f[k][1]
 out["linear_kernel_hbm_bytes_per_launch"] = gb / max(gn, 1)
-json.dump(out, open(os.path.join(root, "profiles/r04_pmc_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(root, f"profiles/{TAG}_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k[:90]: v for k, v in out["kernels"].items() if "linear" in k or "attention" in k or "layernorm" in k}, indent=1)[:3000])
 print("GEMM mean bytes/launch", out["linear_kernel_hbm_bytes_per_launch"])
 
@@ -53,6 +54,6 @@ if os.path.exists(mpath):
                              "mfma_util": v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * g),
                              "lds_bank_conflict_frac": v.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(v.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0),
                              "wave_wait_frac": v.get("SQ_WAIT_ANY", 0.0) / max(v.get("SQ_WAVE_CYCLES", 0.0), 1.0)}
-    json.dump(res, open(os.path.join(root, "profiles/r04_pmc_mfma.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(root, f"profiles/{TAG}_pmc_mfma.json"), "w"), indent=1)
     for k, v in list(res["kernels"].items())[:6]:
         print(f"{k[:80]:80s} mfma_util {v['mfma_util']:.3f} lds_conflict {v['lds_bank_conflict_frac']:.3f} wait {v['wave_wait_frac']:.3f}")
