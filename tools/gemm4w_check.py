@@ -37,6 +37,10 @@ def check(M, N, K, act, use_bias, use_res):
     gemm4w(a, w, bias, act, res, out[:M])
     torch.cuda.synchronize()
     same = torch.equal(ref, out[:M]) and bool((out[M] == 7.0).all())
+    if K == 768 and not use_res and use_bias and VAR == 0:       # the unrolled statement with the deferred half (variant 7)
+        out7 = torch.full((M + 1, N), 7.0, device="cuda", dtype=torch.float16)
+        gemm4w(a, w, bias, act, res, out7[:M], 7)
+        same = same and torch.equal(ref, out7[:M]) and bool((out7[M] == 7.0).all())
     err = (ref.float() - out[:M].float()).abs().max().item()
     # independent check of the reference itself (fp32 matmul) so that "identical" is not "identically wrong"
     sl = slice(0, min(M, 512))
@@ -103,7 +107,8 @@ def main():
         ok &= check(40000, 768, K, 0, True, True)
         ok &= check(33333, 1024, K, 1, True, False)
     # more tiles than CUs (persistent rounds), bench widths
-    for (M, N, K, act, ub, ur) in ((20000, 768, 768, 0, True, True), (20000, 2304, 768, 0, True, False), (20000, 3072, 768, 1, True, False),
+    for (M, N, K, act, ub, ur) in ((257, 256, 768, 0, True, False), (1000, 3072, 768, 1, True, False), (66000, 256, 768, 0, True, False), (131072, 512, 768, 1, True, False),
+                                   (20000, 768, 768, 0, True, True), (20000, 2304, 768, 0, True, False), (20000, 3072, 768, 1, True, False),
                                    (20000, 768, 3072, 0, True, True), (70001, 768, 768, 0, True, True)):
         ok &= check(M, N, K, act, ub, ur)
     print("ALL IDENTICAL" if ok else "MISMATCH", flush=True)

@@ -30,7 +30,7 @@ def simulate(gen: Gen, nt: int, wr0: int = 0, rda0: int = 0, rdb0: int = 0x8000,
     labels = {}
     for pc, l in enumerate(prog):
         if l.endswith(":"): labels.setdefault(l[:-1], []).append(pc)
-    S = {"row16a": row16a, "row16b": row16b, "nt": nt, "wbase": wbase, "wr": wr0, "rda": rda0, "rdb": rdb0, "scc": 0, "m0": None}
+    S = {"row16a": row16a, "row16b": row16b, "crow16": 16 * 2304 * 2, "nt": nt, "wbase": wbase, "wr": wr0, "rda": rda0, "rdb": rdb0, "scc": 0, "m0": None}
     V = {"lanea": ("lane", 0), "laneb": ("lane", 0)}          # vector registers that matter: (tag, scalar part)
     events = []                                              # (kind, payload)
     pc, steps = 0, 0
@@ -79,6 +79,9 @@ def simulate(gen: Gen, nt: int, wr0: int = 0, rda0: int = 0, rdb0: int = 0x8000,
             if prog[pc - 1].startswith("s_add_u32 m0"): raise ProtocolError(f"pc {pc}: piece directly behind its M0 write (needs one wait state)")
             events.append(("dma", dict(voff=a[0], rs=rs, soff=S[so], m0=S["m0"], pc=pc)))
         elif op == "global_load_dwordx2": events.append(("vmem", None))
+        elif op == "buffer_store_dwordx4":
+            events.append(("store", dict(reg=a[0], voff=a[1], rs=a[2], soff=S[a[3].split()[0]], off=int(re.search(r"offset:(\d+)", l).group(1)), nt=" nt" in l)))
+        elif op == "s_lshl_b32": S[a[0]] = (val(a[1]) << val(a[2])) & 0xffffffff
         elif op == "ds_read_b128":
             off = int(re.search(r"offset:(\d+)", l).group(1)); base = a[1].split()[0]
             events.append(("read", dict(dst=a[0], kind=V[base][0], slot=V[base][1], off=off, reg=base)))
@@ -136,8 +139,14 @@ def check(gen: Gen, nt: int, wr0=0, rda0=0, rdb0=0x8000, **kw):
     frag_src = {}                                            # fragment register -> (op, t, ks, idx)
     mfma_seen = {}
     reads_in_step = []
+    stores = [e[1] for e in ev if e[0] == "store"]
+    if gen.defer_nt:
+        # the 16 deferred stores, each once: 16-row block 4 + (n >> 2) through the scalar offset, the pair of 16-column blocks n & 3 through the immediate, previous tile's descriptor
+        exp = [dict(reg=f"dq{n}", voff="cvoff", rs="rcp", soff=(4 + (n >> 2)) * S["crow16"], off=(n & 3) * 64, nt=True) for n in range(16)]
+        if stores != exp: raise ProtocolError(f"deferred stores: {[x for x in zip(stores, exp) if x[0] != x[1]][:2]}")
+    elif stores: raise ProtocolError("stores in a statement without a deferred half")
     for kind, p in ev:
-        if kind == "vmem": issued.append(None)
+        if kind in ("vmem", "store"): issued.append(None)
         elif kind == "dma":
             h = stream[ndma // 8]; ndma += 1
             s = slot_of[h]
@@ -216,6 +225,7 @@ def check_all(variants=None, nts=(3, 4, 5, 6, 7, 12, 13, 48)):
             g = Gen(**kw)
             check_mfma_wait(g, nt)
             wr, rda, rdb = check(Gen(cold=True), 0, wr0=0)
+            if kw.get("defer_nt") and kw["defer_nt"] != nt: continue          # unrolled for one K-tile count
             # chain five statements: the ring phase advances by 2 nt mod 5 from tile to tile
             for _ in range(5):
                 if kw.get("b1_early", False): wr, _, _ = check(Gen(b1=True), 0, wr0=wr)          # out of the previous tile's epilogue (the first tile's: behind the cold prefetch)
