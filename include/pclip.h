@@ -166,7 +166,8 @@ int pclip_gemm4w_f16(const void* A, int lda, const void* B, int ldb, void* C, in
                      const void* bias, int act, const void* residual, pclip_stream_t stream);
 /* ... with the build of the K-loop chosen by the caller: 0 = the product loop, 1 = its RACE-STRESS build (an s_sleep pause of one wave, a different one each
  * time, in front of every counted s_waitcnt and every barrier: a wait that is too weak then reads stale LDS; tests demand bit-identity with variant 0),
- * 2 .. = schedule experiments (tools/gen_gemm4w.py VARIANTS).  Test / tuning entry. */
+ * 6 = ABLATION build that runs the K-loops and stores NOTHING (timing only: what a fully hidden epilogue would buy), 7 = K = 768 bias / QuickGELU tiles with the
+ * second half of every tile stored from registers under the next tile's K-loop (bit-identical, measured slower; other shapes fall back to 0).  Test / tuning entry. */
 int pclip_gemm4w_var_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                          const void* bias, int act, const void* residual, int var, pclip_stream_t stream);
 /* Routing of pclip_gemm_f16's 256 x 256 tiles: mode 1 = four-wave asm-loop kernel (default; env PCLIP_GEMM_4W), 0 = eight-wave kernel, < 0 = query only.

@@ -770,7 +770,7 @@ def test_conv3x3_implicit_gemm_equals_im2col_path(ops, B, H, W, Cin, Cout, relu)
         assert (got.float().cpu() - yt).abs().max().item() <= 2e-2 * yt.abs().max().item()
 
 
-@pytest.mark.parametrize("B,L,H,Lq", [(5, 197, 12, 1), (3, 50, 12, 1), (2, 257, 16, 1), (4, 197, 12, 40), (2, 77, 8, 77)])
+@pytest.mark.parametrize("B,L,H,Lq", [(5, 197, 12, 1), (3, 50, 12, 1), (2, 257, 16, 1), (4, 197, 12, 40), (2, 77, 8, 77), (2, 280, 4, 200), (3, 257, 16, 160), (2, 288, 2, 256)])      # the last three: 5 - 8 query tiles against MORE than 8 key tiles (the query-first kernel must not take them)
 def test_attention_first_queries_matches_full_attention(ops, B, L, H, Lq):
     """Separate-operand attention (queries of the first Lq tokens, keys / values of all tokens) against the fused-QKV kernel:
     the rows it produces must be bit-identical to the same rows of the full attention."""

@@ -49,7 +49,7 @@ class Ops:
 
 
 class Gen:
-    def __init__(self, dma_spread=6, dma_first=9, read_stride=2, sleep=0, cold=False, b1=False, b1_early=False, defer_nt=0):
+    def __init__(self, dma_spread=6, dma_first=9, read_stride=2, sleep=0, cold=False, b1=False, b1_early=False, defer_nt=0, first_vm=8):
         self.lines = []
         self.dma_spread = dma_spread      # MFMAs between two LDS-DMA pieces of a block
         self.dma_first = dma_first        # MFMA index behind which the first piece's M0 write sits
@@ -61,6 +61,9 @@ class Gen:
         # defer_nt = nt > 0: the statement is UNROLLED for exactly nt K-tiles and carries, behind the A pieces of its first nt - 3 iterations, the direct stores of the
         # PREVIOUS output tile's deferred half (rows 64 .. 127 of every wave, packed fp16 in 64 registers): half of the epilogue's store issue under the K-loop
         self.defer_nt = defer_nt
+        # counted wait behind the statement's first block: 8 = only A(2) stays in flight; with b1_early on tiles whose last epilogue slab issues exactly eight stores per
+        # wave (bias / QuickGELU tiles: one bounds-checked descriptor, no branch) 24 = those eight stores + the eight bias loads + A(2): B(1) is OLDER than all of them
+        self.first_vm = first_vm
         cold = self.cold
         o = Ops()
         if not cold:
@@ -252,7 +255,7 @@ class Gen:
         e("s_waitcnt lgkmcnt(0)")
         self.block(buf=0, read_buf=1, read_ks=1, dmas=[('A', False, [])] if self.b1_early else [('B', False, []), ('A', False, [])], salu=[])
         self.jitter(5)
-        e("s_waitcnt vmcnt(8) lgkmcnt(0)")                      # K-tile 1 landed (and everything older: the previous tile's output stores), A(2) may fly
+        e(f"s_waitcnt vmcnt({self.first_vm}) lgkmcnt(0)")       # K-tile 1 landed (and everything older: the previous tile's output stores), A(2) may fly
         self.jitter(6)
         e("s_barrier")                                          # B(0)
         # ---- steady iterations t = 0 .. nt - 4
@@ -306,10 +309,9 @@ class Gen:
 VARIANTS = {
     0: dict(),
     1: dict(sleep=3),
-    2: dict(),                                # the product loop with the batched LDS reads on RESIDUAL tiles too (flat addresses): A/B
-    3: dict(dma_spread=4, dma_first=1),
-    4: dict(dma_spread=5, dma_first=17),
-    5: dict(),                                # the product loop with an UN-STAGED epilogue: 8-byte stores straight from the accumulator layout (no LDS, no barriers) — experiment
+    # 2 .. 5: schedule / epilogue experiments of round 5, measured and removed from the product sources (git history: piece placement from the first gap or later, a burst,
+    #         every gap; B'(1) out of the epilogue with and without a relaxed first wait; batched LDS reads on residual tiles; un-staged 8-byte stores) — all within +-1.5 %
+    #         or slower: profiles/r05_gemm4w_variants.txt, r05_gemm4w_epilogue.txt
     6: dict(),                                # the product loop WITHOUT the epilogue (nothing is stored): ablation — what a fully hidden epilogue would buy at most
     7: dict(defer_nt=12),                     # K = 768 (12 K-tiles), bias / QuickGELU tiles: unrolled, the previous tile's second half stored from registers under the loop
 }
@@ -324,7 +326,8 @@ if __name__ == "__main__":
         txt += Gen(**kw).emit_statement(f"PCLIP_GEMM4W_LOOP_V{v}") + "\n"
     txt += Gen(cold=True).emit_statement("PCLIP_GEMM4W_COLD") + "\n" + Gen(cold=True, sleep=3).emit_statement("PCLIP_GEMM4W_COLD_STRESS")
     txt += "\n" + Gen(b1=True).emit_statement("PCLIP_GEMM4W_B1")
-    txt += "\n#define PCLIP_GEMM4W_NVAR %d\n" % len(VARIANTS)
+    txt += "\n#define PCLIP_GEMM4W_NVAR %d\n" % (max(VARIANTS) + 1)
+    txt += "#define PCLIP_GEMM4W_HAS_VAR(v) (%s)\n" % " || ".join(f"(v) == {v}" for v in VARIANTS)
     txt += "#define PCLIP_GEMM4W_B1_EARLY(v) (%s)\n" % (" || ".join(f"(v) == {v}" for v, on in B1_EARLY.items() if on) or "false")
     open(a.o, "w").write(txt)
     print("wrote", a.o)

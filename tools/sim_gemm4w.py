@@ -129,7 +129,7 @@ def check(gen: Gen, nt: int, wr0=0, rda0=0, rdb0=0x8000, **kw):
     # ---- walk the events: ordering rules
     # vector-memory ops in issue order: the half-tile of a piece, None for anything else.  At entry the previous statement's A(1) pieces may still be in flight, with the
     # epilogue's output stores behind them
-    issued = [] if cold else [("A", 1, False)] * 8 + [None] * 24 + ([("B", 1, False)] * 8 if early else []) + [None] * 8
+    issued = [] if cold else [("A", 1, False)] * 8 + [None] * 24 + ([("B", 1, False)] * 8 if early else []) + [None] * 8      # (... + the epilogue's last eight stores)
     landed_visible = {("A", 0, False), ("B", 0, False)}      # published by the previous statement + the caller's barrier
     waited = {("A", 0, False), ("B", 0, False)}              # this wave's pieces have landed (counted wait), not yet published by a barrier
     reads_of = {}                                            # slot -> state of its last read: "pending" (issued), "done" (behind lgkmcnt(0)), "free" (behind a barrier after that)
