@@ -207,6 +207,21 @@ def test_gemm4w_in_place_residual_and_refusals(ops):
     y = x.clone()
     ops.gemm4w(a, w, bias, 0, y, y)                                            # residual stream updated in place
     assert torch.equal(y, ref)
+    # strided operands and output (views of wider buffers), a single row, fewer rows than a tile
+    g = torch.Generator(device="cuda").manual_seed(1)
+    A2 = (torch.randn(3000, 2 * 768, device="cuda", generator=g) * 0.5).half()
+    W2 = (torch.randn(512, 3 * 768, device="cuda", generator=g) * 0.03).half()
+    O2 = torch.full((3000, 1024), 7.0, device="cuda", dtype=torch.float16)
+    b2 = torch.randn(512, device="cuda", generator=g).half()
+    av, wv, ov = A2[:, 768:], W2[:, 768:2 * 768], O2[:, 256:768]
+    with ops.gemm_eight_wave():
+        ref2 = ops.gemm(av.contiguous(), wv.contiguous(), b2, 1)
+    ops.gemm4w(av, wv, b2, 1, None, ov)
+    assert torch.equal(ov, ref2) and bool((O2[:, :256] == 7.0).all()) and bool((O2[:, 768:] == 7.0).all())
+    for m in (1, 100):
+        with ops.gemm_eight_wave():
+            r3 = ops.gemm(a[:m].contiguous(), w, bias, 0)
+        assert torch.equal(ops.gemm4w(a[:m].contiguous(), w, bias, 0), r3)
     from proto_clip_amd._lib import PclipError
     for bad in (lambda: ops.gemm4w(a[:, :128], w[:, :128]),                     # K < 192
                 lambda: ops.gemm4w(a, w[:700]),                                # N % 256
