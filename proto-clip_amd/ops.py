@@ -531,6 +531,7 @@ def gemm_res_ln(a, w, bias, x, gamma, beta, eps: float = 1e-5, out=None):
     N = w.shape[0]
     if out is None:
         out = torch.empty(M, N, dtype=torch.float16, device=x.device)
+    # (N > 4096 is outside the entry point's contract; for 1024 < N <= 4096 the LIBRARY itself runs the two launches — include/pclip.h — with the same bits)
     if gamma.dtype != torch.float32 or beta.dtype != torch.float32 or x.stride(0) % 8 or a.stride(0) % 8 or w.stride(0) % 8 or N % 8 or N > 4096 or \
             not out.is_contiguous():
         gemm(a, w, bias, residual=x, out=x)
