@@ -106,6 +106,16 @@ int pclip_classify_f16(const void* q, const void* zi, const void* zt, int Q, int
                        float one_minus_alpha, float beta, float* p, int32_t* argmax, float* topk_p,
                        int32_t* topk_i, int k, void* ws, size_t ws_bytes, pclip_stream_t stream);
 
+/* Prototype build + classification in ONE launch (csrc/pclip_proto_classify.hip; reference main.py:399-405 followed by utils.py:225-244 / main.py:190):
+ * proto_f16 [N, D] = pclip_proto_build_f16(mem [N*K, D], per_shot_norm) — written, and returned to the caller, by the first N workgroups — and the outputs of
+ * pclip_classify_f16(q, proto_f16, zt, ...) from the other workgroups of the same grid, which wait for the prototypes behind their own query loads.  Same bits as the
+ * two calls.  Shapes: pclip_proto_classify_applies(N, K, D, Q) (N <= 32, D % 32 == 0, D <= 1024, Q >= 1) — otherwise PCLIP_E_ARG: make the two calls.
+ * sync: two int32 words, ZERO before the first call; the kernel leaves them zero.  One pair per stream: calls that may run concurrently must not share it. */
+int pclip_proto_classify_applies(int N, int K, int D, int Q);
+int pclip_proto_classify_f16(const void* mem, int N, int K, int D, int per_shot_norm, void* proto_f16, float* proto_sq, const void* q, const void* zt, int Q,
+                             float alpha, float one_minus_alpha, float beta, float* p, int32_t* argmax, float* topk_p, int32_t* topk_i, int topk,
+                             int32_t* sync, pclip_stream_t stream);
+
 /* Test entry of the fused large-N classification (csrc/pclip_classify_panel.hip; pclip_classify_f16 takes that path by itself for N > 32 when only the argmax is
  * asked for): the distances it forms for its first tile — dump [2][256][128] fp32 = d2 of query rows 0..255 x classes 0..127, visual bank then textual bank —
  * with exact != 0 (torch.cdist's sqrt -> square round trip kept: PCLIP_CLASSIFY_PANEL_EXACT=1) they must be the bits pclip_sqdist_f16 writes (utils.py:230-233),

@@ -142,9 +142,9 @@ def test_ood_performance(cfg, test_loader, clip_model=None, memory_bank_v_path=N
             adapter_weights_path=adapter_weights_path)
         K = cfg["shots"]
         N = embeddings_v.shape[0] // K
-        z_img_proto = ops.proto_build(embeddings_v, N, K)                                            # 96-99
         z_text_proto = ops.l2norm_rows(embeddings_t)                                                 # 101-102
         feats = adapter(test_features, l2norm_out=True)                                              # 104-105
-        _, am, _, _ = ops.classify(feats, z_img_proto, z_text_proto, cfg["alpha"], cfg["beta"], want_p=False, want_argmax=True)
+        # 96-99 (prototypes) + 107-109 (P, argmax): one launch where the class count allows it, the two calls otherwise (same bits)
+        _, _, am, _, _ = ops.proto_classify(embeddings_v, N, K, feats, z_text_proto, cfg["alpha"], cfg["beta"])
         correct = (am.long() == test_labels.to(am.device)).sum().item()
     return 100.0 * correct / max(test_features.shape[0], 1)

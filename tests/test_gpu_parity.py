@@ -212,6 +212,57 @@ def test_classify_single_launch_small_N(ops, Q, N, D, alpha, beta):
         assert (am != am2).sum().item() <= (~clear).sum().item()
 
 
+@pytest.mark.parametrize("Q,N,K,D", [(8100, 10, 16, 512), (1, 1, 1, 32), (17, 3, 5, 64), (333, 16, 4, 512), (1000, 32, 16, 1024), (77, 31, 2, 96),
+                                     (100, 17, 8, 768), (70000, 10, 16, 512), (500, 37, 4, 512), (64, 10, 16, 2048)])
+@pytest.mark.parametrize("per_shot", [True, False])
+def test_proto_classify_one_launch_is_the_two_calls(ops, Q, N, K, D, per_shot):
+    """pclip_proto_classify_f16 (main.py:399-405 + utils.py:225-244 + main.py:190 in one launch: builder workgroups publish the prototypes, the others wait for them
+    behind their own query loads) returns the bits of proto_build followed by classify — prototypes, p, argmax, top-k — call after call (its two sync words are left
+    zero), at a Q that caps the grid, and for shapes without a single-launch form (N > 32, D > 1024: the wrapper makes the two calls)."""
+    mem = dev(torch.from_numpy(synth.normal((N * K, D), 31, 0)).half())
+    q = dev(po.l2norm_rows(torch.from_numpy(synth.normal((Q, D), 31, 1)).half()))
+    zt = dev(po.l2norm_rows(torch.from_numpy(synth.normal((N, D), 31, 2)).half()))
+    k = min(3, N)
+    zi0 = ops.proto_build(mem, N, K, per_shot_norm=per_shot)
+    p0, am0, tp0, ti0 = ops.classify(q, zi0, zt, 0.4, 9.0, want_p=True, want_argmax=True, topk=k)
+    assert ops.proto_classify_applies(N, K, D, Q) == (N <= 32 and D <= 1024)
+    for rep in range(3):
+        zi, p, am, tp, ti = ops.proto_classify(mem, N, K, q, zt, 0.4, 9.0, per_shot_norm=per_shot, want_p=True, want_argmax=True, topk=k, one_launch=True)
+        assert torch.equal(zi, zi0), f"prototypes differ (call {rep})"
+        assert torch.equal(p, p0) and torch.equal(am, am0) and torch.equal(tp, tp0) and torch.equal(ti, ti0), f"classification differs (call {rep})"
+    zi, _, am, _, _ = ops.proto_classify(mem, N, K, q, zt, 0.4, 9.0, per_shot_norm=per_shot, one_launch=True)            # argmax only
+    assert torch.equal(zi, zi0) and torch.equal(am, am0)
+    if ops.proto_classify_applies(N, K, D, Q):
+        assert all(int(b.abs().sum().item()) == 0 for b in ops._sync_words.values()), "sync words not left zero"
+
+
+def test_proto_classify_under_graph_replay(ops):
+    """Recorded into a hipGraph (each recorded call owns a pair of sync words from the arena) and replayed: the same bits every replay, different memory banks between replays."""
+    N, K, D, Q = 10, 16, 512, 8100
+    mem = dev(torch.from_numpy(synth.normal((N * K, D), 32, 0)).half())
+    q = dev(po.l2norm_rows(torch.from_numpy(synth.normal((Q, D), 32, 1)).half()))
+    zt = dev(po.l2norm_rows(torch.from_numpy(synth.normal((N, D), 32, 2)).half()))
+    ops.proto_classify(mem, N, K, q, zt, 1.0, 0.7, one_launch=True)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.proto_classify(mem, N, K, q, zt, 1.0, 0.7, one_launch=True)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        outs = [ops.proto_classify(mem, N, K, q, zt, 1.0, 0.7, one_launch=True) for _ in range(4)]
+    for rep in range(3):
+        mem.copy_(dev(torch.from_numpy(synth.normal((N * K, D), 33 + rep, 0)).half()))
+        gr.replay()
+        torch.cuda.synchronize()
+        zi0 = ops.proto_build(mem, N, K)
+        am0 = ops.classify(q, zi0, zt, 1.0, 0.7, want_p=False, want_argmax=True)[1]
+        for zi, _, am, _, _ in outs:
+            assert torch.equal(zi, zi0) and torch.equal(am, am0)
+
+
 @pytest.mark.parametrize("Q,N,D", [(300, 200, 512), (1000, 1000, 512), (257, 100, 1024), (5000, 198, 768), (33, 40, 128)])
 def test_classify_fused_row_panels(ops, Q, N, D):
     """The fused large-N classification (csrc/pclip_classify_panel.hip): (i) the distances it forms (sampled tile: query rows 0..255 x classes 0..127, both banks) are the BITS
