@@ -45,9 +45,14 @@ __device__ __forceinline__ void classify_small_body(char* smem, const int block,
     if (g < ngroups) {
         const int m = g * 16 + qr;
         const half_t* qrow = q + (size_t)(m < Q ? m : Q - 1) * D + kg * 8;
+        if (steps >= 16) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
-            if (s < steps) qf[s] = ld_half8(qrow + s * 32);
+            for (int s = 0; s < 16; ++s) qf[s] = ld_half8(qrow + s * 32);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                if (s < steps) qf[s] = ld_half8(qrow + s * 32);
+        }
         have = true;
     }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -115,6 +120,38 @@ __device__ __forceinline__ void classify_small_body(char* smem, const int block,
             for (int t = 0; t < NT; ++t) { acc[b][t] = float4_t{0.f, 0.f, 0.f, 0.f}; zn[b][t] = 0.f; }
         float qs = 0.f;
         for (int s0 = 0; s0 < steps; s0 += 16) {                                    // 512 k per pass: 16 query loads in flight
+            if (steps - s0 >= 16) {
+                // a full pass, free of per-step branches: the LDS fragment reads of four steps are issued together (a branch per step kept every read -> MFMA pair a
+                // serial LDS round trip: 1.8 us of the 7.4 us EuroSAT launch; profiles/r05_c2_phases.txt)
+                if (!have) {
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) qf[s] = ld_half8(qrow + (s0 + s) * 32);
+                }
+                have = false;
+#pragma unroll
+                for (int s4 = 0; s4 < 16; s4 += 4) {
+                    half8_t zf[4][NB][NT];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int b = 0; b < NB; ++b)
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+                                zf[u][b][t] = *reinterpret_cast<const half8_t*>(smem + ((b * NT + t) * 16 + qr) * row_bytes + (s0 + s4 + u) * 64 + kg * 16);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        qs = sq8(qf[s4 + u], qs);
+#pragma unroll
+                        for (int b = 0; b < NB; ++b)
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) {
+                                zn[b][t] = sq8(zf[u][b][t], zn[b][t]);
+                                acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zf[u][b][t], qf[s4 + u], acc[b][t], 0, 0, 0);
+                            }
+                    }
+                }
+                continue;
+            }
             if (!have) {
 #pragma unroll
                 for (int s = 0; s < 16; ++s)
@@ -136,8 +173,8 @@ __device__ __forceinline__ void classify_small_body(char* smem, const int block,
                         }
                 }
         }
-        qs += __shfl_xor(qs, 16, WAVE);
-        qs += __shfl_xor(qs, 32, WAVE);
+        qs += lane_xor<16>(qs);
+        qs += lane_xor<32>(qs);
         // cdist epilogue + softmax over the classes of this query (utils.py:225-244), as in sqdist_kernel / fuse_probs_kernel
         float pr[NT][4];
 #pragma unroll
@@ -146,8 +183,8 @@ __device__ __forceinline__ void classify_small_body(char* smem, const int block,
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 float zsq = zn[b][t];                                                 // ||z_c||^2 of class t*16 + qr ...
-                zsq += __shfl_xor(zsq, 16, WAVE);
-                zsq += __shfl_xor(zsq, 32, WAVE);
+                zsq += lane_xor<16>(zsq);
+                zsq += lane_xor<32>(zsq);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float zs = __shfl(zsq, cls0 + e, WAVE);                     // ... moved to the accumulator layout
@@ -157,8 +194,8 @@ __device__ __forceinline__ void classify_small_body(char* smem, const int block,
                     if (t * 16 + cls0 + e < N) { mn = fminf(mn, d2[t][e]); mx = fmaxf(mx, d2[t][e]); }
                 }
             }
-            mn = fminf(mn, __shfl_xor(mn, 16, WAVE)); mn = fminf(mn, __shfl_xor(mn, 32, WAVE));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE)); mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+            mn = fminf(mn, lane_xor<16>(mn)); mn = fminf(mn, lane_xor<32>(mn));
+            mx = fmaxf(mx, lane_xor<16>(mx)); mx = fmaxf(mx, lane_xor<32>(mx));
             const float top = __fmul_rn(beta, beta >= 0.f ? -mn : -mx);
             float sum = 0.f;
 #pragma unroll
@@ -168,8 +205,8 @@ __device__ __forceinline__ void classify_small_body(char* smem, const int block,
                     d2[t][e] = (t * 16 + cls0 + e < N) ? expf(__fsub_rn(__fmul_rn(beta, -d2[t][e]), top)) : 0.f;
                     sum += d2[t][e];
                 }
-            sum += __shfl_xor(sum, 16, WAVE);
-            sum += __shfl_xor(sum, 32, WAVE);
+            sum += lane_xor<16>(sum);
+            sum += lane_xor<32>(sum);
             const float w = b ? oma : alpha;
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -194,12 +231,8 @@ __device__ __forceinline__ void classify_small_body(char* smem, const int block,
                 }
             }
         auto quad_argmax = [&](float& v, int& i) {
-#pragma unroll
-            for (int off = 16; off <= 32; off <<= 1) {
-                const float ov = __shfl_xor(v, off, WAVE);
-                const int oi = __shfl_xor(i, off, WAVE);
-                if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-            }
+            { const float ov = lane_xor<16>(v); const int oi = lane_xor_i<16>(i); if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; } }
+            { const float ov = lane_xor<32>(v); const int oi = lane_xor_i<32>(i); if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; } }
         };
         if (argmax) {
             quad_argmax(best, besti);

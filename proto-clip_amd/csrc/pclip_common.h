@@ -30,29 +30,60 @@ int pclip_check_launch(const char* what);
 // round fp32 -> fp16 -> fp32 (the r16() of SURVEY Appendix A; RNE like torch's .half())
 __device__ __forceinline__ float r16(float x) { return (float)(half_t)x; }
 
+// Value of lane (id ^ OFF), OFF in {1, 2, 4, 8, 16, 32}, on the VALU: DPP (quad_perm, row_ror:8, row_shl:4 / row_shr:4 under bank masks) and the gfx950 row / half swaps
+// (v_permlane16_swap, v_permlane32_swap) — __shfl_xor compiles to ds_bpermute_b32, an LDS-pipe round trip of ~100 cycles per butterfly level, which IS the run time of
+// the latency-bound kernels (one wave per row: prototype build, small-N classification, row norms).  Same partner lanes, so the reductions below keep their bits.
+template <int OFF>
+__device__ __forceinline__ int lane_xor_i(int v) {
+    static_assert(OFF == 1 || OFF == 2 || OFF == 4 || OFF == 8 || OFF == 16 || OFF == 32, "lane_xor: power-of-two distance inside a wave");
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (OFF == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);     // {own, partner} below lane 32, {partner, own} above
+        return (int)(r[0] ^ r[1] ^ (unsigned)v);
+    } else if constexpr (OFF == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);     // the same per pair of 16-lane rows
+        return (int)(r[0] ^ r[1] ^ (unsigned)v);
+    } else if constexpr (OFF == 8) {
+        return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false);                             // row_ror:8
+    } else if constexpr (OFF == 4) {
+        const int t = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xF, 0x5, false);                      // row_shl:4 into the banks (4-lane groups) 0 and 2: lane i <- i + 4
+        return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xF, 0xA, false);                             // row_shr:4 into the banks 1 and 3:                lane i <- i - 4
+    } else if constexpr (OFF == 2) {
+        return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);                              // quad_perm [2, 3, 0, 1]
+    } else {
+        return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);                              // quad_perm [1, 0, 3, 2]
+    }
+#else
+    return v;
+#endif
+}
+template <int OFF>
+__device__ __forceinline__ float lane_xor(float v) { return __builtin_bit_cast(float, lane_xor_i<OFF>(__builtin_bit_cast(int, v))); }
+
+#define PCLIP_BUTTERFLY(STEP) do { STEP(32); STEP(16); STEP(8); STEP(4); STEP(2); STEP(1); } while (0)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+#define PCLIP_STEP(OFF) v += lane_xor<OFF>(v)
+    PCLIP_BUTTERFLY(PCLIP_STEP);
+#undef PCLIP_STEP
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, WAVE));
+#define PCLIP_STEP(OFF) v = fmaxf(v, lane_xor<OFF>(v))
+    PCLIP_BUTTERFLY(PCLIP_STEP);
+#undef PCLIP_STEP
     return v;
 }
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, WAVE));
+#define PCLIP_STEP(OFF) v = fminf(v, lane_xor<OFF>(v))
+    PCLIP_BUTTERFLY(PCLIP_STEP);
+#undef PCLIP_STEP
     return v;
 }
 // (value, index) argmax with lowest-index tie rule (torch CPU max, main.py:190)
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        float ov = __shfl_xor(v, off, WAVE);
-        int oi = __shfl_xor(i, off, WAVE);
-        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-    }
+#define PCLIP_STEP(OFF) do { const float ov = lane_xor<OFF>(v); const int oi = lane_xor_i<OFF>(i); if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; } } while (0)
+    PCLIP_BUTTERFLY(PCLIP_STEP);
+#undef PCLIP_STEP
 }
 
 __device__ __forceinline__ half8_t ld_half8(const half_t* p) { return *reinterpret_cast<const half8_t*>(p); }
