@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void hp_sweep_kernel(const float* __restrict__
 
 // ---- small class counts (N <= 32): pclip_classify_small.h -------------------------------------------------------
 template <int NT, bool TWO>
-__global__ __launch_bounds__(512) void classify_small_kernel(const half_t* __restrict__ q, const half_t* __restrict__ zi,
+__global__ __launch_bounds__(256) void classify_small_kernel(const half_t* __restrict__ q, const half_t* __restrict__ zi,
                                                              const half_t* __restrict__ zt, int Q, int N, int D, float alpha,
                                                              float oma, float beta, float* __restrict__ p,
                                                              int32_t* __restrict__ argmax, float* __restrict__ topk_p,
@@ -406,29 +406,15 @@ __global__ __launch_bounds__(512) void classify_small_kernel(const half_t* __res
     classify_small_body<NT, TWO, false>(smem, blockIdx.x, gridDim.x, q, zi, zt, Q, N, D, alpha, oma, beta, p, argmax, topk_p, topk_i, k);
 }
 
-
 template <int NT, bool TWO>
 int launch_classify_small(const void* q, const void* zi, const void* zt, int Q, int N, int D, float alpha, float oma, float beta,
                           float* p, int32_t* argmax, float* topk_p, int32_t* topk_i, int k, int cus, hipStream_t s) {
-    const size_t lds = (size_t)(TWO ? 2 : 1) * NT * 16 * (D * 2 + 16);
-    static DevOnce attr;
-    if (!attr.done()) {
-        if (hipFuncSetAttribute((const void*)classify_small_kernel<NT, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-            pclip_set_error("pclip_classify_f16: cannot raise the dynamic LDS limit");
-            return PCLIP_E_LAUNCH;
-        }
-        attr.set();
-    }
+    constexpr int NWAVES = 4, GPW = TWO ? NWAVES / 2 : NWAVES;      // four waves: two (visual, textual) pairs, or four groups with one bank
     const int ngroups = ceil_div(Q, 16);
-    int wg_per_cu = (int)((size_t)160 * 1024 / lds);
-    if (wg_per_cu > 8) wg_per_cu = 8;
-    const bool spread = ngroups <= 2 * cus * wg_per_cu;          // 2-wave workgroups give every group its own slot at once
-    static int spread_waves = getenv("PCLIP_CLASSIFY_SMALL_WAVES") ? atoi(getenv("PCLIP_CLASSIFY_SMALL_WAVES")) : 4;
-    const int nwaves = spread ? spread_waves : 8;
-    int grid = ceil_div(ngroups, nwaves);
-    if (grid > cus * wg_per_cu) grid = cus * wg_per_cu;
-    classify_small_kernel<NT, TWO><<<grid, nwaves * 64, lds, s>>>((const half_t*)q, (const half_t*)zi, (const half_t*)zt, Q, N, D, alpha,
-                                                                 oma, beta, p, argmax, topk_p, topk_i, k);
+    int grid = ceil_div(ngroups, GPW);
+    if (grid > 2 * cus) grid = 2 * cus;                             // ~200 registers per lane: two workgroups per CU; larger Q loops
+    classify_small_kernel<NT, TWO><<<grid, NWAVES * 64, TWO ? classify_small_lds(NT, NWAVES) : 0, s>>>((const half_t*)q, (const half_t*)zi, (const half_t*)zt, Q, N, D,
+                                                                                                        alpha, oma, beta, p, argmax, topk_p, topk_i, k);
     return pclip_check_launch("classify (small N)");
 }
 
@@ -564,8 +550,7 @@ extern "C" int pclip_classify_f16(const void* q, const void* zi, const void* zt,
             if (cus <= 0) cus = 256;
         }
         const int nt = N <= 16 ? 1 : 2;
-        const size_t lds = (size_t)(zt ? 2 : 1) * nt * 16 * ((size_t)D * 2 + 16);
-        if (mode > 0 && N > 0 && N <= 32 && D > 0 && D % 32 == 0 && lds <= 150 * 1024 && q && zi && k >= 0 && k <= N && k <= 16 &&
+        if (mode > 0 && N > 0 && N <= 32 && D > 0 && D % 32 == 0 && q && zi && k >= 0 && k <= N && k <= 16 &&
             ((!topk_p && !topk_i) || k > 0)) {
             hipStream_t s = (hipStream_t)stream;
 #define PCLIP_SMALL(NT)                                                                                                                   \

@@ -40,22 +40,12 @@ __global__ __launch_bounds__(256) void proto_classify_kernel(const half_t* __res
 template <int NCH, int NT>
 int launch(const void* mem, int N, int K, int D, int per_shot_norm, void* proto, float* proto_sq, const void* q, const void* zt, int Q, float alpha, float oma,
            float beta, float* p, int32_t* argmax, float* topk_p, int32_t* topk_i, int k, int* sync, int cus, hipStream_t s) {
-    const size_t lds_c = (size_t)2 * NT * 16 * (D * 2 + 16), lds_b = (size_t)4 * NCH * 512 * 4;
+    const size_t lds_c = classify_small_lds(NT, 4), lds_b = (size_t)4 * NCH * 512 * 4;
     const size_t lds = lds_c > lds_b ? lds_c : lds_b;
-    static DevOnce attr;
-    if (!attr.done()) {
-        if (hipFuncSetAttribute((const void*)proto_classify_kernel<NCH, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-            pclip_set_error("pclip_proto_classify_f16: cannot raise the dynamic LDS limit");
-            return PCLIP_E_LAUNCH;
-        }
-        attr.set();
-    }
     static const int wt = getenv("PCLIP_PROTO_CLASSIFY_WT") ? atoi(getenv("PCLIP_PROTO_CLASSIFY_WT")) : 1;
     const int ngroups = ceil_div(Q, 16);
-    int wg_per_cu = (int)((size_t)160 * 1024 / lds);
-    if (wg_per_cu > 8) wg_per_cu = 8;
-    int consumers = ceil_div(ngroups, 4);
-    const int cap = cus * wg_per_cu - N;
+    int consumers = ceil_div(ngroups, 2);                           // four waves: two (visual, textual) pairs per workgroup
+    const int cap = 2 * cus - N;
     if (consumers > cap) consumers = cap > 1 ? cap : 1;
     proto_classify_kernel<NCH, NT><<<N + consumers, 256, lds, s>>>((const half_t*)mem, K, per_shot_norm, (half_t*)proto, proto_sq, (const half_t*)q,
                                                                   (const half_t*)zt, Q, N, D, alpha, oma, beta, p, argmax, topk_p, topk_i, k, sync, wt);
