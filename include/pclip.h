@@ -106,6 +106,15 @@ int pclip_classify_f16(const void* q, const void* zi, const void* zt, int Q, int
                        float one_minus_alpha, float beta, float* p, int32_t* argmax, float* topk_p,
                        int32_t* topk_i, int k, void* ws, size_t ws_bytes, pclip_stream_t stream);
 
+/* The fused row-panel classification walks the class tiles ONCE where it can prove the result (csrc/pclip_classify_panel.hip: per group of 16 classes the nearest
+ * class of each bank is kept as a candidate, everybody else is bounded through the group's second smallest distances; a panel whose rows all satisfy
+ * max bound < best candidate is finished from the candidates — the very argmax of the second pass — and only the others walk the tiles again).
+ * pclip_classify_panel_passes: 0 = that (default; env PCLIP_CLASSIFY_PANEL_PASSES), 1 = always two passes (round 5's first form), 2 = candidates computed but every panel
+ * sent through the second pass (tests); returns the previous mode, a negative argument only queries.  pclip_classify_panel_stats: out2[0] = panels classified,
+ * out2[1] = panels that needed the second pass, since the last reset (host pointers; synchronises the device). */
+int pclip_classify_panel_passes(int mode);
+int pclip_classify_panel_stats(int* out2, int reset);
+
 /* Prototype build + classification in ONE launch (csrc/pclip_proto_classify.hip; reference main.py:399-405 followed by utils.py:225-244 / main.py:190):
  * proto_f16 [N, D] = pclip_proto_build_f16(mem [N*K, D], per_shot_norm) — written, and returned to the caller, by the first N workgroups — and the outputs of
  * pclip_classify_f16(q, proto_f16, zt, ...) from the other workgroups of the same grid, which wait for the prototypes behind their own query loads.  Same bits as the

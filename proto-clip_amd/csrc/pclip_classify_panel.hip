@@ -5,6 +5,12 @@
 //   pass 2: the same distances again -> p = alpha e_i / S_i + (1 - alpha) e_t / S_t -> running (best p, class) per query
 // No distance leaves the chip; the 2 MB of prototypes stay L2-resident.  The second contraction costs as many FLOPs again (2 x 102 GFLOP for ImageNet); what it
 // buys is the 800 MB round trip and the second launch.
+// ONE pass where the result can be proven (default since round 5's second half; pclip_classify_panel_passes): pass 1 also leaves, per (row, lane-slot, tile) group of
+// 16 classes, a 32-byte record in the workspace — per bank the nearest class with BOTH its distances, and the group's second smallest distance.  The nearest classes
+// are the candidates; every other class of a group is bounded through the second smallest distances (p is monotone in both).  When the largest bound of a row is
+// below its best candidate's p, the candidates' argmax is the row's argmax — the bits pass 2 would produce — and a panel all of whose rows satisfy that skips pass 2.
+// Class-structured data (the few-shot setting) proves every panel: ImageNet split 245 -> ~175 us; structureless rows (every distance alike, flat p) mostly take the
+// second pass and pay the records on top (+13 %).
 // Layout trick: both banks travel as ONE operand of 2 N rows, row 2 n = visual prototype n, row 2 n + 1 = textual prototype n (`interleave_kernel`, 2 MB, into the
 // caller's workspace): in the (operand-swapped) accumulator layout a lane then holds BOTH banks' distances of a class in adjacent registers, so pass 2 mixes them
 // without exchanging anything.  d2 is the expression of sqdist_kernel — (sqrt(max(||q||^2 + ||z||^2 - 2 q.z, 0)))^2 with the same fp32 norms and the same MFMA k
@@ -13,6 +19,9 @@
 #include "pclip_gemm.h"
 #include <stdlib.h>
 #include <type_traits>
+
+typedef int int2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
 
 namespace {
 using CP = pgemm::Cfg<256, 256, 4, 2>;                   // 4 x 2 waves: a lane owns 4 query rows x 32 interleaved columns (16 classes x 2 banks) of a tile
@@ -45,10 +54,11 @@ __device__ __forceinline__ float d2_of(float acc, float qs, float zs) {
 }
 
 // DUMP (tests): instead of classifying, the distances of panel 0 / tile 0 are written as sqdist_kernel would ([256][128] per bank) — the bit-identity check
-template <bool EXACT, bool DUMP>
+template <bool EXACT, bool DUMP, bool CAND>
 __global__ __launch_bounds__(512, 2) void classify_panel_kernel(const half_t* __restrict__ q, const half_t* __restrict__ zz, int Q, int rows2, int D,
                                                                 const float* __restrict__ q_sqp, const float* __restrict__ zz_sq, float alpha, float oma,
-                                                                float w, int32_t* __restrict__ argmax, float* __restrict__ dump, int npanels) {
+                                                                float w, int32_t* __restrict__ argmax, float* __restrict__ dump, int npanels,
+                                                                float* __restrict__ rec, int* __restrict__ stats, int mode) {
     using C = CP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* strips = reinterpret_cast<float*>(smem + C::LDS_BYTES);        // [2][256] prototype norms of a tile | [2][256] query norms of a panel
@@ -80,7 +90,8 @@ __global__ __launch_bounds__(512, 2) void classify_panel_kernel(const half_t* __
         const int next_panel = panel + G;
         // One pass over the panel's class tiles; PASS 0: statistics, PASS 1: argmax.  Separate instantiations (and scopes) per pass: the per-row state of one pass is
         // not alive during the other's K-loops (all of it at once spilled 29 registers).  `tile_fn(tn, k, d, rowconst)` consumes the lane's distances of row k.
-        auto walk = [&](auto pass_tag, auto&& tile_fn) {
+        // PASS 0 with `then_next`: the pass is expected to be the panel's only one (candidate records, below), so its last tile prefetches the NEXT panel
+        auto walk = [&](auto pass_tag, const bool then_next, auto&& tile_fn) {
             constexpr int PASS = decltype(pass_tag)::value;
 #pragma unroll 1
             for (int tn = 0; tn < tiles_n; ++tn) {
@@ -92,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void classify_panel_kernel(const half_t* __
                     const bool last = tn + 1 == tiles_n;
                     zpar ^= 1;
                     if (!last) issue(m0, tn + 1, zpar);
-                    else if (PASS == 0) issue(m0, 0, zpar);
+                    else if (PASS == 0 && !then_next) issue(m0, 0, zpar);
                     else if (next_panel < npanels) { issue_q(next_panel * C::BM, qpar ^ 1); issue(next_panel * C::BM, 0, zpar); }
                 }
                 const float* zn = zstrip + zp * 256 + wn * 128;
@@ -116,8 +127,11 @@ __global__ __launch_bounds__(512, 2) void classify_panel_kernel(const half_t* __
         };
         auto row_of = [&](int k) { return wm * 64 + (k >> 1) * 32 + (k & 1) * 16 + (lane & 15); };     // the lane's four query rows
         const int slot = wn * 4 + (lane >> 4);                                                         // 0 .. 7: the lanes x waves that share a row
+        constexpr bool cand = CAND && !DUMP;                                                           // one pass + candidate records (two passes only where the proof fails)
+        float* rec_wg = rec + (size_t)blockIdx.x * tiles_n * (8 * 256 * 8);
+        bool second_pass = !cand;
         if (DUMP) {
-            walk(std::integral_constant<int, 1>{}, [&](int tn, int k, const float (&d)[2][16]) {
+            walk(std::integral_constant<int, 1>{}, false, [&](int tn, int k, const float (&d)[2][16]) {
                 if (panel != 0 || tn != 0) return;
 #pragma unroll
                 for (int bank = 0; bank < 2; ++bank)
@@ -136,12 +150,44 @@ __global__ __launch_bounds__(512, 2) void classify_panel_kernel(const half_t* __
             float mn[4][2], sm[4][2];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { mn[k][0] = mn[k][1] = 3e38f; sm[k][0] = sm[k][1] = 0.f; }
-            walk(std::integral_constant<int, 0>{}, [&](int tn, int k, const float (&d)[2][16]) {
+            walk(std::integral_constant<int, 0>{}, cand, [&](int tn, int k, const float (&d)[2][16]) {
+                float gmin[2] = {0.f, 0.f};
+                if (cand) {
+                    // candidate record of this (row, lane-slot, tile) group of 16 classes: per bank the smallest distance with its class and that class's distance in
+                    // the OTHER bank, and the second smallest distance (a bound for everybody else of the group); 5 VALU per element and bank, no state across tiles
+                    float rm1[2], rpr[2], rm2[2];
+                    int rcls[2];
+                    const int cls0 = tn * (C::BN / 2) + (wn * 128 + 4 * (lane >> 4)) / 2;
+#pragma unroll
+                    for (int bank = 0; bank < 2; ++bank) {
+                        float m1 = d[bank][0], m2 = 3e38f, pr = d[bank ^ 1][0];
+                        int i1 = 0;
+#pragma unroll
+                        for (int c = 1; c < 16; ++c) {
+                            const bool lt = d[bank][c] < m1;
+                            m2 = __builtin_amdgcn_fmed3f(d[bank][c], m1, m2);
+                            pr = lt ? d[bank ^ 1][c] : pr;
+                            i1 = lt ? c : i1;
+                            m1 = lt ? d[bank][c] : m1;
+                        }
+                        rcls[bank] = cls0 + (i1 >> 2) * 16 + ((i1 >> 1) & 1) * 8 + (i1 & 1);
+                        rm1[bank] = gmin[bank] = m1; rpr[bank] = pr; rm2[bank] = m2;
+                    }
+                    // record: { d_i min, its d_t, second d_i, d_t min | its d_i, second d_t, class of d_i min, class of d_t min } — floats and ints in words of their own type
+                    float* dst = rec_wg + (((size_t)tn * 8 + slot) * 256 + row_of(k)) * 8;
+                    *reinterpret_cast<float4_t*>(dst) = float4_t{rm1[0], rpr[0], rm2[0], rm1[1]};
+                    *reinterpret_cast<float2_t*>(dst + 4) = float2_t{rpr[1], rm2[1]};
+                    *reinterpret_cast<int2_t*>(dst + 6) = int2_t{rcls[0], rcls[1]};
+                }
 #pragma unroll
                 for (int bank = 0; bank < 2; ++bank) {
                     float t = d[bank][0];
+                    if (cand) {
+                        t = gmin[bank];                                        // the group's minimum is in the record already
+                    } else {
 #pragma unroll
-                    for (int c = 1; c < 16; ++c) t = fminf(t, d[bank][c]);
+                        for (int c = 1; c < 16; ++c) t = fminf(t, d[bank][c]);
+                    }
                     const float m2 = fminf(mn[k][bank], t);
                     float s = sm[k][bank] * __builtin_amdgcn_exp2f((m2 - mn[k][bank]) * w);
 #pragma unroll
@@ -171,13 +217,57 @@ __global__ __launch_bounds__(512, 2) void classify_panel_kernel(const half_t* __
             }
             pgemm::lds_barrier();
         }
+        // ---- candidates: the argmax from the records of pass 1, with a proof that nobody else can win ----
+        // Every class that is not a group's nearest in one of the banks has d_i >= the group's second smallest d_i and d_t >= its second smallest d_t, hence (the
+        // expression below is monotone in both) p <= U_group.  If max_groups U < the best candidate's p, the candidates' argmax (lowest class among equal maxima) IS
+        // the argmax of the row: same bits as pass 2 would give.  Otherwise (flat distributions: small beta, near-ties) the panel takes the second pass.
+        if (cand) {
+            float* scr = reinterpret_cast<float*>(smem + (p ^ 1) * C::STAGE_BYTES);
+            int* fail = reinterpret_cast<int*>(rowc + 1024);
+            const int row = tid & 255, half = tid >> 8, ng = tiles_n * 8;
+            const float4_t c4 = *reinterpret_cast<const float4_t*>(rowc + row * 4);
+            float bv = -1.f, umax = 0.f;
+            int bi = 0x7fffffff;
+            if (tid == 0) *fail = 0;
+            __syncthreads();                                                   // the records of every lane are complete (vmcnt(0)) and visible to the workgroup
+#pragma unroll 2
+            for (int g = half * (ng >> 1); g < (half + 1) * (ng >> 1); ++g) {
+                // (plain loads: the records were written through this CU's L1 by this workgroup and the barrier above waited for them)
+                const float* rp = rec_wg + ((size_t)g * 256 + row) * 8;
+                const float4_t a = *reinterpret_cast<const float4_t*>(rp);
+                const float2_t b = *reinterpret_cast<const float2_t*>(rp + 4);
+                const int2_t ci = *reinterpret_cast<const int2_t*>(rp + 6);
+                const float p1 = __builtin_fmaf(c4[0], __builtin_amdgcn_exp2f((c4[1] - a[0]) * w), c4[2] * __builtin_amdgcn_exp2f((c4[3] - a[1]) * w));
+                const float p2 = __builtin_fmaf(c4[0], __builtin_amdgcn_exp2f((c4[1] - b[0]) * w), c4[2] * __builtin_amdgcn_exp2f((c4[3] - a[3]) * w));
+                const float u = __builtin_fmaf(c4[0], __builtin_amdgcn_exp2f((c4[1] - a[2]) * w), c4[2] * __builtin_amdgcn_exp2f((c4[3] - b[1]) * w));
+                const int i1 = ci[0], i2 = ci[1];
+                if (p1 > bv || (p1 == bv && i1 < bi)) { bv = p1; bi = i1; }
+                if (p2 > bv || (p2 == bv && i2 < bi)) { bv = p2; bi = i2; }
+                umax = fmaxf(umax, u);
+            }
+            if (half) { scr[row * 4] = bv; reinterpret_cast<int*>(scr)[row * 4 + 1] = bi; scr[row * 4 + 2] = umax; }
+            __syncthreads();
+            if (!half) {
+                const float ov = scr[row * 4], ou = scr[row * 4 + 2];
+                const int oi = reinterpret_cast<const int*>(scr)[row * 4 + 1];
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                umax = fmaxf(umax, ou);
+                if (m0 + row < Q && (!(umax < bv) || mode == 2)) *fail = 1;     // (mode 2, tests: every panel takes the second pass)
+            }
+            __syncthreads();
+            second_pass = *fail != 0;
+            if (!second_pass && !half && m0 + row < Q) argmax[m0 + row] = bi;
+            if (stats && tid == 0) { atomicAdd(stats, 1); if (second_pass) atomicAdd(stats + 1, 1); }
+            __syncthreads();                                                   // the scratch is a K-tile buffer again; `fail` may be rewritten by the next panel
+            if (second_pass) issue(m0, 0, zpar);                               // the prefetched tile was the next panel's: this panel's first tile again (same buffer, same strip: in order)
+        }
         // ---- pass 2: p = alpha e_i / S_i + (1 - alpha) e_t / S_t, running (best, class) per row ----
-        {
+        if (second_pass) {
             float best[4];
             int besti[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { best[k] = -1.f; besti[k] = 0x7fffffff; }
-            walk(std::integral_constant<int, 1>{}, [&](int tn, int k, const float (&d)[2][16]) {
+            walk(std::integral_constant<int, 1>{}, false, [&](int tn, int k, const float (&d)[2][16]) {
                 const float4_t c4 = *reinterpret_cast<const float4_t*>(rowc + row_of(k) * 4);
                 const int cls0 = tn * (C::BN / 2) + (wn * 128 + 4 * (lane >> 4)) / 2;
 #pragma unroll
@@ -215,7 +305,25 @@ __global__ __launch_bounds__(512, 2) void classify_panel_kernel(const half_t* __
 
 size_t pclip_classify_panel_workspace(int Q, int N, int D) {
     const size_t rows2 = (size_t)2 * ((N + 127) / 128 * 128), Qp = (size_t)(Q + 255) / 256 * 256;
-    return align_up(rows2 * D * 2, 256) + align_up(rows2 * 4, 256) + align_up(Qp * 4, 256);
+    int cus = pclip_device_cus();
+    if (cus <= 0) cus = 256;
+    const size_t npanels = Qp / 256, grid = npanels < (size_t)cus ? npanels : (size_t)cus;
+    // + the candidate records: per resident panel and class tile 8 x 256 groups x 32 B (a quarter of the fp32 distance rows the two stages would write)
+    return align_up(rows2 * D * 2, 256) + align_up(rows2 * 4, 256) + align_up(Qp * 4, 256) + grid * (rows2 / 256) * (8 * 256 * 32) + 256;
+}
+
+static int g_panel_passes = -1;                // -1: PCLIP_CLASSIFY_PANEL_PASSES / default 0; 0 one pass + candidates (second pass where the proof fails), 1 always two passes, 2 tests
+extern "C" int pclip_classify_panel_passes(int mode) {
+    const int before = g_panel_passes;
+    if (mode >= 0) g_panel_passes = mode > 2 ? 0 : mode;
+    return before;
+}
+__device__ int g_panel_stats[2];               // panels classified | panels that took the second pass (since the last reset)
+extern "C" int pclip_classify_panel_stats(int* out2, int reset) {
+    int z[2] = {0, 0};
+    if (out2 && hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_panel_stats), sizeof(z)) != hipSuccess) return PCLIP_E_LAUNCH;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_panel_stats), z, sizeof(z)) != hipSuccess) return PCLIP_E_LAUNCH;
+    return PCLIP_OK;
 }
 
 static int g_panel_mode = -1;                  // -1: PCLIP_CLASSIFY_PANEL / default (on), decided at the first call
@@ -243,35 +351,42 @@ int pclip_classify_panel_launch(const void* q, const void* zi, const void* zt, i
     char* b = (char*)ws;
     half_t* zz = (half_t*)b; b += align_up((size_t)rows2 * D * 2, 256);
     float* zz_sq = (float*)b; b += align_up((size_t)rows2 * 4, 256);
-    float* q_sqp = (float*)b;
+    float* q_sqp = (float*)b; b += align_up((size_t)Qp * 4, 256);
+    float* rec = (float*)b;
+    if (g_panel_passes < 0) { const char* e = getenv("PCLIP_CLASSIFY_PANEL_PASSES"); g_panel_passes = e ? atoi(e) : 0; if (g_panel_passes < 0 || g_panel_passes > 2) g_panel_passes = 0; }
+    int* stats = nullptr;
+    if (hipGetSymbolAddress((void**)&stats, HIP_SYMBOL(g_panel_stats)) != hipSuccess) stats = nullptr;
     interleave_kernel<<<ceil_div(rows2, 4), 256, 0, s>>>((const half_t*)zi, (const half_t*)zt, zi_sq, zt_sq, N, D, rows2, zz, zz_sq);
     pad_norms_kernel<<<ceil_div(Qp, 256), 256, 0, s>>>(q_sq, Q, Qp, q_sqp);
     int cus = pclip_device_cus();
     if (cus <= 0) cus = 256;
     const int npanels = Qp / 256, grid = npanels < cus ? npanels : cus;
-    constexpr int LDS = CP::LDS_BYTES + 8192;
+    constexpr int LDS = CP::LDS_BYTES + 8192 + 64;
     // d2 = max(||q||^2 + ||z||^2 - 2 q.z, 0) by default: without torch.cdist's sqrt -> square round trip (<= 1 fp32 ulp from the two-stage path's distances, whose
     // correctly rounded sqrtf costs twelve VALU instructions per element: 371 vs 250 us on the ImageNet split — the arithmetic this kernel is bound by);
     // PCLIP_CLASSIFY_PANEL_EXACT=1 keeps the round trip (bit-identical distances)
     static const bool exact_env = getenv("PCLIP_CLASSIFY_PANEL_EXACT") && getenv("PCLIP_CLASSIFY_PANEL_EXACT")[0] == '1';
     const bool exact = dump ? dump_exact : exact_env;
     const float w = beta * 1.4426950408889634f;
-#define PCLIP_PANEL(EX, DU)                                                                                                                      \
+#define PCLIP_PANEL(EX, DU, CA)                                                                                                                  \
     do {                                                                                                                                         \
         static DevOnce attr;                                                                                                                     \
         if (!attr.done()) {                                                                                                                      \
-            if (hipFuncSetAttribute((const void*)classify_panel_kernel<EX, DU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) { \
+            if (hipFuncSetAttribute((const void*)classify_panel_kernel<EX, DU, CA>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) { \
                 pclip_set_error("pclip_classify_f16: cannot raise the dynamic LDS limit to %d", LDS);                                            \
                 return PCLIP_E_LAUNCH;                                                                                                           \
             }                                                                                                                                    \
             attr.set();                                                                                                                          \
         }                                                                                                                                        \
-        classify_panel_kernel<EX, DU><<<DU ? 1 : grid, 512, LDS, s>>>((const half_t*)q, zz, Q, rows2, D, q_sqp, zz_sq, alpha, oma, w, argmax, dump, DU ? 1 : npanels); \
+        classify_panel_kernel<EX, DU, CA><<<DU ? 1 : grid, 512, LDS, s>>>((const half_t*)q, zz, Q, rows2, D, q_sqp, zz_sq, alpha, oma, w, argmax, dump, DU ? 1 : npanels, rec, stats, g_panel_passes); \
     } while (0)
-    if (dump && exact) PCLIP_PANEL(true, true);
-    else if (dump) PCLIP_PANEL(false, true);
-    else if (exact) PCLIP_PANEL(true, false);
-    else PCLIP_PANEL(false, false);
+    const bool cand = g_panel_passes != 1;
+    if (dump && exact) PCLIP_PANEL(true, true, false);
+    else if (dump) PCLIP_PANEL(false, true, false);
+    else if (exact && cand) PCLIP_PANEL(true, false, true);
+    else if (exact) PCLIP_PANEL(true, false, false);
+    else if (cand) PCLIP_PANEL(false, false, true);
+    else PCLIP_PANEL(false, false, false);
 #undef PCLIP_PANEL
     return pclip_check_launch("classify (row panels)");
 }

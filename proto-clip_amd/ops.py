@@ -234,6 +234,8 @@ def _sync_pair(device) -> torch.Tensor:
     buf = _sync_words.get(key)
     if buf is None:
         buf = _sync_words[key] = torch.zeros(2, dtype=torch.int32, device=device)
+    else:
+        buf.zero_()              # the kernel leaves them zero only when it runs to completion: a launch that faulted must not poison every later call
     return buf
 
 
@@ -292,6 +294,28 @@ class classify_fused:
     def __exit__(self, *exc):
         _lib.load().pclip_classify_panel_config(self.before if self.before >= 0 else 1)
         return False
+
+
+class classify_panel_passes:
+    """`with ops.classify_panel_passes(mode):` — 0 one pass + candidates with proof (default), 1 always two passes, 2 candidates computed, second pass forced (tests)."""
+    def __init__(self, mode: int):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = _lib.load().pclip_classify_panel_passes(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().pclip_classify_panel_passes(self.prev if self.prev >= 0 else 0)
+        return False
+
+
+def classify_panel_stats(reset: bool = False):
+    """(panels classified by the fused kernel, panels that needed its second pass) since the last reset; synchronises."""
+    import ctypes
+    out = (ctypes.c_int * 2)()
+    check(_lib.load().pclip_classify_panel_stats(ctypes.cast(out, ctypes.c_void_p), int(reset)), "pclip_classify_panel_stats")
+    return int(out[0]), int(out[1])
 
 
 def classify_panel_distances(q, zi, zt, exact: bool = False):

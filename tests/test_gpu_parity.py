@@ -284,7 +284,17 @@ def test_classify_fused_row_panels(ops, Q, N, D):
         assert int((a.contiguous().view(torch.int32) - b.contiguous().view(torch.int32)).abs().max()) <= 1
     for alpha, beta in ((0.5, 12.0), (0.2, 12.0), (1.0, 0.7), (0.0, 5.0), (0.35, 1.0)):
         with ops.classify_fused():
+            ops.classify_panel_stats(reset=True)
             _, am, _, _ = ops.classify(dev(q), dev(zi), dev(zt), alpha, beta, want_p=False, want_argmax=True)
+            npan, nsecond = ops.classify_panel_stats()
+            # one pass + candidates + proof (default) == always two passes == candidates with the second pass forced: the same argmax, bit for bit
+            with ops.classify_panel_passes(1):
+                _, am_two, _, _ = ops.classify(dev(q), dev(zi), dev(zt), alpha, beta, want_p=False, want_argmax=True)
+            with ops.classify_panel_passes(2):
+                _, am_forced, _, _ = ops.classify(dev(q), dev(zi), dev(zt), alpha, beta, want_p=False, want_argmax=True)
+            assert torch.equal(am, am_two) and torch.equal(am, am_forced), (alpha, beta, (am != am_two).sum().item(), (am != am_forced).sum().item())
+            assert npan == (Q + 255) // 256
+            observe(f"fused classify Q={Q} N={N} alpha={alpha} beta={beta}: fraction of panels that needed the second pass", nsecond / npan, 1.0)
         with ops.classify_two_stage():
             _, am2, _, _ = ops.classify(dev(q), dev(zi), dev(zt), alpha, beta, want_p=False, want_argmax=True)
         p2, _, _, _ = ops.classify(dev(q), dev(zi), dev(zt), alpha, beta, want_p=True, want_argmax=False)
