@@ -565,10 +565,7 @@ extern "C" int pclip_classify_f16(const void* q, const void* zi, const void* zt,
     // large class counts, argmax only: the fused row-panel kernel (pclip_classify_panel.hip) — no distance rows in HBM.  PCLIP_CLASSIFY_PANEL=0: two stages.
     if (zt && argmax && !p && !topk_p && !topk_i && q && zi && pclip_classify_panel_applies(Q, N, D, beta) &&
         ws_bytes >= w.bytes + pclip_classify_panel_workspace(Q, N, D)) {
-        int e;
-        if (!q_sq) { if ((e = pclip_row_sqnorm_f16(q, Q, D, w.q_sq, stream))) return e; q_sq = w.q_sq; }
-        if (!zi_sq) { if ((e = pclip_row_sqnorm_f16(zi, N, D, w.zi_sq, stream))) return e; zi_sq = w.zi_sq; }
-        if (!zt_sq) { if ((e = pclip_row_sqnorm_f16(zt, N, D, w.zt_sq, stream))) return e; zt_sq = w.zt_sq; }
+        // (norms that were not supplied are formed by the kernel's own preparation launch: the arithmetic of pclip_row_sqnorm_f16)
         return pclip_classify_panel_launch(q, zi, zt, Q, N, D, q_sq, zi_sq, zt_sq, alpha, one_minus_alpha, beta, argmax, nullptr, false, (char*)ws + w.bytes, (hipStream_t)stream);
     }
     const int ldd = padded_ld(N);

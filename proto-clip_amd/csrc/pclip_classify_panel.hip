@@ -17,6 +17,7 @@
 // order — i.e. bit-identical distances (tests/test_gpu_parity.py: a sampled tile); the softmax arithmetic is the online form (exp2 with beta log2 e folded in), so p
 // agrees with pclip_fuse_probs to fp32 rounding and the argmax wherever the top-2 margin exceeds that.
 #include "pclip_gemm.h"
+#include "pclip_proto_dev.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -27,22 +28,42 @@ namespace {
 using CP = pgemm::Cfg<256, 256, 4, 2>;                   // 4 x 2 waves: a lane owns 4 query rows x 32 interleaved columns (16 classes x 2 banks) of a tile
 constexpr float BIG_D2 = 1e30f;                           // squared norm of the padding prototypes: never the minimum, exp() == 0
 
-// zz[2 n + b] = z_b[n] (zero rows beyond N), zz_sq likewise (BIG_D2 beyond N).  One wave per output row.
-__global__ __launch_bounds__(256) void interleave_kernel(const half_t* __restrict__ zi, const half_t* __restrict__ zt, const float* __restrict__ zi_sq,
-                                                         const float* __restrict__ zt_sq, int N, int D, int rows, half_t* __restrict__ zz,
-                                                         float* __restrict__ zz_sq) {
-    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows) return;
-    const int n = r >> 1, b = r & 1;
-    const half_t* src = (b ? zt : zi) + (size_t)n * D;
-    for (int c = lane * 8; c < D; c += 512) st_half8(zz + (size_t)r * D + c, n < N ? ld_half8(src + c) : half8_t{});
-    if (lane == 0) zz_sq[r] = n < N ? (b ? zt_sq : zi_sq)[n] : BIG_D2;
-}
-
-// padded copy of the query norms (whole 256-row panels: the strips are fetched by LDS-DMA without bounds)
-__global__ __launch_bounds__(256) void pad_norms_kernel(const float* __restrict__ src, int Q, int Qp, float* __restrict__ dst) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < Qp) dst[i] = i < Q ? src[i] : 0.f;
+// Operand preparation in ONE launch, a wave per row: rows [0, rows2) build zz[2 n + b] = z_b[n] (zero rows beyond N) with zz_sq (BIG_D2 beyond N), rows
+// [rows2, rows2 + Qp) the padded query norms (whole 256-row panels: the strips are fetched by LDS-DMA without bounds).  Norms the caller did not supply are
+// computed here with pclip_row_sqnorm_f16's arithmetic (load_row_sq of pclip_proto_dev.h: the same bits) — the path was five launches before the panels started.
+template <int NCH>
+__global__ __launch_bounds__(256) void panel_prep_kernel(const half_t* __restrict__ q, const half_t* __restrict__ zi, const half_t* __restrict__ zt,
+                                                         const float* __restrict__ q_sq, const float* __restrict__ zi_sq, const float* __restrict__ zt_sq, int Q, int Qp,
+                                                         int N, int D, int rows2, half_t* __restrict__ zz, float* __restrict__ zz_sq, float* __restrict__ q_sqp) {
+    const int lane = threadIdx.x & 63;
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows2 + Qp; r += gridDim.x * 4) {
+        if (r < rows2) {
+            const int n = r >> 1, b = r & 1;
+            RowRegs<NCH> rr;
+            float ss = BIG_D2;
+            if (n < N) {
+                const half_t* src = (b ? zt : zi) + (size_t)n * D;
+                const float* sq = b ? zt_sq : zi_sq;
+                ss = load_row_sq<NCH>(src, D, lane, rr);
+                if (sq) ss = sq[n];
+            } else {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) rr.v[c] = half8_t{};
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+                if (c * 512 + lane * 8 < D) st_half8(zz + (size_t)r * D + c * 512 + lane * 8, rr.v[c]);
+            if (lane == 0) zz_sq[r] = ss;
+        } else {
+            const int i = r - rows2;
+            float ss = 0.f;
+            if (i < Q) {
+                if (q_sq) ss = q_sq[i];
+                else { RowRegs<NCH> rr; ss = load_row_sq<NCH>(q + (size_t)i * D, D, lane, rr); }
+            }
+            if (lane == 0) q_sqp[i] = ss;
+        }
+    }
 }
 
 template <bool EXACT>
@@ -343,7 +364,7 @@ bool pclip_classify_panel_applies(int Q, int N, int D, float beta) {
     return g_panel_mode > 0 && enough && N > 32 && D >= 128 && D % 64 == 0 && D <= 4096 && beta >= 0.f && Q >= 1 && (long)256 * D * 2 < 0x7fffffffL;
 }
 
-// q_sq / zi_sq / zt_sq: device arrays (the caller supplies or has computed them).  dump != nullptr: test mode (distances of panel 0 / tile 0, no argmax; dump_exact:
+// q_sq / zi_sq / zt_sq: device arrays or null (computed by the preparation launch with pclip_row_sqnorm_f16's arithmetic).  dump != nullptr: test mode (distances of panel 0 / tile 0, no argmax; dump_exact:
 // with / without the sqrt round trip).
 int pclip_classify_panel_launch(const void* q, const void* zi, const void* zt, int Q, int N, int D, const float* q_sq, const float* zi_sq, const float* zt_sq,
                                 float alpha, float oma, float beta, int32_t* argmax, float* dump, bool dump_exact, void* ws, hipStream_t s) {
@@ -356,8 +377,12 @@ int pclip_classify_panel_launch(const void* q, const void* zi, const void* zt, i
     if (g_panel_passes < 0) { const char* e = getenv("PCLIP_CLASSIFY_PANEL_PASSES"); g_panel_passes = e ? atoi(e) : 0; if (g_panel_passes < 0 || g_panel_passes > 2) g_panel_passes = 0; }
     int* stats = nullptr;
     if (hipGetSymbolAddress((void**)&stats, HIP_SYMBOL(g_panel_stats)) != hipSuccess) stats = nullptr;
-    interleave_kernel<<<ceil_div(rows2, 4), 256, 0, s>>>((const half_t*)zi, (const half_t*)zt, zi_sq, zt_sq, N, D, rows2, zz, zz_sq);
-    pad_norms_kernel<<<ceil_div(Qp, 256), 256, 0, s>>>(q_sq, Q, Qp, q_sqp);
+    {
+        const int jobs = rows2 + Qp, pg = ceil_div(jobs, 4) < 4096 ? ceil_div(jobs, 4) : 4096;
+#define PCLIP_PREP(NCH) panel_prep_kernel<NCH><<<pg, 256, 0, s>>>((const half_t*)q, (const half_t*)zi, (const half_t*)zt, q_sq, zi_sq, zt_sq, Q, Qp, N, D, rows2, zz, zz_sq, q_sqp)
+        if (D <= 512) PCLIP_PREP(1); else if (D <= 1024) PCLIP_PREP(2); else if (D <= 2048) PCLIP_PREP(4); else PCLIP_PREP(8);
+#undef PCLIP_PREP
+    }
     int cus = pclip_device_cus();
     if (cus <= 0) cus = 256;
     const int npanels = Qp / 256, grid = npanels < cus ? npanels : cus;
