@@ -59,6 +59,45 @@ __global__ __launch_bounds__(256) void mfma_loop(const half8_t* __restrict__ src
     if (s == 12345.678f) out[0] = s;       // keep the loop alive
 }
 
+// SHAPE 2 / 3: the 16x16x32 loop with its fragments RE-READ from LDS every trip at the four-wave GEMM's ratio (16 ds_read_b128 per 64 MFMAs; 3: twice that, the
+// eight-wave kernel's ratio) — what the LDS read traffic costs in sustained rate under the cap.  LDS holds 64 KB of the same random halves, conflict-free rows.
+template <int READS>
+__global__ __launch_bounds__(256) void mfma_lds_loop(const half8_t* __restrict__ src, float* __restrict__ out, int iters) {
+    __shared__ half8_t lds[4096];                      // 64 KB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = src[i & 1023];
+    __syncthreads();
+    float4_t acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+    int base = wave * 1024 + lane;
+    for (int it = 0; it < iters; ++it) {
+        half8_t a[8], b[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a[i] = lds[(base + i * 64) & 4095]; b[i] = lds[(base + 512 + i * 64) & 4095]; }
+        if (READS == 2) {
+            half8_t a2[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a2[i] = lds[(base + 2048 + i * 64) & 4095];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { half8_t t = lds[(base + 2560 + i * 64) & 4095]; b[i] = b[i] + a2[i] * (_Float16)0 + t * (_Float16)0; }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        base += 64;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][3];
+    if (s == 12345.678f) out[0] = s;
+}
+
 int main(int argc, char** argv) {
     const double secs = argc > 1 ? atof(argv[1]) : 1.5;
     const float scale = argc > 2 ? atof(argv[2]) : 1.0f;     // operand scale (0: zeros)
@@ -74,16 +113,19 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const double flop_per_trip_wave = 64.0 * 2 * 16 * 16 * 32;      // both shapes
     for (int rep = 0; rep < 3; ++rep)
-        for (int shape = 0; shape < 2; ++shape) {
+        for (int shape = 0; shape < 4; ++shape) {
             int iters = 2000;
             for (int pass = 0; pass < 2; ++pass) {                   // calibrate, then the timed run of ~secs
                 hipEventRecord(e0);
-                if (shape == 0) mfma_loop<0><<<cus, 256>>>(src, out, iters); else mfma_loop<1><<<cus, 256>>>(src, out, iters);
+                if (shape == 0) mfma_loop<0><<<cus, 256>>>(src, out, iters);
+                else if (shape == 1) mfma_loop<1><<<cus, 256>>>(src, out, iters);
+                else if (shape == 2) mfma_lds_loop<1><<<cus, 256>>>(src, out, iters);
+                else mfma_lds_loop<2><<<cus, 256>>>(src, out, iters);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (pass == 0) { iters = (int)(iters * secs * 1e3 / ms); continue; }
                 const double tf = flop_per_trip_wave * iters * 4.0 * cus / (ms * 1e-3) / 1e12;
-                printf("%s  %8.1f ms  %8.1f TFLOP/s (%d CUs, one wave per SIMD, operand scale %.2f)\n", shape == 0 ? "v_mfma_f32_16x16x32_f16" : "v_mfma_f32_32x32x16_f16", ms, tf, cus, scale);
+                printf("%s  %8.1f ms  %8.1f TFLOP/s (%d CUs, one wave per SIMD, operand scale %.2f)\n", shape == 0 ? "v_mfma_f32_16x16x32_f16" : shape == 1 ? "v_mfma_f32_32x32x16_f16" : shape == 2 ? "16x16x32 + 16 ds_read_b128 / 64" : "16x16x32 + 32 ds_read_b128 / 64", ms, tf, cus, scale);
                 fflush(stdout);
             }
         }
