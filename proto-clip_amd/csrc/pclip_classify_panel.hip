@@ -356,11 +356,12 @@ extern "C" int pclip_classify_panel_config(int mode) {
 
 bool pclip_classify_panel_applies(int Q, int N, int D, float beta) {
     if (g_panel_mode < 0) { const char* e = getenv("PCLIP_CLASSIFY_PANEL"); g_panel_mode = e ? atoi(e) : 1; if (g_panel_mode < 0 || g_panel_mode > 2) g_panel_mode = 1; }
-    // worth it from about half a panel per CU (a panel = 256 queries x every class tile, twice): below that the chip is mostly idle and the two-stage path wins
-    // (FewSOL-198, Q = 666: 112 vs 28 us); mode 2 forces the fused kernel for every shape it can run (tests)
-    int cus = pclip_device_cus();
-    if (cus <= 0) cus = 256;
-    const bool enough = g_panel_mode == 2 || (long)((Q + 255) / 256) * 2 >= cus;
+    // Routing by measurement (tools/fused_routing_probe.py, profiles/r05_fused_routing.txt): up to one panel per CU the fused kernel's time is ~12 + 17 us per class tile
+    // whatever Q is (a CU walks its panel's tiles alone), the two stages cost ~22 us + 8e-6 us per (query, class) — fused from Q N >= 2e6 tiles - 1e6 (ImageNet: Q >= 15 k;
+    // Food-101's 30 k queries: 32 vs 58 us; SUN397: 79 vs 107; below that the chip is mostly idle and the two stages win: FewSOL-198, Q = 666: 26 vs 50 us);
+    // mode 2 forces the fused kernel for every shape it can run (tests)
+    const double tiles = (double)(2 * ((N + 127) / 128 * 128) / 256);
+    const bool enough = g_panel_mode == 2 || (double)Q * (double)N >= 2.0e6 * tiles - 1.0e6;
     return g_panel_mode > 0 && enough && N > 32 && D >= 128 && D % 64 == 0 && D <= 4096 && beta >= 0.f && Q >= 1 && (long)256 * D * 2 < 0x7fffffffL;
 }
 
