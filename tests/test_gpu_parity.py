@@ -311,6 +311,43 @@ def test_classify_fused_row_panels(ops, Q, N, D):
         assert int(am.min()) >= 0 and int(am.max()) < N
 
 
+def test_classify_fused_exact_ties_take_the_lowest_class(ops):
+    """Duplicated prototypes (classes 7 == 150 == 151 in both banks, 30 == 31 in the visual bank only) make EXACT ties of p: main.py:190's `.max(1)[1]` on the CPU returns the
+    lowest class.  The fused kernel's candidate proof cannot separate a tie (bound == best) and must hand such panels to its second pass; every routing — one pass +
+    candidates, always two passes, the two stages — returns the same, lowest, class, and never the duplicate."""
+    Q, N, D = 700, 200, 512
+    g = torch.Generator().manual_seed(5)
+    nrm = torch.nn.functional.normalize
+    cen = torch.randn(N, D, generator=g)
+    zi = nrm(cen + 0.3 * torch.randn(N, D, generator=g), dim=-1).half()
+    zt = nrm(cen + 0.5 * torch.randn(N, D, generator=g), dim=-1).half()
+    for dup in (150, 151):
+        zi[dup] = zi[7]
+        zt[dup] = zt[7]
+    zi[31] = zi[30]
+    y = torch.cat([torch.full((300,), 7), torch.full((100,), 30), torch.randint(0, N, (Q - 400,), generator=g)])
+    q = nrm(cen[y] + 0.8 * torch.randn(Q, D, generator=g), dim=-1).half()
+    for alpha, beta in ((0.5, 12.0), (1.0, 3.0), (0.0, 5.0)):
+        outs = {}
+        with ops.classify_fused():
+            for passes in (0, 1):
+                with ops.classify_panel_passes(passes):
+                    ops.classify_panel_stats(reset=True)
+                    outs[passes] = ops.classify(dev(q), dev(zi), dev(zt), alpha, beta, want_p=False, want_argmax=True)[1]
+                    if passes == 0:
+                        assert ops.classify_panel_stats()[1] > 0, "tied rows must fail the candidate proof"
+        with ops.classify_two_stage():
+            am2 = ops.classify(dev(q), dev(zi), dev(zt), alpha, beta, want_p=False, want_argmax=True)[1]
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], am2), (alpha, beta)
+        am = outs[0].cpu()
+        assert not bool(((am == 150) | (am == 151)).any()), "a duplicate of class 7 won a tie"
+        assert int((am[:300] == 7).sum()) > 250                                    # (the queries drawn around class 7 do land on it)
+        if alpha > 0.99:
+            assert not bool((am == 31).any()), "the visual duplicate of class 30 won a tie at alpha = 1"
+        p_or = po.P(q, zi, zt, alpha, beta)
+        assert (am.long() == p_or.max(1)[1]).float().mean().item() > 0.995          # the oracle's fp32 p may break a tie the other way only through rounding
+
+
 def test_fuse_probs_edge_cases(ops):
     Q, N = 70, 130
     d2i = torch.from_numpy(synth.uniform(Q * N, 12, 0).reshape(Q, N)).float() * 4
