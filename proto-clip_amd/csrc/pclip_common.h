@@ -86,6 +86,29 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
 #undef PCLIP_STEP
 }
 
+// x / d for MANY x and ONE wave-uniform divisor d (a row's norm, a shot count): the correctly rounded fp32 quotient in 6 instead of 11 VALU instructions per element.
+// hipcc expands an IEEE fp32 division into v_div_scale x2, v_rcp, two reciprocal refinements, a multiply, three quotient / residual steps, v_div_fmas, v_div_fixup;
+// the scaling only acts at the ends of the exponent range and the reciprocal part depends on d alone.  prepare() does the reciprocal part once; div() repeats the
+// SAME fma chain on the unscaled operands (v_div_scale returns them unchanged, v_div_fmas is a plain fma and v_div_fixup a pass-through for d in [2^-60, 2^60] and
+// |x| in {0} + [2^-30, 2^30] — every use here: fp16-valued rows, sums of <= 2^10 of them), so the quotient has the same bits; the sign of a zero quotient is x's
+// (v_div_fixup's rule, d > 0); any other divisor (zero, huge, NaN: degenerate rows) takes the compiler's division.  The latency-bound kernels (prototype build:
+// eight divisions per row and lane) are instruction-issue-bound, one wave per SIMD (profiles/r05_c2_phases.txt).
+struct RowDiv {
+    float d, nd, y;
+    bool fast;
+    __device__ __forceinline__ explicit RowDiv(float div) : d(div), nd(-div), y(0.f), fast(div >= 0x1p-60f && div <= 0x1p60f) {
+        const float y0 = __builtin_amdgcn_rcpf(div);
+        y = __builtin_fmaf(__builtin_fmaf(nd, y0, 1.f), y0, y0);
+    }
+    __device__ __forceinline__ float div(float x) const { return fast ? div_fast(x) : x / d; }      // (wave-uniform choice; loops over many x test `fast` once themselves)
+    __device__ __forceinline__ float div_fast(float x) const {
+        const float q0 = x * y;
+        const float q1 = __builtin_fmaf(__builtin_fmaf(nd, q0, x), y, q0);
+        const float q2 = __builtin_fmaf(__builtin_fmaf(nd, q1, x), y, q1);
+        return __builtin_copysignf(q2, x);
+    }
+};
+
 __device__ __forceinline__ half8_t ld_half8(const half_t* p) { return *reinterpret_cast<const half8_t*>(p); }
 __device__ __forceinline__ void st_half8(half_t* p, half8_t v) { *reinterpret_cast<half8_t*>(p) = v; }
 

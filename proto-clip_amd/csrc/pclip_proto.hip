@@ -15,16 +15,22 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const half_t* __restri
     for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
         RowRegs<NCH> r;
         float ss = load_row_sq<NCH>(x + (size_t)row * D, D, lane, r);
-        float n = r16(sqrtf(ss));
+        const RowDiv dn(r16(sqrtf(ss)));
         float ss2 = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             int d = c * 512 + lane * 8;
             if (d < D) {
                 half8_t o;
+                if (dn.fast) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (half_t)dn.div_fast((float)r.v[c][j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)r.v[c][j] / dn.d);
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    o[j] = (half_t)((float)r.v[c][j] / n);
                     float f = (float)o[j];
                     ss2 += f * f;
                 }

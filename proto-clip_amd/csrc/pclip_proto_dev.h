@@ -54,16 +54,18 @@ __device__ __forceinline__ void finish_prototype(float (&acc)[NCH][8], float inv
                                                  half_t* proto_f16, float* proto_f32, float* proto_sq, bool wt = false) {
     float z[NCH][8];
     float ss = 0.f;
+    const RowDiv dcnt(inv_or_cnt);
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            z[c][j] = r16(acc[c][j] / inv_or_cnt);   // mean over shots, rounded once (torch fp16 mean)
+            z[c][j] = r16(dcnt.fast ? dcnt.div_fast(acc[c][j]) : acc[c][j] / inv_or_cnt);      // mean over shots, rounded once (torch fp16 mean)
             ss += z[c][j] * z[c][j];
         }
     ss = wave_sum(ss);
     const float n16 = r16(sqrtf(ss));
     const float n32 = sqrtf(ss);
+    const RowDiv d16(n16), d32(n32);
     float ss2 = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -71,9 +73,15 @@ __device__ __forceinline__ void finish_prototype(float (&acc)[NCH][8], float inv
         if (d < D) {
             if (proto_f16 || proto_sq) {
                 half8_t o;
+                if (d16.fast) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (half_t)d16.div_fast(z[c][j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (half_t)(z[c][j] / n16);
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    o[j] = (half_t)(z[c][j] / n16);
                     float f = (float)o[j];
                     ss2 += f * f;
                 }
@@ -90,8 +98,8 @@ __device__ __forceinline__ void finish_prototype(float (&acc)[NCH][8], float inv
                 float4_t o0, o1;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    o0[j] = z[c][j] / n32;
-                    o1[j] = z[c][j + 4] / n32;
+                    o0[j] = d32.fast ? d32.div_fast(z[c][j]) : z[c][j] / n32;
+                    o1[j] = d32.fast ? d32.div_fast(z[c][j + 4]) : z[c][j + 4] / n32;
                 }
                 *reinterpret_cast<float4_t*>(proto_f32 + (size_t)n * D + d) = o0;
                 *reinterpret_cast<float4_t*>(proto_f32 + (size_t)n * D + d + 4) = o1;
@@ -123,16 +131,35 @@ __device__ __forceinline__ void class_sum(const half_t* __restrict__ mem, int lo
 #pragma unroll
             for (int u = 0; u < PF; ++u) load_row<NCH>(mem + (size_t)(row0 + 4 * u) * D, D, lane, rr[u]);
             float nn[PF];
-            if (per_shot_norm) {
 #pragma unroll
-                for (int u = 0; u < PF; ++u) nn[u] = r16(sqrtf(row_sq<NCH>(rr[u])));
-            }
+            for (int u = 0; u < PF; ++u) nn[u] = per_shot_norm ? r16(sqrtf(row_sq<NCH>(rr[u]))) : 1.f;
+
+            bool allfast = true;
 #pragma unroll
-            for (int u = 0; u < PF; ++u) {
+            for (int u = 0; u < PF; ++u) allfast = allfast && RowDiv(nn[u]).fast;
+            if (!per_shot_norm) {
 #pragma unroll
-                for (int c = 0; c < NCH; ++c)
+                for (int u = 0; u < PF; ++u)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[c][j] += per_shot_norm ? r16((float)rr[u].v[c][j] / nn[u]) : (float)rr[u].v[c][j];
+                    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[c][j] += (float)rr[u].v[c][j];
+            } else if (allfast) {                                   // ONE wave-uniform branch for the PF rows: nothing between their division chains
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const RowDiv dv(nn[u]);
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[c][j] += r16(dv.div_fast((float)rr[u].v[c][j]));
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < PF; ++u)
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[c][j] += r16((float)rr[u].v[c][j] / nn[u]);
             }
             continue;
         }
@@ -144,11 +171,19 @@ __device__ __forceinline__ void class_sum(const half_t* __restrict__ mem, int lo
             if (row0 + 4 * u >= hi) break;
             const RowRegs<NCH>& r = rr[u];
             if (per_shot_norm) {
-                float n = r16(sqrtf(row_sq<NCH>(r)));
+                const float n = r16(sqrtf(row_sq<NCH>(r)));
+                const RowDiv dn(n);
+                if (dn.fast) {
 #pragma unroll
-                for (int c = 0; c < NCH; ++c)
+                    for (int c = 0; c < NCH; ++c)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[c][j] += r16((float)r.v[c][j] / n);
+                        for (int j = 0; j < 8; ++j) acc[c][j] += r16(dn.div_fast((float)r.v[c][j]));
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[c][j] += r16((float)r.v[c][j] / n);
+                }
             } else {
 #pragma unroll
                 for (int c = 0; c < NCH; ++c)
