@@ -1,6 +1,6 @@
 # Round-5 evidence run (one gpurun call): full GPU suite with the tolerance ledger, the bench line, rocprofv3 kernel stats of the same command, tool benches,
 # and LAST — on the tree that was just timed — the PMC passes (separate --pmc runs, kernel-trace only).  Argument: tag.  Everything lands in gpurun_out/.
-TAG=${1:-v3}
+TAG=${1:-v4}
 mkdir -p gpurun_out
 PCLIP_OBSERVED_JSON=1 timeout 2400 python -m pytest tests -m gpu -q --timeout 900 --tb=short 2>&1 | grep -vE "^E   +(\+|where)" > gpurun_out/r05_pytest_gpu_$TAG.log
 grep -v "of the bound" gpurun_out/r05_pytest_gpu_$TAG.log | tail -12
