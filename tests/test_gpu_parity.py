@@ -2,6 +2,8 @@
 against the committed reference outputs (tests/golden).  Bit-exact for index work (argmax, counts);
 floating point within the tolerances BASELINE.json's north_star states (p within 1e-3, top-1 identical),
 prototypes within 2 fp16 ulp."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -346,6 +348,16 @@ def test_classify_fused_exact_ties_take_the_lowest_class(ops):
             assert not bool((am == 31).any()), "the visual duplicate of class 30 won a tie at alpha = 1"
         p_or = po.P(q, zi, zt, alpha, beta)
         assert (am.long() == p_or.max(1)[1]).float().mean().item() > 0.995          # the oracle's fp32 p may break a tie the other way only through rounding
+
+
+def test_classify_routings_differential_fuzz():
+    """tools/fuzz_classify.py: 80 random (shape, alpha, beta, data regime) cases — class-structured, structureless, un-normalised, duplicated prototypes / queries, tiny and
+    huge scales, alpha in {0, 1}, beta in {0, ..., 20} — fused row panels (one pass + candidate proof) against the two stages: differences only at proven ties."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_classify.py"), "80", "7"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "unproven differences in 0 cases" in r.stdout
 
 
 def test_fuse_probs_edge_cases(ops):
