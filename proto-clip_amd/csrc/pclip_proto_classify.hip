@@ -1,11 +1,13 @@
 // Prototype build + classification in ONE launch (reference main.py:399-405 + utils.py:225-244 + main.py:190, the test-time path
 // `z_img_proto = normalise(mean_k normalise(mem))` -> `P(zq, z_img_proto, z_text_proto, alpha, beta)` -> argmax).
-// At EuroSAT's size (10 classes x 16 shots, 8100 queries, D = 512) both stages are latency: a launch costs ~3.5 us on this device before it does any work
-// (tools/c2_probe.py), proto_build is 4.9 us and classify 7.3 us.  Here the first N workgroups of the grid build one prototype each (class_sum + finish_prototype of
-// pclip_proto_dev.h: the bits of pclip_proto_build_f16), publish the row and count themselves in sync[0] (agent-scope release); the other workgroups run
-// classify_small's body (pclip_classify_small.h: the bits of pclip_classify_f16) — their query fragments and the textual bank are requested FIRST, so the HBM latency
-// of the queries runs under the prototype build, then they wait for sync[0] == N and stage the visual bank.  Workgroups are dispatched in blockIdx order, the builders
-// wait for nobody, so the wait cannot deadlock whatever the residency; sync[] is left zero by the last consumer past the wait (one pair of words per stream).
+// At EuroSAT's size (10 classes x 16 shots, 8100 queries, D = 512) both stages are latency: a trivial kernel replays at 1.9 us, proto_build at 4.0 us and classify at
+// 6.4 us (tools/c2_probe.py).  Here the first N workgroups of the grid build one prototype each (class_sum + finish_prototype of pclip_proto_dev.h: the bits of
+// pclip_proto_build_f16), publish the row (write-through stores at agent scope) and count themselves in sync[0]; the other workgroups run classify_small's body
+// (pclip_classify_small.h: the bits of pclip_classify_f16) — the textual waves start at once, the visual waves request their queries FIRST, wait for sync[0] == N
+// and read the prototype rows with agent-coherent loads.  Workgroups are dispatched in blockIdx order and the builders wait for nobody, so the wait cannot deadlock
+// whatever the residency; sync[] is left zero by the last visual wave past the wait (one pair of words per stream).
+// MEASURED SLOWER than the two launches (12.8 - 16.8 us against 10.3): the hand-over across XCDs costs more than the launch it removes (profiles/r05_c2_phases.txt) —
+// the entry point stays for callers that want one graph node; the host wrapper takes the two launches unless asked.
 #include "pclip_proto_dev.h"
 #include "pclip_classify_small.h"
 #include <stdlib.h>

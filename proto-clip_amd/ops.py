@@ -249,9 +249,9 @@ ONE_LAUNCH = os.environ.get("PCLIP_PROTO_CLASSIFY_ONE_LAUNCH", "0") == "1"
 def proto_classify(mem, N: int, K: int, q, zt, alpha: float, beta: float, per_shot_norm: bool = True, want_p=False, want_argmax=True, topk: int = 0,
                    one_launch: bool = None):
     """main.py:399-405 + utils.py:225-244 + main.py:190: prototypes from the memory bank and the classification of q against them.  Returns
-    (z_img_proto [N, D] fp16, p, argmax, topk_p, topk_i).  Default: `proto_build` followed by `classify` (two launches: 5.0 + 7.4 us at EuroSAT's size);
+    (z_img_proto [N, D] fp16, p, argmax, topk_p, topk_i).  Default: `proto_build` followed by `classify` (two launches: 4.0 + 6.4 us at EuroSAT's size);
     one_launch=True (or PCLIP_PROTO_CLASSIFY_ONE_LAUNCH=1) takes pclip_proto_classify_f16 — builder and consumer workgroups in ONE grid, the same bits — which
-    measures 13.3 us there (the cross-workgroup hand-over costs more than the launch it saves), so it is not the default."""
+    measures 12.8 - 16.8 us there (the cross-workgroup hand-over costs more than the launch it saves), so it is not the default."""
     require_cuda(mem, q, zt)
     mem, q, zt = _f16c(mem), _f16c(q), _f16c(zt)
     if mem.shape[0] != N * K:
