@@ -510,8 +510,8 @@ def run(args, hooks, out=None):
                          "frac_at_sustained_clock": (gm["tflops"] / (MFMA_PEAK_TFLOPS * sclk / 2400.0)) if sclk else None,
                          # context, not the contract's peak: what the matrix pipe sustains on this class of operands under the 1.4 kW socket cap (register-only loops,
                          # tools/probe/mfma_power.hip, measured on other boxes of the pool; on zero operands the same loops reach the nominal 2.5 PFLOP/s)
-                         "power_limited_reference": {"mfma_16x16x32_registers_only_tflops": 1965.0, "with_the_kernels_lds_read_ratio_tflops": 1605.0,
-                                                     "frac_of_registers_only": gm["tflops"] / 1965.0, "source": "profiles/r05_mfma_power_probe.txt"},
+                         "power_limited_reference": {"mfma_16x16x32_registers_only_tflops": 1940.0, "four_wave_k_loop_alone_tflops": 1435.0,
+                                                     "frac_of_registers_only": gm["tflops"] / 1940.0, "source": "profiles/r05_mfma_power_probe.txt, r05_gemm4w_epilogue.txt"},
                          "traffic": traffic, "traffic_unit": f"HBM bytes per launch (profiles/{traffic_file}: {traffic_note})",
                          "launches_per_step": gm["launches"], "avg_launch_us": gm["avg_us"],
                          "gemm_ms_per_step": gm["total_ms"], "algorithmic_gflop_per_step": gm["flops"] / 1e9},
