@@ -376,8 +376,13 @@ int pclip_classify_panel_launch(const void* q, const void* zi, const void* zt, i
     float* q_sqp = (float*)b; b += align_up((size_t)Qp * 4, 256);
     float* rec = (float*)b;
     if (g_panel_passes < 0) { const char* e = getenv("PCLIP_CLASSIFY_PANEL_PASSES"); g_panel_passes = e ? atoi(e) : 0; if (g_panel_passes < 0 || g_panel_passes > 2) g_panel_passes = 0; }
+    static int* stats_dev[64];                                      // the counters' device address, looked up once per device
+    int dev = 0;
     int* stats = nullptr;
-    if (hipGetSymbolAddress((void**)&stats, HIP_SYMBOL(g_panel_stats)) != hipSuccess) stats = nullptr;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        if (!stats_dev[dev] && hipGetSymbolAddress((void**)&stats_dev[dev], HIP_SYMBOL(g_panel_stats)) != hipSuccess) stats_dev[dev] = nullptr;
+        stats = stats_dev[dev];
+    }
     {
         const int jobs = rows2 + Qp, pg = ceil_div(jobs, 4) < 4096 ? ceil_div(jobs, 4) : 4096;
 #define PCLIP_PREP(NCH) panel_prep_kernel<NCH><<<pg, 256, 0, s>>>((const half_t*)q, (const half_t*)zi, (const half_t*)zt, q_sq, zi_sq, zt_sq, Q, Qp, N, D, rows2, zz, zz_sq, q_sqp)
