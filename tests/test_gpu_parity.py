@@ -360,6 +360,16 @@ def test_classify_routings_differential_fuzz():
     assert "unproven differences in 0 cases" in r.stdout
 
 
+def test_small_class_count_differential_fuzz():
+    """tools/fuzz_small.py: 60 random (Q, N <= 32, K, D, alpha, beta, regime) cases — the one-launch small-N classification against the oracle's P (1e-5, argmax
+    unless the oracle ties) and the prototype-build + classification launch against proto_build + classify, bit for bit."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_small.py"), "60", "11"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "failures in 0" in r.stdout
+
+
 def test_fuse_probs_edge_cases(ops):
     Q, N = 70, 130
     d2i = torch.from_numpy(synth.uniform(Q * N, 12, 0).reshape(Q, N)).float() * 4
