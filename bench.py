@@ -199,10 +199,9 @@ def c2_kernels(device):
 
     t_pb = gpu_time(lambda: ops.proto_build(mem, N, K))
     t_cl = gpu_time(lambda: ops.classify(q, zi, zt, 1.0, 0.7, want_p=False, want_argmax=True))
-    t_one = gpu_time(lambda: ops.proto_classify(mem, N, K, q, zt, 1.0, 0.7, one_launch=True))
     byts = Q * D * 2 + 2 * N * D * 2 + Q * 4
     return {"workload": "C2 EuroSAT 16-shot ViT-B/32: N = 10, K = 16, D = 512, Q = 8100 (kernels only, hipGraph replay)",
-            "proto_build_us": t_pb * 1e6, "classify_argmax_us": t_cl * 1e6, "proto_build_and_classify_one_launch_us": t_one * 1e6, "classify_algorithmic_bytes": byts,
+            "proto_build_us": t_pb * 1e6, "classify_argmax_us": t_cl * 1e6, "classify_algorithmic_bytes": byts,
             "classify_gb_per_s": byts / t_cl / 1e9, "classify_frac_of_hbm_8tb": byts / t_cl / 8e12}
 
 

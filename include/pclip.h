@@ -115,15 +115,10 @@ int pclip_classify_f16(const void* q, const void* zi, const void* zt, int Q, int
 int pclip_classify_panel_passes(int mode);
 int pclip_classify_panel_stats(int* out2, int reset);
 
-/* Prototype build + classification in ONE launch (csrc/pclip_proto_classify.hip; reference main.py:399-405 followed by utils.py:225-244 / main.py:190):
- * proto_f16 [N, D] = pclip_proto_build_f16(mem [N*K, D], per_shot_norm) — written, and returned to the caller, by the first N workgroups — and the outputs of
- * pclip_classify_f16(q, proto_f16, zt, ...) from the other workgroups of the same grid, which wait for the prototypes behind their own query loads.  Same bits as the
- * two calls.  Shapes: pclip_proto_classify_applies(N, K, D, Q) (N <= 32, D % 32 == 0, D <= 1024, Q >= 1) — otherwise PCLIP_E_ARG: make the two calls.
- * sync: two int32 words, ZERO before the first call; the kernel leaves them zero.  One pair per stream: calls that may run concurrently must not share it. */
-int pclip_proto_classify_applies(int N, int K, int D, int Q);
-int pclip_proto_classify_f16(const void* mem, int N, int K, int D, int per_shot_norm, void* proto_f16, float* proto_sq, const void* q, const void* zt, int Q,
-                             float alpha, float one_minus_alpha, float beta, float* p, int32_t* argmax, float* topk_p, int32_t* topk_i, int topk,
-                             int32_t* sync, pclip_stream_t stream);
+/* One-launch classification for mid-sized class counts (csrc/pclip_classify_mid.hip; utils.py:225-244 + main.py:190): pclip_classify_f16 takes it by itself for
+ * 32 < N <= 256 with both banks, p and / or argmax (no top-k), Q N <= 2e6.  mode 1 = that routing (default; env PCLIP_CLASSIFY_MID), 2 = every shape the kernel can
+ * run (tests), 0 = off (two stages), < 0 = query only.  Returns the previous setting (-1 = not decided yet). */
+int pclip_classify_mid_config(int mode);
 
 /* Test entry of the fused large-N classification (csrc/pclip_classify_panel.hip; pclip_classify_f16 takes that path by itself for N > 32 when only the argmax is
  * asked for): the distances it forms for its first tile — dump [2][256][128] fp32 = d2 of query rows 0..255 x classes 0..127, visual bank then textual bank —

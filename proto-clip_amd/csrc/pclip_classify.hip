@@ -8,7 +8,10 @@
 
 // fused row-panel classification for large class counts (pclip_classify_panel.hip)
 size_t pclip_classify_panel_workspace(int Q, int N, int D);
-bool pclip_classify_panel_applies(int Q, int N, int D, float beta);
+bool pclip_classify_panel_applies(int Q, int N, int D, float alpha, float one_minus_alpha, float beta);
+bool pclip_classify_mid_applies(int Q, int N, int D, bool has_zt, bool topk);
+int pclip_classify_mid_launch(const void* q, const void* zi, const void* zt, int Q, int N, int D, float alpha, float oma, float beta, float* p, int32_t* argmax,
+                              hipStream_t s);
 int pclip_classify_panel_launch(const void* q, const void* zi, const void* zt, int Q, int N, int D, const float* q_sq, const float* zi_sq, const float* zt_sq,
                                 float alpha, float oma, float beta, int32_t* argmax, float* dump, bool dump_exact, void* ws, hipStream_t s);
 
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(256) void classify_small_kernel(const half_t* __res
                                                              int32_t* __restrict__ argmax, float* __restrict__ topk_p,
                                                              int32_t* __restrict__ topk_i, int k) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    classify_small_body<NT, TWO, false>(smem, blockIdx.x, gridDim.x, q, zi, zt, Q, N, D, alpha, oma, beta, p, argmax, topk_p, topk_i, k);
+    classify_small_body<NT, TWO>(smem, blockIdx.x, gridDim.x, q, zi, zt, Q, N, D, alpha, oma, beta, p, argmax, topk_p, topk_i, k);
 }
 
 template <int NT, bool TWO>
@@ -561,9 +564,12 @@ extern "C" int pclip_classify_f16(const void* q, const void* zi, const void* zt,
 #undef PCLIP_SMALL
         }
     }
+    // mid-sized class counts (32 < N <= 256), p and / or argmax: one launch, norms in-kernel (pclip_classify_mid.hip).  PCLIP_CLASSIFY_MID=0: two stages.
+    if (q && zi && (p || argmax) && pclip_classify_mid_applies(Q, N, D, zt != nullptr, topk_p || topk_i || k > 0))
+        return pclip_classify_mid_launch(q, zi, zt, Q, N, D, alpha, one_minus_alpha, beta, p, argmax, (hipStream_t)stream);
     SqWs w = carve_sq(ws, Q, N);
     // large class counts, argmax only: the fused row-panel kernel (pclip_classify_panel.hip) — no distance rows in HBM.  PCLIP_CLASSIFY_PANEL=0: two stages.
-    if (zt && argmax && !p && !topk_p && !topk_i && q && zi && pclip_classify_panel_applies(Q, N, D, beta) &&
+    if (zt && argmax && !p && !topk_p && !topk_i && q && zi && pclip_classify_panel_applies(Q, N, D, alpha, one_minus_alpha, beta) &&
         ws_bytes >= w.bytes + pclip_classify_panel_workspace(Q, N, D)) {
         // (norms that were not supplied are formed by the kernel's own preparation launch: the arithmetic of pclip_row_sqnorm_f16)
         return pclip_classify_panel_launch(q, zi, zt, Q, N, D, q_sq, zi_sq, zt_sq, alpha, one_minus_alpha, beta, argmax, nullptr, false, (char*)ws + w.bytes, (hipStream_t)stream);

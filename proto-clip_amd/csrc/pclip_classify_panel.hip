@@ -354,7 +354,7 @@ extern "C" int pclip_classify_panel_config(int mode) {
     return before;
 }
 
-bool pclip_classify_panel_applies(int Q, int N, int D, float beta) {
+bool pclip_classify_panel_applies(int Q, int N, int D, float alpha, float one_minus_alpha, float beta) {
     if (g_panel_mode < 0) { const char* e = getenv("PCLIP_CLASSIFY_PANEL"); g_panel_mode = e ? atoi(e) : 1; if (g_panel_mode < 0 || g_panel_mode > 2) g_panel_mode = 1; }
     // Routing by measurement (tools/fused_routing_probe.py, profiles/r05_fused_routing.txt): up to one panel per CU the fused kernel's time is ~12 + 17 us per class tile
     // whatever Q is (a CU walks its panel's tiles alone), the two stages cost ~22 us + 8e-6 us per (query, class) — fused from Q N >= 2e6 tiles - 1e6 (ImageNet: Q >= 15 k;
@@ -362,7 +362,10 @@ bool pclip_classify_panel_applies(int Q, int N, int D, float beta) {
     // mode 2 forces the fused kernel for every shape it can run (tests)
     const double tiles = (double)(2 * ((N + 127) / 128 * 128) / 256);
     const bool enough = g_panel_mode == 2 || (double)Q * (double)N >= 2.0e6 * tiles - 1.0e6;
-    return g_panel_mode > 0 && enough && N > 32 && D >= 128 && D % 64 == 0 && D <= 4096 && beta >= 0.f && Q >= 1 && (long)256 * D * 2 < 0x7fffffffL;
+    // the candidate proof bounds a class through p's monotonicity in both distances: both mixing weights and beta must be non-negative (a user's --alpha outside
+    // [0, 1] takes the two stages)
+    const bool monotone = alpha >= 0.f && one_minus_alpha >= 0.f && beta >= 0.f;
+    return g_panel_mode > 0 && enough && monotone && N > 32 && D >= 128 && D % 64 == 0 && D <= 4096 && Q >= 1 && (long)256 * D * 2 < 0x7fffffffL;
 }
 
 // q_sq / zi_sq / zt_sq: device arrays or null (computed by the preparation launch with pclip_row_sqnorm_f16's arithmetic).  dump != nullptr: test mode (distances of panel 0 / tile 0, no argmax; dump_exact:

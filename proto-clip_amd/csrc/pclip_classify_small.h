@@ -1,5 +1,5 @@
-// classify_small: the whole of P (utils.py:225-244) for N <= 32 classes in one launch — the body shared by classify_small_kernel (pclip_classify.hip) and the
-// prototype-build + classification launch (pclip_proto_classify.hip).  ONE definition: the two entry points produce the same bits.
+// classify_small: the whole of P (utils.py:225-244) for N <= 32 classes in one launch — the body of classify_small_kernel (pclip_classify.hip); sq8 is shared with the
+// mid-N kernel (pclip_classify_mid.hip).
 #pragma once
 #include "pclip_common.h"
 
@@ -28,14 +28,13 @@ __device__ __forceinline__ float sq8(half8_t f, float acc) {
 // LDS bytes of a workgroup of `nwaves` waves: two exchange buffers of NT * 4 floats per lane and pair
 __host__ __device__ constexpr int classify_small_lds(int nt, int nwaves) { return 2 * (nwaves / 2) * nt * 4 * 64 * 4; }
 
-// `block` of `nblocks` workgroups run this body.  FUSED (pclip_proto_classify.hip): `zi` is being written by the builder workgroups of the SAME launch — the visual
-// waves request their queries, wait for sync[0] == nbuilders and read the rows with agent-coherent loads (wt: sc1; otherwise behind an agent-scope acquire).
-template <int NT, bool TWO, bool FUSED>
+// `block` of `nblocks` workgroups run this body.
+template <int NT, bool TWO>
 __device__ __forceinline__ void classify_small_body(char* smem, const int block, const int nblocks, const half_t* __restrict__ q, const half_t* zi,
                                                     const half_t* __restrict__ zt, int Q, int N, int D, float alpha,
                                                     float oma, float beta, float* __restrict__ p,
                                                     int32_t* __restrict__ argmax, float* __restrict__ topk_p,
-                                                    int32_t* __restrict__ topk_i, int k, int* sync = nullptr, int nbuilders = 0, int wt = 0) {
+                                                    int32_t* __restrict__ topk_i, int k) {
     const int tid = threadIdx.x, nwaves = blockDim.x >> 6;
     const int lane = tid & 63, wave = tid >> 6, qr = lane & 15, kg = lane >> 4;
     const int steps = D >> 5, ngroups = (Q + 15) >> 4;
@@ -58,17 +57,7 @@ __device__ __forceinline__ void classify_small_body(char* smem, const int block,
                 if (s0 + s < steps) qf[s] = ld_half8(qrow + (s0 + s) * 32);
         }
     };
-#if defined(__HIP_DEVICE_COMPILE__)
-    const __amdgpu_buffer_rsrc_t zi_rs = __builtin_amdgcn_make_buffer_rsrc((void*)zi, 0, N * D * 2, 0x00020000);
-#endif
-    auto load_z1 = [&](int c, int kk) -> half8_t {                                    // 8 halves of class row c at k = kk
-        if (FUSED && wt && !bank) {                                                   // agent-coherent load (sc1): the row was written by another workgroup of this launch
-#if defined(__HIP_DEVICE_COMPILE__)
-            return __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(zi_rs, (c * D + kk) * 2, 0, 16));
-#endif
-        }
-        return ld_half8(z + (size_t)c * D + kk);
-    };
+    auto load_z1 = [&](int c, int kk) -> half8_t { return ld_half8(z + (size_t)c * D + kk); };     // 8 halves of class row c at k = kk
     auto load_z = [&](int s0) {                                                       // rows of classes >= N are zero
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -89,15 +78,6 @@ __device__ __forceinline__ void classify_small_body(char* smem, const int block,
     };
     const bool mine = g < ngroups;
     if (mine) load_q(g, 0);
-    if (FUSED && !bank) {
-        // the visual waves wait for the builders behind their own query loads; every waiting wave counts itself once it is past the wait (the answer is looked at
-        // when the work is done: the round trip runs under the MFMAs) and the last one zeroes both words for the next launch (ordered behind this one on the stream)
-        int spins = 0;
-        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nbuilders && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
-        if (!wt) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                   // this wave's later loads of zi see the builders' rows
-    }
-    int ticket = -1;
-    if (FUSED && !bank && lane == 0) ticket = __hip_atomic_fetch_add(sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (single && mine) load_z(0);
     const int cls0 = 4 * kg;                                                          // first class of this lane inside a tile
     float* xch = reinterpret_cast<float*>(smem);
@@ -255,10 +235,6 @@ __device__ __forceinline__ void classify_small_body(char* smem, const int block,
                         if (t * 16 + cls0 + e == bi) pr[t][e] = -2.f;                 // remove the winner
             }
         }
-    }
-    if (FUSED && ticket == (TWO ? nblocks * (nwaves >> 1) : nblocks * nwaves) - 1) {  // (lane 0 of the last visual wave past the wait)
-        __hip_atomic_store(sync + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -1,9 +1,6 @@
-// Device functions of the prototype reduction shared by pclip_proto.hip (pclip_proto_build_f16 / partial sums) and pclip_proto_classify.hip
-// (prototype build + classification in one launch): ONE definition, so the prototypes are the same bits whichever kernel forms them.
+// Device functions of the prototype reduction (pclip_proto.hip: pclip_proto_build_f16 / partial sums; load_row_sq also serves pclip_classify_panel.hip)
 #pragma once
 #include "pclip_common.h"
-
-typedef unsigned pc_u32x4_t __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -48,10 +45,9 @@ __device__ __forceinline__ float load_row_sq(const half_t* xr, int D, int lane, 
 
 // ---- shared tail: fp32 class sum -> z=r16(sum/cnt) -> fp16 / fp32 normalised prototype ----------
 // Executed by ONE wave; acc[c][j] holds this lane's slice of the class sum.
-// wt: the fp16 row is stored write-through at agent scope (sc1), for a reader in another workgroup of the same launch (pclip_proto_classify.hip)
 template <int NCH>
 __device__ __forceinline__ void finish_prototype(float (&acc)[NCH][8], float inv_or_cnt, int n, int D, int lane,
-                                                 half_t* proto_f16, float* proto_f32, float* proto_sq, bool wt = false) {
+                                                 half_t* proto_f16, float* proto_f32, float* proto_sq) {
     float z[NCH][8];
     float ss = 0.f;
     const RowDiv dcnt(inv_or_cnt);
@@ -85,14 +81,7 @@ __device__ __forceinline__ void finish_prototype(float (&acc)[NCH][8], float inv
                     float f = (float)o[j];
                     ss2 += f * f;
                 }
-                if (proto_f16 && wt) {
-#if defined(__HIP_DEVICE_COMPILE__)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pc_u32x4_t, o), __builtin_amdgcn_make_buffer_rsrc((void*)proto_f16, 0, 0x7fffffff, 0x00020000),
-                                                           (n * D + d) * 2, 0, 16);
-#endif
-                } else if (proto_f16) {
-                    st_half8(proto_f16 + (size_t)n * D + d, o);
-                }
+                if (proto_f16) st_half8(proto_f16 + (size_t)n * D + d, o);
             }
             if (proto_f32) {
                 float4_t o0, o1;

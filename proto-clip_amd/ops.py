@@ -213,75 +213,44 @@ def classify(q, zi, zt, alpha: float, beta: float, want_p=False, want_argmax=Tru
     return p, am, tp, ti
 
 
-_sync_words = {}
-_sync_arena = {}
-
-
-def _sync_pair(device) -> torch.Tensor:
-    """Two zeroed int32 words for pclip_proto_classify_f16 (builders' count, consumers' count).  The kernel leaves them zero, so one pair per (device, stream)
-    serves every eager call on that stream.  A call recorded into a hipGraph gets a pair of its OWN from a zeroed arena allocated outside the capture (replays of
-    one node are ordered; nodes never share a pair); if no arena exists yet (first call ever is inside a capture) the pair is zeroed by a fill node of the graph."""
-    if torch.cuda.is_current_stream_capturing():
-        arena = _sync_arena.get(device)
-        if arena is None or arena[1] + 2 > arena[0].numel():
-            return torch.zeros(2, dtype=torch.int32, device=device)
-        buf = arena[0][arena[1]:arena[1] + 2]
-        arena[1] += 2
-        return buf
-    if device not in _sync_arena:
-        _sync_arena[device] = [torch.zeros(8192, dtype=torch.int32, device=device), 0]
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    buf = _sync_words.get(key)
-    if buf is None:
-        buf = _sync_words[key] = torch.zeros(2, dtype=torch.int32, device=device)
-    else:
-        buf.zero_()              # the kernel leaves them zero only when it runs to completion: a launch that faulted must not poison every later call
-    return buf
-
-
-def proto_classify_applies(N: int, K: int, D: int, Q: int) -> bool:
-    return bool(_lib.load().pclip_proto_classify_applies(N, K, D, Q))
-
-
-ONE_LAUNCH = os.environ.get("PCLIP_PROTO_CLASSIFY_ONE_LAUNCH", "0") == "1"
-
-
-def proto_classify(mem, N: int, K: int, q, zt, alpha: float, beta: float, per_shot_norm: bool = True, want_p=False, want_argmax=True, topk: int = 0,
-                   one_launch: bool = None):
+def proto_classify(mem, N: int, K: int, q, zt, alpha: float, beta: float, per_shot_norm: bool = True, want_p=False, want_argmax=True, topk: int = 0):
     """main.py:399-405 + utils.py:225-244 + main.py:190: prototypes from the memory bank and the classification of q against them.  Returns
-    (z_img_proto [N, D] fp16, p, argmax, topk_p, topk_i).  Default: `proto_build` followed by `classify` (two launches: 4.0 + 6.4 us at EuroSAT's size);
-    one_launch=True (or PCLIP_PROTO_CLASSIFY_ONE_LAUNCH=1) takes pclip_proto_classify_f16 — builder and consumer workgroups in ONE grid, the same bits — which
-    measures 12.8 - 16.8 us there (the cross-workgroup hand-over costs more than the launch it saves), so it is not the default."""
+    (z_img_proto [N, D] fp16, p, argmax, topk_p, topk_i): `proto_build` followed by `classify` (4.0 + 6.4 us at EuroSAT's size).  (A one-launch form — builder and
+    consumer workgroups in one grid — was built in round 5 and measured SLOWER, 12.8 - 16.8 us: the cross-XCD hand-over of the prototype rows costs more than the
+    launch it saves; removed in round 6, profiles/r05_c2_phases.txt.)"""
     require_cuda(mem, q, zt)
     mem, q, zt = _f16c(mem), _f16c(q), _f16c(zt)
     if mem.shape[0] != N * K:
         raise _lib.PclipError(f"memory bank has {mem.shape[0]} rows, expected N*K={N * K}")
-    Q, D = q.shape
-    if one_launch is None:
-        one_launch = ONE_LAUNCH
-    if not one_launch or not proto_classify_applies(N, K, D, Q) or topk > 16:
-        zi = proto_build(mem, N, K, per_shot_norm)
-        return (zi,) + tuple(classify(q, zi, zt, alpha, beta, want_p=want_p, want_argmax=want_argmax, topk=topk))
-    dev = q.device
-    zi = torch.empty(N, D, dtype=torch.float16, device=dev)
-    p = torch.empty(Q, N, dtype=torch.float32, device=dev) if want_p else None
-    am = torch.empty(Q, dtype=torch.int32, device=dev) if want_argmax else None
-    tp = torch.empty(Q, topk, dtype=torch.float32, device=dev) if topk else None
-    ti = torch.empty(Q, topk, dtype=torch.int32, device=dev) if topk else None
-    a32, oma32 = float(np.float32(alpha)), float(np.float32(1 - float(alpha)))
-    check(_lib.load().pclip_proto_classify_f16(ptr(mem), N, K, D, int(per_shot_norm), ptr(zi), None, ptr(q), ptr(zt), Q, a32, oma32, float(np.float32(beta)),
-                                               ptr(p), ptr(am), ptr(tp), ptr(ti), topk, ptr(_sync_pair(dev)), stream()), "pclip_proto_classify_f16")
-    return zi, p, am, tp, ti
+    zi = proto_build(mem, N, K, per_shot_norm)
+    return (zi,) + tuple(classify(q, zi, zt, alpha, beta, want_p=want_p, want_argmax=want_argmax, topk=topk))
+
+
+class classify_mid:
+    """`with ops.classify_mid(mode):` — routing of the one-launch mid-N kernel (32 < N <= 256): 0 off (two stages), 1 by size (default), 2 every shape it can run."""
+    def __init__(self, mode: int):
+        self.mode = mode
+
+    def __enter__(self):
+        self.before = _lib.load().pclip_classify_mid_config(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().pclip_classify_mid_config(self.before if self.before >= 0 else 1)
+        return False
 
 
 class classify_two_stage:
-    """`with ops.classify_two_stage():` — argmax-only classification through pclip_sqdist_f16 + pclip_fuse_probs instead of the fused row-panel kernel (its reference)."""
+    """`with ops.classify_two_stage():` — classification through pclip_sqdist_f16 + pclip_fuse_probs instead of the fused row-panel kernel / the one-launch mid-N
+    kernel (their reference)."""
     def __enter__(self):
         self.before = _lib.load().pclip_classify_panel_config(0)
+        self.before_mid = _lib.load().pclip_classify_mid_config(0)
         return self
 
     def __exit__(self, *exc):
         _lib.load().pclip_classify_panel_config(self.before if self.before >= 0 else 1)
+        _lib.load().pclip_classify_mid_config(self.before_mid if self.before_mid >= 0 else 1)
         return False
 
 

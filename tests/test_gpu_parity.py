@@ -214,55 +214,71 @@ def test_classify_single_launch_small_N(ops, Q, N, D, alpha, beta):
         assert (am != am2).sum().item() <= (~clear).sum().item()
 
 
-@pytest.mark.parametrize("Q,N,K,D", [(8100, 10, 16, 512), (1, 1, 1, 32), (17, 3, 5, 64), (333, 16, 4, 512), (1000, 32, 16, 1024), (77, 31, 2, 96),
-                                     (100, 17, 8, 768), (70000, 10, 16, 512), (500, 37, 4, 512), (64, 10, 16, 2048)])
-@pytest.mark.parametrize("per_shot", [True, False])
-def test_proto_classify_one_launch_is_the_two_calls(ops, Q, N, K, D, per_shot):
-    """pclip_proto_classify_f16 (main.py:399-405 + utils.py:225-244 + main.py:190 in one launch: builder workgroups publish the prototypes, the others wait for them
-    behind their own query loads) returns the bits of proto_build followed by classify — prototypes, p, argmax, top-k — call after call (its two sync words are left
-    zero), at a Q that caps the grid, and for shapes without a single-launch form (N > 32, D > 1024: the wrapper makes the two calls)."""
-    mem = dev(torch.from_numpy(synth.normal((N * K, D), 31, 0)).half())
-    q = dev(po.l2norm_rows(torch.from_numpy(synth.normal((Q, D), 31, 1)).half()))
-    zt = dev(po.l2norm_rows(torch.from_numpy(synth.normal((N, D), 31, 2)).half()))
-    k = min(3, N)
-    zi0 = ops.proto_build(mem, N, K, per_shot_norm=per_shot)
-    p0, am0, tp0, ti0 = ops.classify(q, zi0, zt, 0.4, 9.0, want_p=True, want_argmax=True, topk=k)
-    assert ops.proto_classify_applies(N, K, D, Q) == (N <= 32 and D <= 1024)
-    for rep in range(3):
-        zi, p, am, tp, ti = ops.proto_classify(mem, N, K, q, zt, 0.4, 9.0, per_shot_norm=per_shot, want_p=True, want_argmax=True, topk=k, one_launch=True)
-        assert torch.equal(zi, zi0), f"prototypes differ (call {rep})"
-        assert torch.equal(p, p0) and torch.equal(am, am0) and torch.equal(tp, tp0) and torch.equal(ti, ti0), f"classification differs (call {rep})"
-    zi, _, am, _, _ = ops.proto_classify(mem, N, K, q, zt, 0.4, 9.0, per_shot_norm=per_shot, one_launch=True)            # argmax only
-    assert torch.equal(zi, zi0) and torch.equal(am, am0)
-    if ops.proto_classify_applies(N, K, D, Q):
-        assert all(int(b.abs().sum().item()) == 0 for b in ops._sync_words.values()), "sync words not left zero"
+@pytest.mark.parametrize("Q,N,D", [(2465, 100, 1024), (666, 198, 768), (32, 198, 768), (3669, 37, 512), (1692, 47, 512), (17, 33, 128), (5000, 256, 512), (100, 129, 384),
+                                   (1, 40, 512), (4100, 64, 2048), (9000, 101, 512), (300, 250, 1024), (77, 160, 640), (1000, 70, 1280)])
+@pytest.mark.parametrize("alpha,beta", [(0.5, 12.0), (0.8, 9.0), (0.2, 12.0), (1.0, 0.7), (0.0, 3.0), (0.3, -2.0)])
+def test_classify_one_launch_mid_N(ops, Q, N, D, alpha, beta):
+    """32 < N <= 256 (Caltech-101, FewSOL-198, OxfordPets, DTD ...): the one-launch kernel (csrc/pclip_classify_mid.hip — eight waves per group of 16
+    queries, both banks streamed once, norms in-kernel) against the oracle's P (utils.py:225-244; p within 1e-5, argmax wherever the oracle's top two are 1e-6 apart)
+    and against the two stages it replaces (p within 2e-6, argmax up to the same ties); p-only, argmax-only and both; the argmax is the first maximum of the p it wrote."""
+    q = po.l2norm_rows(torch.from_numpy(synth.normal((Q, D), 23, 0)).half())
+    cen = torch.from_numpy(synth.normal((N, D), 23, 1)).float()
+    q = po.l2norm_rows((q.float() + 0.8 * po.l2norm_rows(cen)[torch.arange(Q) % N]).half())           # class structure: a clear winner for most queries
+    zi = po.l2norm_rows((cen + 0.3 * torch.from_numpy(synth.normal((N, D), 23, 3)).float()).half())
+    zt = (po.l2norm_rows((cen + 0.5 * torch.from_numpy(synth.normal((N, D), 23, 2)).float()).half()).float() * 1.2).half()    # non-unit bank
+    with ops.classify_mid(2):
+        p, am, _, _ = ops.classify(dev(q), dev(zi), dev(zt), alpha, beta, want_p=True, want_argmax=True)
+        _, am_only, _, _ = ops.classify(dev(q), dev(zi), dev(zt), alpha, beta, want_p=False, want_argmax=True)
+        p_only, _, _, _ = ops.classify(dev(q), dev(zi), dev(zt), alpha, beta, want_p=True, want_argmax=False)
+    p_or = po.P(q, zi, zt, alpha, beta)
+    assert (p.cpu() - p_or).abs().max().item() <= 1e-5
+    top2 = p_or.double().topk(2, dim=1)[0]
+    clear = top2[:, 0] - top2[:, 1] > 1e-6
+    assert torch.equal(am.cpu().long()[clear], p_or.max(1)[1][clear])
+    assert torch.equal(p.cpu().max(1)[1], am.cpu().long())
+    assert torch.equal(am_only, am) and torch.equal(p_only, p)
+    if D % 64 == 0:
+        with ops.classify_two_stage():
+            p2, am2, _, _ = ops.classify(dev(q), dev(zi), dev(zt), alpha, beta, want_p=True, want_argmax=True)
+        assert (p - p2).abs().max().item() <= 2e-6
+        assert (am != am2).sum().item() <= (~clear).sum().item()
+    # top-k requests keep the two stages (the kernel writes p and argmax only)
+    if D % 64 == 0:
+        k = 3
+        _, _, tp, ti = ops.classify(dev(q), dev(zi), dev(zt), alpha, beta, want_p=False, want_argmax=False, topk=k)
+        rv, ri = p_or.topk(k, dim=1)
+        torch.testing.assert_close(tp.cpu(), rv, rtol=0, atol=1e-5)
 
 
-def test_proto_classify_under_graph_replay(ops):
-    """Recorded into a hipGraph (each recorded call owns a pair of sync words from the arena) and replayed: the same bits every replay, different memory banks between replays."""
-    N, K, D, Q = 10, 16, 512, 8100
-    mem = dev(torch.from_numpy(synth.normal((N * K, D), 32, 0)).half())
-    q = dev(po.l2norm_rows(torch.from_numpy(synth.normal((Q, D), 32, 1)).half()))
-    zt = dev(po.l2norm_rows(torch.from_numpy(synth.normal((N, D), 32, 2)).half()))
-    ops.proto_classify(mem, N, K, q, zt, 1.0, 0.7, one_launch=True)
-    torch.cuda.synchronize()
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        ops.proto_classify(mem, N, K, q, zt, 1.0, 0.7, one_launch=True)
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    gr = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(gr):
-        outs = [ops.proto_classify(mem, N, K, q, zt, 1.0, 0.7, one_launch=True) for _ in range(4)]
-    for rep in range(3):
-        mem.copy_(dev(torch.from_numpy(synth.normal((N * K, D), 33 + rep, 0)).half()))
-        gr.replay()
+def test_classify_mid_default_routing_and_graph_replay(ops):
+    """The product's own routing takes the one-launch kernel at the C1 / C5 shapes (no context manager), also inside a captured graph; a second launch on fresh
+    queries leaves no state behind."""
+    for Q, N, D in ((2465, 100, 1024), (666, 198, 768)):
+        g = torch.Generator(device="cuda").manual_seed(N)
+        nrm = torch.nn.functional.normalize
+        zi = nrm(torch.randn(N, D, device="cuda", generator=g), dim=-1).half()
+        zt = nrm(torch.randn(N, D, device="cuda", generator=g), dim=-1).half()
+        q = nrm(torch.randn(Q, D, device="cuda", generator=g) + 2 * zi[torch.arange(Q, device="cuda") % N].float(), dim=-1).half()
+        _, am, _, _ = ops.classify(q, zi, zt, 0.5, 12.0)
+        with ops.classify_two_stage():
+            p2, am2, _, _ = ops.classify(q, zi, zt, 0.5, 12.0, want_p=True, want_argmax=True)
+        margin = p2.double().topk(2, dim=1)[0]
+        diff = (am != am2).nonzero().flatten()
+        assert bool(((margin[:, 0] - margin[:, 1])[diff] < 1e-6).all())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.classify(q, zi, zt, 0.5, 12.0)
+        torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        zi0 = ops.proto_build(mem, N, K)
-        am0 = ops.classify(q, zi0, zt, 1.0, 0.7, want_p=False, want_argmax=True)[1]
-        for zi, _, am, _, _ in outs:
-            assert torch.equal(zi, zi0) and torch.equal(am, am0)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            out = ops.classify(q, zi, zt, 0.5, 12.0)[1]
+        for rep in range(3):
+            q.copy_(nrm(torch.randn(Q, D, device="cuda", generator=g) + 2 * zi[torch.arange(Q, device="cuda") % N].float(), dim=-1).half())
+            gr.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, ops.classify(q, zi, zt, 0.5, 12.0)[1])
 
 
 @pytest.mark.parametrize("Q,N,D", [(300, 200, 512), (1000, 1000, 512), (257, 100, 1024), (5000, 198, 768), (33, 40, 128)])
@@ -361,8 +377,8 @@ def test_classify_routings_differential_fuzz():
 
 
 def test_small_class_count_differential_fuzz():
-    """tools/fuzz_small.py: 60 random (Q, N <= 32, K, D, alpha, beta, regime) cases — the one-launch small-N classification against the oracle's P (1e-5, argmax
-    unless the oracle ties) and the prototype-build + classification launch against proto_build + classify, bit for bit."""
+    """tools/fuzz_small.py: 60 random (Q, N <= 256, K, D, alpha, beta, regime) cases — the one-launch classifications (N <= 32: classify_small, 32 < N <= 256:
+    classify_mid) against the oracle's P (1e-5, argmax unless the oracle ties) and against the two stages (p within 2e-6)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_small.py"), "60", "11"], capture_output=True, text=True, timeout=600)
@@ -578,6 +594,74 @@ def test_full_size_properties_C3(ops):
     _, am1, _, _ = ops.fuse_probs(d2i, None, 1000, 1.0, 12.0, want_p=False, want_argmax=True)
     assert cnt[2, 1].item() == (am1.long().cpu() == split.test_labels).sum().item()
     assert acc_lo < cnt[1, 1].item() / 50000 < acc_hi, cnt
+
+
+@pytest.mark.parametrize("structured", [True, False])
+def test_full_size_default_routing_C3(ops, structured):
+    """The DEFAULT routing of `ops.classify(argmax)` at BASELINE's full size (Q = 50 000, N = 1000, D = 512; utils.py:225-244 + main.py:190): the fused row-panel kernel
+    (csrc/pclip_classify_panel.hip) — asserted through its panel counters, 196 panels — against (i) the two-stage path's argmax up to PROVEN ties (two-stage top-2
+    margin < 1e-6 for every query that differs), (ii) the oracle's P on 2048 sampled rows, same rule.  structured: the few-shot split (one pass + candidate proof on every
+    panel); not structured: queries unrelated to any class (flat p) — the candidate proof fails and the second pass runs on the full grid of panels."""
+    Q, N, D, alpha, beta = 50000, 1000, 512, 0.5, 12.0
+    split = synth.make_split(N, 16, D, 64, Q, seed=1, sigma=4.0, sigma_text=2.4)
+    zi = ops.proto_build(dev(split.visual_memory_keys.t().contiguous()), N, 16)
+    zt = ops.l2norm_rows(dev(split.textual_memory_bank.t().contiguous()))
+    if structured:
+        q = dev(split.test_features)
+    else:
+        g = torch.Generator().manual_seed(11)
+        q = dev(torch.nn.functional.normalize(torch.randn(Q, D, generator=g), dim=-1).half())
+    ops.classify_panel_stats(reset=True)
+    _, am, _, _ = ops.classify(q, zi, zt, alpha, beta, want_p=False, want_argmax=True)         # no context manager: the product's own routing
+    npan, nsecond = ops.classify_panel_stats()
+    assert npan == (Q + 255) // 256, f"the fused row-panel kernel did not take the call ({npan} panels counted)"
+    observe(f"C3 full size, default routing, {'structured' if structured else 'structureless'} queries: fraction of panels that needed the second pass", nsecond / npan, 1.0)
+    if structured:
+        assert nsecond < npan // 2               # class-structured rows: most panels are proven by their candidates (this split: 23 of 196 are not)
+    else:
+        assert nsecond > npan // 4               # flat rows: the second pass is what is being tested (82 - 156 of 196 panels by seed)
+    with ops.classify_two_stage():
+        ops.classify_panel_stats(reset=True)
+        _, am2, _, _ = ops.classify(q, zi, zt, alpha, beta, want_p=False, want_argmax=True)
+        assert ops.classify_panel_stats()[0] == 0
+    p2, _, _, _ = ops.classify(q, zi, zt, alpha, beta, want_p=True, want_argmax=False)
+    assert torch.equal(am2.long(), p2.max(1)[1])
+    top2 = p2.topk(2, dim=1).values.double()
+    margin = (top2[:, 0] - top2[:, 1]).cpu()
+    diff = (am != am2).nonzero().flatten().cpu()
+    observe(f"C3 full size ({'structured' if structured else 'structureless'}): two-stage top-2 margin of a query whose fused argmax differs (tie proof)",
+            margin[diff].max().item() if len(diff) else 0.0, 1e-6)
+    assert bool((margin[diff] < 1e-6).all()), (diff.tolist()[:10], margin[diff].tolist()[:10])
+    assert len(diff) <= Q // 1000
+    idx = torch.randperm(Q, generator=torch.Generator().manual_seed(3))[:2048]
+    p_or = po.P(q[idx.cuda()].cpu(), zi.cpu(), zt.cpu(), alpha, beta).double()
+    t2 = p_or.topk(2, dim=1).values
+    d_or = (am[idx.cuda()].cpu().long() != p_or.max(1)[1]).nonzero().flatten()
+    assert bool(((t2[:, 0] - t2[:, 1])[d_or] < 1e-6).all()), d_or.tolist()[:10]
+    assert (p2[idx.cuda()].cpu().double() - p_or).abs().max().item() <= 1e-5
+    if structured:
+        acc = (am.cpu().long() == split.test_labels).float().mean().item()
+        assert 0.2 < acc < 0.99
+
+
+def test_classify_alpha_outside_unit_interval_takes_two_stages(ops):
+    """The fused kernel's one-pass candidate proof bounds a class through p's monotonicity in BOTH distances, which needs alpha >= 0 and 1 - alpha >= 0:
+    a user-supplied --alpha outside [0, 1] must not reach it.  Such calls route to the two stages even when the fused kernel is forced; results = the oracle's."""
+    Q, N, D = 600, 200, 512
+    g = torch.Generator().manual_seed(2)
+    nrm = torch.nn.functional.normalize
+    cen = torch.randn(N, D, generator=g)
+    zi, zt = nrm(cen + 0.3 * torch.randn(N, D, generator=g), dim=-1).half(), nrm(cen + 0.5 * torch.randn(N, D, generator=g), dim=-1).half()
+    q = nrm(cen[torch.randint(0, N, (Q,), generator=g)] + 0.8 * torch.randn(Q, D, generator=g), dim=-1).half()
+    for alpha in (1.2, -0.1):
+        with ops.classify_fused():
+            ops.classify_panel_stats(reset=True)
+            _, am, _, _ = ops.classify(dev(q), dev(zi), dev(zt), alpha, 3.0, want_p=False, want_argmax=True)
+            assert ops.classify_panel_stats()[0] == 0
+        p_or = po.P(q, zi, zt, alpha, 3.0).double()
+        t2 = p_or.topk(2, dim=1).values
+        d_or = (am.cpu().long() != p_or.max(1)[1]).nonzero().flatten()
+        assert bool(((t2[:, 0] - t2[:, 1])[d_or] < 1e-6).all())
 
 
 def test_sqdist_big_tile_path_matches_small_tile_path_and_oracle():

@@ -110,29 +110,6 @@ def test_sqdist_big_and_fused_classify_under_jitter(ops, slib):
         assert torch.equal(am, am_ref)
 
 
-@pytest.mark.parametrize("Q,N,K,D", [(8100, 10, 16, 512), (200, 32, 4, 1024), (40000, 5, 16, 256)])
-def test_proto_classify_with_late_builders(ops, slib, Q, N, K, D):
-    """The prototype-build + classification launch: in the stress build half of the builder workgroups sleep ~4 us before they publish their row, so a consumer whose
-    wait (or acquire) were missing would stage a stale prototype.  Bits of the normal library's two calls, ten launches in a row on the same sync words."""
-    g = torch.Generator(device="cuda").manual_seed(11)
-    nrm = torch.nn.functional.normalize
-    mem = torch.randn(N * K, D, device="cuda", generator=g).half()
-    q = nrm(torch.randn(Q, D, device="cuda", generator=g), dim=-1).half()
-    zt = nrm(torch.randn(N, D, device="cuda", generator=g), dim=-1).half()
-    sync = torch.zeros(2, dtype=torch.int32, device="cuda")
-    for rep in range(10):
-        mem = torch.randn(N * K, D, device="cuda", generator=g).half()               # fresh prototypes each launch: a stale row is a different row
-        zi0 = ops.proto_build(mem, N, K)
-        am0 = ops.classify(q, zi0, zt, 0.5, 12.0, want_p=False, want_argmax=True)[1]
-        zi = torch.full((N, D), float("nan"), dtype=torch.float16, device="cuda")
-        am = torch.full((Q,), -1, dtype=torch.int32, device="cuda")
-        rc = slib.pclip_proto_classify_f16(_lib.ptr(mem), N, K, D, 1, _lib.ptr(zi), None, _lib.ptr(q), _lib.ptr(zt), Q, 0.5, 0.5, 12.0, None, _lib.ptr(am), None, None, 0,
-                                           _lib.ptr(sync), _lib.stream())
-        assert rc == 0, slib.pclip_last_error()
-        assert torch.equal(zi, zi0) and torch.equal(am, am0), f"launch {rep}"
-    assert int(sync.abs().sum().item()) == 0
-
-
 @pytest.mark.parametrize("B,L,H,causal", [(64, 197, 12, False), (32, 257, 16, False), (128, 50, 12, False), (256, 77, 8, True), (16, 129, 12, False), (16, 224, 12, True),
                                           (8, 280, 4, False)])
 def test_attention_under_jitter(ops, slib, B, L, H, causal):

@@ -25,8 +25,6 @@ def main():
            "proto_build": lambda: ops.proto_build(mem, N, K),
            "classify": lambda: ops.classify(q, zi, zt, 1.0, 0.7, want_p=False, want_argmax=True),
            "both": both}
-    if hasattr(ops, "proto_classify"):
-        fns["fused"] = lambda: ops.proto_classify(mem, N, K, q, zt, 1.0, 0.7, one_launch=True)
     for name, fn in fns.items():
         fn()
         torch.cuda.synchronize()
