@@ -80,54 +80,76 @@ def step(st):
 
 
 def measure_gemm(st):
-    """Instrumented extra step (outside the timed region): HIP events on the launch stream around every
-    MFMA-GEMM launch -> total algorithmic FLOPs / total duration of that kernel."""
-    from proto_clip_amd import ops
+    """The MFMA-GEMM launches of one step, timed WITHOUT per-launch event overhead (an event pair around every launch puts ~33 us of gap between
+    consecutive GEMMs — 31.4 ms of "GEMM time" where rocprofv3 sums the same kernels to 28.9 ms).  An instrumented step (outside the timed region) records every
+    `ops.gemm` call; calls are grouped by (M, N, K, epilogue); each group's FIRST call is then replayed `reps` times back to back between ONE pair of HIP events on the
+    launch stream (residual GEMMs into a scratch output, so the residual stream is not accumulated into).  Per-launch time of a group = elapsed / reps — the figure
+    `rocprofv3 --kernel-trace --stats` reports as that kernel's average (profiles/r06_bench_*_kernel_stats.csv); step total = sum over groups of calls x time."""
+    from proto_clip_amd import ops, _lib
     real = ops.gemm
     rec = []
 
-    def timed(a, w, bias=None, act=0, residual=None, out=None):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        y = real(a, w, bias, act, residual, out)
-        e1.record()
-        rec.append((e0, e1, gemm_flops(a.shape[0], w.shape[0], a.shape[1])))
-        return y
+    def grab(a, w, bias=None, act=0, residual=None, out=None):
+        rec.append((a, w, bias, act, residual))
+        return real(a, w, bias, act, residual, out)
 
-    real_ln = ops.gemm_ln
-
-    def timed_ln(x, stats, wf, colsum, bfold, act=0, out=None):          # the LayerNorm-folded linears: the same MFMA kernel, another epilogue
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        y = real_ln(x, stats, wf, colsum, bfold, act, out)
-        e1.record()
-        rec.append((e0, e1, gemm_flops(x.shape[0], wf.shape[0], x.shape[1])))
-        return y
-
-    real_rs = ops.gemm_res_partials
-
-    def timed_rs(a, w, bias, x):                                          # residual GEMMs whose epilogue also emits the row-statistics partials
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        y = real_rs(a, w, bias, x)
-        e1.record()
-        rec.append((e0, e1, gemm_flops(a.shape[0], w.shape[0], a.shape[1])))
-        return y
-
-    from proto_clip_amd import _lib
     lib = _lib.load()
-    ops.gemm, ops.gemm_ln, ops.gemm_res_partials = timed, timed_ln, timed_rs
+    ops.gemm = grab
     n0 = lib.pclip_gemm_kernel_launches()
     try:
         step(st)
         torch.cuda.synchronize()
     finally:
-        ops.gemm, ops.gemm_ln, ops.gemm_res_partials = real, real_ln, real_rs
+        ops.gemm = real
     launches = lib.pclip_gemm_kernel_launches() - n0           # a call whose last round is split = two kernel launches
-    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
-    fl = sum(f for _, _, f in rec)
-    return dict(launches=launches, calls=len(rec), total_ms=ms, avg_us=1e3 * ms / max(launches, 1),
-                tflops=fl / (ms * 1e-3) / 1e12, flops=fl)
+    groups = {}
+    for a, w, bias, act, residual in rec:
+        key = (a.shape[0], w.shape[0], a.shape[1], act, bias is not None, residual is not None)
+        groups.setdefault(key, []).append((a, w, bias, act, residual))
+    W = st["model"].visual.width if hasattr(st["model"].visual, "width") else 0
+
+    def name_of(M, N, K, act, has_bias, has_res):
+        if W and M > 4096:
+            if (N, K, act) == (3 * W, W, 0) and not has_res: return "in_proj"
+            if (N, K) == (W, W) and has_res: return "out_proj"
+            if (N, K, act) == (4 * W, W, 1): return "c_fc"
+            if (N, K) == (W, 4 * W) and has_res: return "c_proj"
+        return f"other {M}x{N}x{K}" + (" +gelu" if act == 1 else "") + (" +res" if has_res else "")
+
+    per, total_ms, total_fl = {}, 0.0, 0.0
+    for key, calls in groups.items():
+        M, N, K, act, has_bias, has_res = key
+        a, w, bias, act, residual = calls[0]
+        out = torch.empty(M, N, dtype=torch.float16, device=a.device)
+        fl = gemm_flops(M, N, K)
+        reps = 10 if fl > 1e11 else 30
+        for _ in range(2):
+            real(a, w, bias, act, residual, out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            real(a, w, bias, act, residual, out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        nm = name_of(*key)
+        d = per.setdefault(nm, dict(calls=0, ms_per_step=0.0, flops_per_step=0.0))
+        d["calls"] += len(calls)
+        d["ms_per_step"] += ms * len(calls)
+        d["flops_per_step"] += fl * len(calls)
+        total_ms += ms * len(calls)
+        total_fl += fl * len(calls)
+    for d in per.values():
+        d["avg_call_us"] = 1e3 * d["ms_per_step"] / d["calls"]
+        d["tflops"] = d["flops_per_step"] / (d["ms_per_step"] * 1e-3) / 1e12
+        d["frac"] = d["tflops"] / MFMA_PEAK_TFLOPS
+        d.pop("flops_per_step")
+    small = {k: v for k, v in per.items() if k.startswith("other")}
+    big = {k: v for k, v in per.items() if not k.startswith("other")}
+    if small:
+        big["other (patch embedding, class-row tail, projection)"] = dict(calls=sum(v["calls"] for v in small.values()), ms_per_step=sum(v["ms_per_step"] for v in small.values()))
+    return dict(launches=launches, calls=len(rec), total_ms=total_ms, avg_us=1e3 * total_ms / max(launches, 1),
+                tflops=total_fl / (total_ms * 1e-3) / 1e12, flops=total_fl, per_variant=big)
 
 
 def self_check(st, n=64):
@@ -140,26 +162,6 @@ def self_check(st, n=64):
     torch.cuda.synchronize()
     ok = full.shape == (BATCH,) and bool(torch.equal(full[idx], sub)) and int(torch.unique(full).numel()) >= 2
     return "ok" if ok else f"MISMATCH: {int((full[idx] != sub).sum())} of {n} labels differ from the sub-batch step"
-
-
-def folded_value(st, steps=10):
-    """Un-timed side measurement for the `extra` block: the same step with the LayerNorm fold on (PCLIP_LN_FOLD=1: an independent rounding of
-    the same size, opt-in — DESIGN section 4), query images / s on this rank."""
-    import proto_clip_amd.clip.model as M
-    was = M.LN_FOLD
-    try:
-        M.LN_FOLD = True
-        for _ in range(3):
-            step(st)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step(st)
-        torch.cuda.synchronize()
-        return steps * BATCH / (time.perf_counter() - t0)
-    finally:
-        M.LN_FOLD = was
-        M.invalidate_ln_fold()
 
 
 def c2_kernels(device):
@@ -205,7 +207,56 @@ def c2_kernels(device):
             "classify_gb_per_s": byts / t_cl / 1e9, "classify_frac_of_hbm_8tb": byts / t_cl / 8e12}
 
 
-PMC_TRAFFIC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")     # newest committed summary first
+def c3_classify(device):
+    """The classification stage at BASELINE configs[2]'s FULL size (Q = 50 000 test queries, N = 1000, D = 512: the fused row-panel kernel of the default routing, which
+    the 1024-query step does not reach), device time by hipGraph replay, on class-structured features (SURVEY 8d's generator) and on structureless ones."""
+    from proto_clip_amd import ops
+    Q, N, K, D = 50000, 1000, 16, 512
+    g = torch.Generator(device=device).manual_seed(1)
+    nrm = torch.nn.functional.normalize
+    cen = torch.randn(N, D, device=device, generator=g)
+    y = torch.randint(0, N, (Q,), device=device, generator=g)
+    q_s = nrm(cen[y] + 0.8 * torch.randn(Q, D, device=device, generator=g), dim=-1).half()
+    zi = ops.proto_build(nrm(cen.repeat_interleave(K, 0) + 0.8 * torch.randn(N * K, D, device=device, generator=g), dim=-1).half(), N, K)
+    zt = nrm(cen + 0.5 * torch.randn(N, D, device=device, generator=g), dim=-1).half()
+    q_r = nrm(torch.randn(Q, D, device=device, generator=g), dim=-1).half()
+
+    def gpu_time(fn, reps=5, iters=5):
+        fn()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(reps):
+                fn()
+        gr.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            gr.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / (iters * reps)
+
+    out = {"workload": "C3 classification stage alone: Q = 50000, N = 1000, D = 512, argmax (default routing = fused row panels)"}
+    for tag, q in (("structured", q_s), ("structureless", q_r)):
+        ops.classify_panel_stats(reset=True)
+        t = gpu_time(lambda: ops.classify(q, zi, zt, ALPHA, BETA, want_p=False, want_argmax=True))
+        npan, nsec = ops.classify_panel_stats()
+        with ops.classify_two_stage():
+            t2 = gpu_time(lambda: ops.classify(q, zi, zt, ALPHA, BETA, want_p=False, want_argmax=True))
+        out[tag] = {"default_routing_us": t * 1e6, "two_stage_us": t2 * 1e6, "panels_second_pass_fraction": (nsec / npan) if npan else None,
+                    "fused_kernel_ran": bool(npan)}
+    return out
+
+
+PMC_TRAFFIC_FILES = ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")     # newest committed summary first
 
 
 def pmc_traffic():
@@ -485,7 +536,6 @@ def run(args, hooks, out=None):
         sclk = (clk.get("sclk_mhz") or {}).get("median")
         power = (clk.get("power_w") or {}).get("median")
         imgs_per_s = args.steps * BATCH * world / dt
-        import proto_clip_amd.clip.model as M
         ref_gflop = GFLOP_PER_IMG_ENCODER + GFLOP_PER_IMG_TAIL
         exe_gflop = gm["flops"] / 1e9 / BATCH + GFLOP_PER_IMG_ATTENTION + GFLOP_PER_IMG_TAIL     # what the HIP path executes: the last block runs on the class rows only
         line = {
@@ -503,8 +553,7 @@ def run(args, hooks, out=None):
                        "alpha": ALPHA, "beta": BETA, "parallelism": f"dp{world} (support rows and queries sharded; all-gather of class sums)"},
             "self_check": check,
             "roofline": {"bound": "mfma", "kernel": "linear4w_kernel (four-wave 256 x 256 tiles, hand-scheduled asm K-loop) + linear_fast_kernel (row-split tails) + linear_small_kernel (fp16 MFMA GEMM: every encoder linear incl. patch embedding and projection, with bias / QuickGELU / residual add in its epilogue"
-                                                    + (", the LayerNorms folded into the consuming linears (PCLIP_LN_FOLD=1)" if M.LN_FOLD else "; the LayerNorms are separate passes (default: the reference's rounding points)")
-                                                    + "; the class-row tail runs the small-M variant)",
+                                                    + "; the LayerNorms are separate passes (the reference's rounding points); the class-row tail runs the small-M variant)",
                          "achieved": gm["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gm["tflops"] / MFMA_PEAK_TFLOPS,
                          "frac_at_sustained_clock": (gm["tflops"] / (MFMA_PEAK_TFLOPS * sclk / 2400.0)) if sclk else None,
                          # context, not the contract's peak: what the matrix pipe sustains on this class of operands under the 1.4 kW socket cap (register-only loops,
@@ -513,7 +562,9 @@ def run(args, hooks, out=None):
                                                      "frac_of_registers_only": gm["tflops"] / 1940.0, "source": "profiles/r05_mfma_power_probe.txt, r05_gemm4w_epilogue.txt"},
                          "traffic": traffic, "traffic_unit": f"HBM bytes per launch (profiles/{traffic_file}: {traffic_note})",
                          "launches_per_step": gm["launches"], "avg_launch_us": gm["avg_us"],
-                         "gemm_ms_per_step": gm["total_ms"], "algorithmic_gflop_per_step": gm["flops"] / 1e9},
+                         "gemm_ms_per_step": gm["total_ms"], "algorithmic_gflop_per_step": gm["flops"] / 1e9,
+                         "per_variant": gm.get("per_variant"),
+                         "method": "every distinct GEMM call of one instrumented step replayed 10 - 30 x back to back between ONE pair of HIP events on the launch stream (no per-launch event gap): avg_call_us is what rocprofv3 --stats reports as the kernel's average"},
             "whole_path": {"note": "reference-equivalent = the FLOPs the REFERENCE module spends per image (every token through all 12 blocks); executed = what the HIP path runs "
                                    "(GEMM launches of the instrumented step + attention contractions + adapter + similarity: the last block works on the class rows only)",
                            "reference_equivalent_gflop_per_image": ref_gflop, "reference_equivalent_tflops": imgs_per_s / world * ref_gflop / 1e3,
@@ -521,11 +572,9 @@ def run(args, hooks, out=None):
                            "executed_gflop_per_image": exe_gflop, "executed_tflops": imgs_per_s / world * exe_gflop / 1e3,
                            "executed_frac": imgs_per_s / world * exe_gflop / 1e3 / MFMA_PEAK_TFLOPS},
         }
-        line["config"]["ln_fold"] = bool(M.LN_FOLD)
         if world == 1 and not args.no_extra and hooks.instrument:
             try:
-                line["extra"] = {"folded_value": folded_value(st), "folded_value_note": "query images/sec of the same step with PCLIP_LN_FOLD=1 (opt-in rounding, un-timed side loop of 10 steps)",
-                                 "c2_kernels": c2_kernels(device)}
+                line["extra"] = {"c2_kernels": c2_kernels(device), "c3_classify": c3_classify(device)}
             except Exception as e:                       # side measurements never take the headline down
                 line["extra"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline and hooks.instrument:

@@ -110,10 +110,11 @@ int pclip_classify_f16(const void* q, const void* zi, const void* zt, int Q, int
  * class of each bank is kept as a candidate, everybody else is bounded through the group's second smallest distances; a panel whose rows all satisfy
  * max bound < best candidate is finished from the candidates — the very argmax of the second pass — and only the others walk the tiles again).
  * pclip_classify_panel_passes: 0 = that (default; env PCLIP_CLASSIFY_PANEL_PASSES), 1 = always two passes (round 5's first form), 2 = candidates computed but every panel
- * sent through the second pass (tests); returns the previous mode, a negative argument only queries.  pclip_classify_panel_stats: out2[0] = panels classified,
- * out2[1] = panels that needed the second pass, since the last reset (host pointers; synchronises the device). */
+ * sent through the second pass (tests); returns the previous mode, a negative argument only queries.  pclip_classify_panel_stats: out3[0] = panels classified,
+ * out3[1] = panels that needed a second pass, out3[2] = class tiles those second passes walked (a second pass covers only the tiles that hold a bound the proof
+ * could not beat), since the last reset (host pointer to three ints; synchronises the device). */
 int pclip_classify_panel_passes(int mode);
-int pclip_classify_panel_stats(int* out2, int reset);
+int pclip_classify_panel_stats(int* out3, int reset);
 
 /* One-launch classification for mid-sized class counts (csrc/pclip_classify_mid.hip; utils.py:225-244 + main.py:190): pclip_classify_f16 takes it by itself for
  * 32 < N <= 256 with both banks, p and / or argmax (no top-k), Q N <= 2e6.  mode 1 = that routing (default; env PCLIP_CLASSIFY_MID), 2 = every shape the kernel can
@@ -184,6 +185,10 @@ int pclip_gemm4w_f16(const void* A, int lda, const void* B, int ldb, void* C, in
  * second half of every tile stored from registers under the next tile's K-loop (bit-identical, measured slower; other shapes fall back to 0).  Test / tuning entry. */
 int pclip_gemm4w_var_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                          const void* bias, int act, const void* residual, int var, pclip_stream_t stream);
+/* Diagnostic (loop variant 8 of pclip_gemm4w_var_f16: the product loop in a kernel that keeps time stamps of its tile phases): device buffer of 260 unsigned that the
+ * next variant-8 launches fill — stamps [4][64] of (workgroup 0 | gridDim / 2) x (wave 0 | 3), eight s_memrealtime stamps (100 MHz) per tile for the first eight
+ * tiles, + one closing stamp per wave at [256 + w].  NULL switches it off.  tools/gemm4w_stamps.py. */
+int pclip_gemm4w_stamp_buffer(void* stamps);
 /* Routing of pclip_gemm_f16's 256 x 256 tiles: mode 1 = four-wave asm-loop kernel (default; env PCLIP_GEMM_4W), 0 = eight-wave kernel, < 0 = query only.
  * Returns the previous setting (-1 = not decided yet).  Same bits either way. */
 int pclip_gemm4w_config(int mode);
@@ -227,41 +232,6 @@ int pclip_conv3x3_bn_f16(const void* x, const void* w, const void* zero_line, in
 int pclip_layernorm_f16(const void* x, int ld_x, const float* gamma, const float* beta, float eps, void* y,
                         int R, int D, pclip_stream_t stream);
 
-/* LayerNorm folded into the nn.Linear that consumes it (ln_1 -> attn.in_proj, ln_2 -> mlp.c_fc of a ResidualAttentionBlock,
- * clip/model.py:155-161, 171-190):  LN(x) W^T + b = rstd (x (g.W)^T - mu colsum(g.W)) + (beta W^T + b), so the linear runs on the
- * un-normalised rows and the LayerNorm pass (read x, write h) disappears.  Three entry points:
- *  - pclip_ln_fold_weights_f16: once per (LayerNorm, Linear) pair.  W [N, K] fp16 (row stride ldw), gamma / beta fp32 [K], bias
- *    fp16 [N] or NULL -> Wf [N, K] fp16 = r16(gamma . W), colsum [N] fp32 = row sums of Wf, bfold [N] fp32 = beta W^T + bias.
- *  - pclip_row_stats_f16: per call.  stats[r] = (mean, 1/sqrt(var + eps)) of row r of x [R, D] fp16 (row stride ld_x), fp32, from
- *    the row's sum and sum of squares (var = E[x^2] - mean^2, clamped at 0).  stats must hold round_up(R, 256) + 256 rows of 2 floats (16-byte aligned):
- *    the linear stages whole 256-row tiles of it, and a row-split call starts its second launch at a multiple of 128 rows.
- *  - pclip_gemm_ln_f16: C [M, N] fp16 = act(r16(rstd_m (acc_mn - mu_m colsum_n) + bfold_n)), acc = x Wf^T in fp32; act 0 none,
- *    1 QuickGELU; N % 64 == 0, K % 64 == 0.  Same value for a row whatever the batch around it.
- * Rounding: h = r16(LN(x)) is not formed and Wf is rounded instead (DESIGN section 4 has the measured effect). */
-/*  - pclip_gemm_res_stats_f16 + pclip_row_stats_finalize: the statistics for free.  `x = x + linear(a)` (clip/model.py:188-189:
- *    pclip_gemm_f16 with residual, C may be residual) whose row-major store pass also emits (sum, sum of squares) of every
- *    updated row per 64 output columns into partials [M][N / 64][2] fp32; pclip_row_stats_finalize turns partials [R][D / 64][2]
- *    into stats [R][2] (stats sized as for pclip_row_stats_f16).  Both routes use one association order (chunks of 8 columns,
- *    butterfly per 64 / 128 / 256 columns, 256-column blocks left to right), so stats are bit-identical whichever kernel or
- *    tile width produced them — and identical to pclip_row_stats_f16 of the same rows. */
-int pclip_gemm_res_stats_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* bias,
-                             const void* residual, float* partials, pclip_stream_t stream);
-int pclip_row_stats_finalize(const float* partials, int R, int D, float eps, float* stats, pclip_stream_t stream);
-/* The two statements of a ResidualAttentionBlock that follow each other without a choice (clip/model.py:188-189 and the LayerNorm the next linear reads:
- * ln_2 behind `x = x + attention(..)`, the next block's ln_1 behind `x = x + mlp(..)`) as ONE launch, with the reference's rounding points:
- *   C [M, N] fp16 (row stride ldc) = r16(C + r16(A B^T + bias))   in place,   y [M, N] fp16 (contiguous) = r16(LayerNorm(C) gamma + beta), fp32 statistics.
- * The GEMM's workgroups count their finished tiles per row panel and the one that completes a panel normalises its rows while they are still on the chip:
- * there is no LayerNorm pass over x (620 MB of HBM traffic per call at the bench's size).  Bit-identical to pclip_gemm_f16(.., residual = C) followed by
- * pclip_layernorm_f16 — which is what runs when the shape has no fused form (few tiles, N > 1024, K = 64), when panel_counters is NULL, or under PCLIP_RES_LN=0.
- * panel_counters: M / 128 + 2 ints of device memory, ZERO on entry, zero again when the call has executed (one array per stream that calls this). */
-int pclip_gemm_res_ln_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* bias,
-                          const float* gamma, const float* beta, float eps, void* y, int32_t* panel_counters, pclip_stream_t stream);
-int pclip_ln_fold_weights_f16(const void* W, int ldw, int N, int K, const float* gamma, const float* beta, const void* bias,
-                              void* Wf, float* colsum, float* bfold, pclip_stream_t stream);
-int pclip_row_stats_f16(const void* x, int ld_x, float eps, float* stats, int R, int D, pclip_stream_t stream);
-int pclip_gemm_ln_f16(const void* x, int ldx, const float* rowstats, const void* Wf, int ldw, void* C, int ldc, int M, int N, int K,
-                      const float* colsum, const float* bfold, int act, pclip_stream_t stream);
-
 /* Residual add fused into the following LayerNorm (clip/model.py:188-189 then ln_2 / next ln_1 / ln_post /
  * ln_final): xs = r16(x + delta); x_out (nullable, may alias x; row stride ld) receives xs;
  * y [R, D] = r16(LayerNorm(xs)).  x and delta rows are ld elements apart. */
@@ -299,12 +269,10 @@ int pclip_vit_assemble_tokens_f16(const void* patch_emb, const void* class_emb, 
                                   int G2, int W, void* tokens, pclip_stream_t stream);
 /* The same assembly fused with ln_pre and the first block's ln_1 (clip/model.py:225-227, 188): x0 = ln_pre(tokens) (the residual
  * stream entering the transformer) and h = ln_1(x0), one pass per token row, bit-identical to the three separate calls.
- * h may be NULL (then gamma_1 / beta_1 are unused) when stats is given: stats [round_up(B*(G2+1), 256) + 256][2] fp32 receives the
- * (mean, rstd) of every x0 row exactly as pclip_row_stats_f16 computes them — the first block's ln_1 folded into its in_proj
- * (pclip_gemm_ln_f16). */
+ * h may be NULL (then gamma_1 / beta_1 are unused): only x0 is produced. */
 int pclip_vit_embed_ln_f16(const void* patch_emb, const void* class_emb, const void* pos_emb, int B, int G2, int W,
                            const float* gamma_pre, const float* beta_pre, const float* gamma_1, const float* beta_1, float eps,
-                           void* x0, void* h, float* stats, pclip_stream_t stream);
+                           void* x0, void* h, pclip_stream_t stream);
 
 /* Text stem (clip/model.py:342-344): x = token_embedding[text] + positional_embedding, fp16. */
 int pclip_text_embed_f16(const int64_t* tokens, const void* tok_emb, const void* pos_emb, int B, int L, int W,

@@ -51,6 +51,7 @@ _SIGS = {
     "pclip_gemm_f16": [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P],
     "pclip_gemm4w_f16": [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P],
     "pclip_gemm4w_var_f16": [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P],
+    "pclip_gemm4w_stamp_buffer": [_P],
     "pclip_gemm4w_config": [c_int],
     "pclip_gemm_splitk_workspace": [c_int, c_int, c_int],
     "pclip_gemm_splitk_f16": [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_size_t, _P],
@@ -58,12 +59,6 @@ _SIGS = {
     "pclip_gemm_bn_res_f16": [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P],
     "pclip_conv3x3_bn_f16": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P],
     "pclip_layernorm_f16": [_P, c_int, _P, _P, c_float, _P, c_int, c_int, _P],
-    "pclip_ln_fold_weights_f16": [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P],
-    "pclip_row_stats_f16": [_P, c_int, c_float, _P, c_int, c_int, _P],
-    "pclip_gemm_res_stats_f16": [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P],
-    "pclip_row_stats_finalize": [_P, c_int, c_int, c_float, _P, _P],
-    "pclip_gemm_res_ln_f16": [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P],
-    "pclip_gemm_ln_f16": [_P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P],
     "pclip_add_layernorm_f16": [_P, _P, c_int, _P, _P, _P, c_float, _P, c_int, c_int, _P],
     "pclip_attention_f16": [_P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "pclip_attention_q_f16": [_P, c_int, c_long, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
@@ -71,7 +66,7 @@ _SIGS = {
     "pclip_im2col_patches_f16": [_P, c_int, c_int, c_int, _P, c_int, _P],
     "pclip_im2col_patches_f32": [_P, c_int, c_int, c_int, _P, c_int, _P],
     "pclip_vit_assemble_tokens_f16": [_P, _P, _P, c_int, c_int, c_int, _P, _P],
-    "pclip_vit_embed_ln_f16": [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P, _P, _P, _P],
+    "pclip_vit_embed_ln_f16": [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P, _P, _P],
     "pclip_text_embed_f16": [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P],
     "pclip_gather_eot_f16": [_P, _P, c_int, c_int, c_int, _P, _P],
     "pclip_im2col3x3_f16": [_P, c_long, c_long, c_long, c_long, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P],

@@ -13,7 +13,6 @@ Both vision towers are built: VisionTransformer (ViT-B/32, ViT-B/16, ViT-L/14) a
 RN101: NHWC activations, 1x1 convs as GEMMs and 3x3 convs as implicit GEMMs with the eval BatchNorm (+ReLU) in their
 epilogue; im2col + GEMM only for the strided 3-channel first convolution of the stem)."""
 import os
-import weakref
 from collections import OrderedDict
 
 import numpy as np
@@ -64,71 +63,20 @@ def _transformer(width, layers):
     return t
 
 
-# LayerNorm folded into the linear that consumes it (ops.gemm_ln): OPT-IN (PCLIP_LN_FOLD=1, +3.5 % throughput on ViT-B/16).  The
-# default keeps the reference's rounding points (h = r16(LN(x)), then the linear): on towers with trained-like LayerNorm
-# statistics that path reproduces the reference's fp16 chain to 6e-5 .. 8e-5 in p — the reference's own self-noise under a
-# one-ulp input jitter — where the folded form (r16(gamma * W) instead of r16(h): an independent rounding) sits at 0.6 - 1.0e-3
-# (tests/test_gpu_e2e.py, profiles/r03_e2e_fold_study.json).  Against the reference's fp32 towers the two are
-# equal.  Split-K (low-latency serving) launches keep the unfused form either way.
-LN_FOLD = os.environ.get("PCLIP_LN_FOLD", "0") == "1"
-# ... and the row statistics come out of the epilogue of the residual GEMM that writes x (ops.gemm_res_stats) instead of a pass
-# over x; PCLIP_LN_STATS_EPI=0 keeps the separate pass (same values bit for bit).
-STATS_IN_EPILOGUE = os.environ.get("PCLIP_LN_STATS_EPI", "1") != "0"
-# Unfolded path, PCLIP_RES_LN_FUSE=1: the LayerNorm that follows a residual add (ln_2, the next block's ln_1) is computed inside the launch of that add's GEMM, by
-# the workgroup that owns the finished row panel (ops.gemm_res_ln) — the same bits as the two launches, no LayerNorm pass over x.  Off by default: measured 1.2 %
-# SLOWER in the bench (profiles/r04_ab_res_ln.txt: the rows' LayerNorm arithmetic is VALU-bound on the GEMM's eight waves per CU, 17 us per 256-row panel).
-RES_LN = os.environ.get("PCLIP_RES_LN_FUSE", "0") == "1"
+# (Rounds 2 - 5 carried two opt-in forms of the LayerNorms — folded into the consuming linear (PCLIP_LN_FOLD=1: an independent rounding, +3.5 % in round 3, -0.9 % against
+# the four-wave GEMM of round 5) and computed inside the residual GEMM's launch (PCLIP_RES_LN_FUSE=1: same bits, -1.2 %).  Both lost to the plain LayerNorm pass and
+# were removed in round 6: profiles/r03_e2e_fold_study.json, r04_ab_res_ln.txt, r06_bench_v0.json.)
 
 
-# block -> {linear name: (tag, folded operands)}.  Kept OUTSIDE the modules (weak keys): the folded copies (~7 W^2 halves per
-# block: 60 MB for ViT-B/16, 350 MB for ViT-L/14) are neither deep-copied nor pickled with the model.
-_FOLD_CACHE = weakref.WeakKeyDictionary()
-
-
-def invalidate_ln_fold(model=None):
-    """Forget the folded LayerNorm / linear operands (all of them, or those of `model`'s blocks).  The cache key is (data_ptr,
-    _version) of the four source tensors, which `param.data = ...` / `param.data.copy_()` do not bump: call this after writing
-    parameters through `.data`."""
-    if model is None:
-        _FOLD_CACHE.clear()
-        return
-    for m in model.modules():
-        _FOLD_CACHE.pop(m, None)
-
-
-def _folded(blk, name, w, b, ln):
-    """(Wf, colsum, bfold) of `ln` folded into the linear (w, b), cached per block and refreshed when any of the four changes;
-    None when r16(gamma * W) overflows fp16 (|gamma W| > 65504: the caller then takes the unfolded LayerNorm + linear)."""
-    ver = lambda t: t._version if not t.is_inference() else -1
-    tag = tuple((t.data_ptr(), ver(t), t.dtype, t.device) for t in (w, b, ln.weight, ln.bias))
-    cache = _FOLD_CACHE.setdefault(blk, {})
-    hit = cache.get(name)
-    if hit is None or hit[0] != tag:
-        f32 = lambda t: t.detach() if t.dtype == torch.float32 else t.detach().float()
-        if w.is_cuda and torch.cuda.is_current_stream_capturing():
-            # the overflow check below is a host read: illegal inside a hipGraph capture.  Fold eagerly first (one warm-up forward, or
-            # invalidate_ln_fold + a forward after changing parameters), then capture (ADVICE r3).
-            raise RuntimeError("PCLIP_LN_FOLD: the folded LayerNorm / linear operands must be built before a graph capture starts (run one eager forward first)")
-        folded = ops.ln_fold_weights(w.detach(), b.detach(), f32(ln.weight), f32(ln.bias))
-        if not all(bool(torch.isfinite(t).all()) for t in folded):      # Wf, colsum and the folded bias; once per (LayerNorm, Linear) pair
-            folded = None
-        hit = (tag, folded)
-        cache[name] = hit
-    return hit[1]
-
-
-def _run_blocks(x, blocks, B, L, heads, causal, select=None, first_token=False, h0=None, stats0=None):
+def _run_blocks(x, blocks, B, L, heads, causal, select=None, first_token=False, h0=None):
     """ResidualAttentionBlock.forward (clip/model.py:187-190) per layer on x [B*L, W] fp16 (updated IN PLACE).
     Both residual adds ride in the epilogue of the GEMM that produces the addend (pclip_gemm_f16 with `residual`: the residual
-    rows are read in the coalesced store pass, r16(x + r16(acc + bias)) — the reference's two roundings), and both LayerNorms
-    are folded into the linears that consume them (ops.gemm_ln: the GEMM runs on x itself against gamma-scaled weights and its
-    epilogue applies the row's mean / rstd), so a block is
-        s = stats(x)   qkv = in_proj_ln(x, s)   a = attention(qkv)   x += out_proj(a)
-        s = stats(x)   f = QuickGELU(c_fc_ln(x, s))                  x += c_proj(f)
-    where stats reads x once (the LayerNorm pass it replaces read x and wrote h).  With LN_FOLD off each LayerNorm is a plain
-    read-x / write-h pass followed by the ordinary linear.
+    rows are read in the coalesced store pass, r16(x + r16(acc + bias)) — the reference's two roundings); each LayerNorm is a
+    read-x / write-h pass (the reference's rounding point h = r16(LN(x))) followed by the ordinary linear:
+        h = ln_1(x)   qkv = in_proj(h)   a = attention(qkv)   x += out_proj(a)
+        h = ln_2(x)   f = QuickGELU(c_fc(h))                  x += c_proj(f)
     In low-latency mode (ops.low_latency: split-K linears of a serving request) the addend is produced by the split-K kernel
-    and the add stays in the LayerNorm pass (pclip_add_layernorm_f16), unfolded.
+    and the add stays in the LayerNorm pass (pclip_add_layernorm_f16).
     Returns (x, d): the stack's output is x (+ d when d is not None — low-latency mode leaves the last add to the caller's
     final LayerNorm), [B, W] rows picked by `select` when given.
 
@@ -139,88 +87,51 @@ def _run_blocks(x, blocks, B, L, heads, causal, select=None, first_token=False, 
     FLOPs saved (6 % of a 12-layer tower).  `first_token` (vision tower: the
     selected row is token 0 of every sequence) additionally projects the last block's QUERIES for those B rows only and runs
     its attention for that one query per image (keys / values still come from every token).
-    `h0` / `stats0`: the first block's ln_1 output, or (LN_FOLD) the row statistics of x, when the caller's stem produced them."""
+    `h0`: the first block's ln_1 output when the caller's stem produced it."""
     n = len(blocks)
     d = None
 
-    class _Norm:
-        """LN(x) in whichever form the next linear takes: the normalised rows `h`, or (folded) x with its row statistics."""
-        def __init__(self, x_, ln, h=None, stats=None):
-            self.x, self.ln, self.h, self.stats = x_, ln, h, stats
-
-        def pick(self, sel):
-            """The same for the rows `sel` picks (statistics are per row: recomputed on the picked rows, same values)."""
-            if self.h is not None:
-                return _Norm(None, self.ln, h=sel(self.h))
-            xs = sel(self.x)
-            return _Norm(xs, self.ln, stats=ops.row_stats(xs))
-
     def norm_of(x_, ln):
-        if ln is None:
-            return None
-        if LN_FOLD and not ops.splitk_active(x_.shape[0]):
-            return _Norm(x_, ln, stats=ops.row_stats(x_))
-        return _Norm(x_, ln, h=ops.layernorm(x_, ln.weight, ln.bias))
+        return None if ln is None else ops.layernorm(x_, ln.weight, ln.bias)
 
-    def linear(nm, blk, name, w, bias, act=0, rows=None):
-        """act(LN(x) w^T + bias); `rows` = a row range of (w, bias) (the q / kv thirds of in_proj)."""
-        if nm.h is not None:
-            sl = slice(None) if rows is None else rows
-            return ops.gemm(nm.h, w[sl], bias[sl], act=act)
-        folded = _folded(blk, name, w, bias, nm.ln)
-        if folded is None:                                  # folded weight not representable in fp16: the reference's two steps
-            sl = slice(None) if rows is None else rows
-            return ops.gemm(ops.layernorm(nm.x, nm.ln.weight, nm.ln.bias), w[sl], bias[sl], act=act)
-        wf, cs, bf = folded
-        if rows is not None:
-            wf, cs, bf = wf[rows], cs[rows], bf[rows]
-        return ops.gemm_ln(nm.x, nm.stats, wf, cs, bf, act=act)
+    def linear(h, w, bias, act=0, rows=None):
+        """act(h w^T + bias); `rows` = a row range of (w, bias) (the q / kv thirds of in_proj)."""
+        sl = slice(None) if rows is None else rows
+        return ops.gemm(h, w[sl], bias[sl], act=act)
 
     def add_linear(x_, a_, lin, ln):
-        """x_ += lin(a_) ; returns (x_, LN(x_) as a _Norm)."""
+        """x_ += lin(a_) ; returns (x_, ln(x_))."""
         if ops.splitk_active(a_.shape[0]):
-            d = ops.gemm(a_, lin.weight, lin.bias)
-            return x_, _Norm(x_, ln, h=ops.add_layernorm(x_, d, ln.weight, ln.bias))
-        if ln is not None and LN_FOLD and STATS_IN_EPILOGUE and not ops.splitk_active(x_.shape[0]):
-            stats = ops.gemm_res_stats(a_, lin.weight, lin.bias, x_)       # the add, and the statistics of the updated rows with it
-            return x_, (_Norm(x_, ln, stats=stats) if stats is not None else norm_of(x_, ln))
-        if ln is not None and RES_LN and not LN_FOLD:
-            # the residual add and the LayerNorm behind it in one launch (ops.gemm_res_ln): no pass over x between the two linears
-            return x_, _Norm(x_, ln, h=ops.gemm_res_ln(a_, lin.weight, lin.bias, x_, ln.weight, ln.bias))
+            dd = ops.gemm(a_, lin.weight, lin.bias)
+            return x_, ops.add_layernorm(x_, dd, ln.weight, ln.bias)
         ops.gemm(a_, lin.weight, lin.bias, residual=x_, out=x_)
         return x_, norm_of(x_, ln)
 
-    nm = None
+    h = None
     if n > 0:
-        ln0 = blocks[0].ln_1
-        if h0 is not None:
-            nm = _Norm(x, ln0, h=h0)
-        elif stats0 is not None:
-            nm = _Norm(x, ln0, stats=stats0)
-        else:
-            nm = norm_of(x, ln0)
+        h = h0 if h0 is not None else norm_of(x, blocks[0].ln_1)
     for i, blk in enumerate(blocks):
         last = i == n - 1
         w, bias = blk.attn.in_proj_weight, blk.attn.in_proj_bias
         if select is not None and last and first_token and not causal:
             W = x.shape[1]
-            kv = linear(nm, blk, "in_proj", w, bias, rows=slice(W, 3 * W))          # keys | values of every token
-            q = linear(nm.pick(select), blk, "in_proj", w, bias, rows=slice(0, W))  # queries of the class tokens
+            kv = linear(h, w, bias, rows=slice(W, 3 * W))                           # keys | values of every token
+            q = linear(select(h), w, bias, rows=slice(0, W))                        # queries of the class tokens
             a, x = ops.attention_first_queries(q, kv, B, L, 1, heads), select(x)
         else:
-            qkv = linear(nm, blk, "in_proj", w, bias)
+            qkv = linear(h, w, bias)
             a = ops.attention(qkv, B, L, heads, causal=causal)
             if select is not None and last:
                 a, x = select(a), select(x)              # x holds the residual stream entering this block's out_proj add
-        x, nm = add_linear(x, a, blk.attn.out_proj, blk.ln_2)
-        f = linear(nm, blk, "c_fc", blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, act=1)
+        x, h = add_linear(x, a, blk.attn.out_proj, blk.ln_2)
+        f = linear(h, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, act=1)
         if last:
             if ops.splitk_active(f.shape[0]):
                 d = ops.gemm(f, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)      # the caller's final LayerNorm adds it
             else:
                 ops.gemm(f, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, residual=x, out=x)
         else:
-            x, nm = add_linear(x, f, blk.mlp.c_proj, blocks[i + 1].ln_1)
+            x, h = add_linear(x, f, blk.mlp.c_proj, blocks[i + 1].ln_1)
     if select is not None and n == 0:
         x = select(x)
     return x, d
@@ -291,17 +202,15 @@ class VisionTransformer(nn.Module):
         cols = ops.im2col_patches(img, P)                                   # conv1 as GEMM (clip/model.py:222)
         patch = ops.gemm(cols, wconv)
         blocks = self.transformer.resblocks
-        h0 = stats0 = None
-        if len(blocks) > 0 and LN_FOLD and not ops.splitk_active(B * L):    # tokens + ln_pre + the row statistics of the first (folded) ln_1
-            x, stats0 = ops.vit_embed_ln(patch, cls16, pos16, B, G * G, W, self.ln_pre.weight, self.ln_pre.bias, want_stats=True)
-        elif len(blocks) > 0:                                               # tokens + ln_pre + the first block's ln_1 in one pass
+        h0 = None
+        if len(blocks) > 0:                                                 # tokens + ln_pre + the first block's ln_1 in one pass
             x, h0 = ops.vit_embed_ln(patch, cls16, pos16, B, G * G, W, self.ln_pre.weight, self.ln_pre.bias, blocks[0].ln_1.weight,
                                      blocks[0].ln_1.bias)                   # clip/model.py:225-227, 188
         else:
             x = ops.vit_assemble_tokens(patch, cls16, pos16, B, G * G, W)   # clip/model.py:225-226
             x = ops.layernorm(x, self.ln_pre.weight, self.ln_pre.bias)      # 227
         pick_cls = lambda t: t.view(B, L, W)[:, 0, :].contiguous()          # x[:, 0, :], 233 (taken before the last block's tail)
-        x, d = _run_blocks(x, blocks, B, L, self.heads, causal=False, select=pick_cls, first_token=True, h0=h0, stats0=stats0)   # 229-231
+        x, d = _run_blocks(x, blocks, B, L, self.heads, causal=False, select=pick_cls, first_token=True, h0=h0)   # 229-231
         if d is None:                                                       # ln_post(x[:, 0, :]), 233
             cls = ops.layernorm(x, self.ln_post.weight, self.ln_post.bias)
         else:

@@ -112,18 +112,21 @@ __global__ __launch_bounds__(512, 2) void classify_panel_kernel(const half_t* __
         // One pass over the panel's class tiles; PASS 0: statistics, PASS 1: argmax.  Separate instantiations (and scopes) per pass: the per-row state of one pass is
         // not alive during the other's K-loops (all of it at once spilled 29 registers).  `tile_fn(tn, k, d, rowconst)` consumes the lane's distances of row k.
         // PASS 0 with `then_next`: the pass is expected to be the panel's only one (candidate records, below), so its last tile prefetches the NEXT panel
-        auto walk = [&](auto pass_tag, const bool then_next, auto&& tile_fn) {
+        // `tmask`: the class tiles to walk (bit tn; pass 1: all of them; the second pass of the candidate form: the tiles whose bounds the proof could not beat)
+        auto walk = [&](auto pass_tag, const bool then_next, unsigned tmask, auto&& tile_fn) {
             constexpr int PASS = decltype(pass_tag)::value;
 #pragma unroll 1
-            for (int tn = 0; tn < tiles_n; ++tn) {
+            for (unsigned left = tmask; left != 0;) {
+                const int tn = __builtin_ctz(left);
+                left &= left - 1;
                 pgemm::Acc<C> acc;
                 pgemm::mainloop_sr<C, 0, true, TP>(tp, nt, smem, acc, p, false, wave, lane);
                 const int zp = zpar;
                 // the next tile's K-tile 0 (this panel's next tile, the first tile of its second pass, or the next panel's first) under this tile's arithmetic
                 {
-                    const bool last = tn + 1 == tiles_n;
+                    const bool last = left == 0;
                     zpar ^= 1;
-                    if (!last) issue(m0, tn + 1, zpar);
+                    if (!last) issue(m0, __builtin_ctz(left), zpar);
                     else if (PASS == 0 && !then_next) issue(m0, 0, zpar);
                     else if (next_panel < npanels) { issue_q(next_panel * C::BM, qpar ^ 1); issue(next_panel * C::BM, 0, zpar); }
                 }
@@ -151,8 +154,10 @@ __global__ __launch_bounds__(512, 2) void classify_panel_kernel(const half_t* __
         constexpr bool cand = CAND && !DUMP;                                                           // one pass + candidate records (two passes only where the proof fails)
         float* rec_wg = rec + (size_t)blockIdx.x * tiles_n * (8 * 256 * 8);
         bool second_pass = !cand;
+        const unsigned all_tiles = tiles_n >= 32 ? 0xffffffffu : ((1u << tiles_n) - 1u);
+        unsigned tmask2 = all_tiles;                                                                   // tiles of the second pass
         if (DUMP) {
-            walk(std::integral_constant<int, 1>{}, false, [&](int tn, int k, const float (&d)[2][16]) {
+            walk(std::integral_constant<int, 1>{}, false, all_tiles, [&](int tn, int k, const float (&d)[2][16]) {
                 if (panel != 0 || tn != 0) return;
 #pragma unroll
                 for (int bank = 0; bank < 2; ++bank)
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void classify_panel_kernel(const half_t* __
             float mn[4][2], sm[4][2];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { mn[k][0] = mn[k][1] = 3e38f; sm[k][0] = sm[k][1] = 0.f; }
-            walk(std::integral_constant<int, 0>{}, cand, [&](int tn, int k, const float (&d)[2][16]) {
+            walk(std::integral_constant<int, 0>{}, cand, all_tiles, [&](int tn, int k, const float (&d)[2][16]) {
                 float gmin[2] = {0.f, 0.f};
                 if (cand) {
                     // candidate record of this (row, lane-slot, tile) group of 16 classes: per bank the smallest distance with its class and that class's distance in
@@ -243,16 +248,25 @@ __global__ __launch_bounds__(512, 2) void classify_panel_kernel(const half_t* __
         // expression below is monotone in both) p <= U_group.  If max_groups U < the best candidate's p, the candidates' argmax (lowest class among equal maxima) IS
         // the argmax of the row: same bits as pass 2 would give.  Otherwise (flat distributions: small beta, near-ties) the panel takes the second pass.
         if (cand) {
+            // PER TILE (round 6): a row's proof fails only against the groups whose bound reaches its best candidate; the second pass walks just the class tiles that
+            // hold such a group for SOME row of the panel (`tmask2`), and its result is merged with the candidates' best — every class of a tile that is not walked
+            // is either a candidate (its exact p is in the merge) or bounded below the best, so the merge is the argmax the full second pass returns, bit for bit.
+            // (Before: one row short of its proof sent the whole panel through all tiles again — 23 of 196 panels on the class-structured ImageNet-sized split of
+            // tests/test_gpu_parity.py::test_full_size_default_routing_C3, i.e. the launch as slow as its slowest panel: 277 instead of 172 us.)
             float* scr = reinterpret_cast<float*>(smem + (p ^ 1) * C::STAGE_BYTES);
-            int* fail = reinterpret_cast<int*>(rowc + 1024);
+            float* umt = scr + 256 * 4;                                        // [half][row][16]: the largest bound of each tile, by half of the groups
+            int* fail = reinterpret_cast<int*>(rowc + 1024);                   // the panel's tile mask
+            float* candb = rowc + 1024 + 16;                                   // [256][2]: the candidates' best (p, class) of a row, for the merge behind the second pass
             const int row = tid & 255, half = tid >> 8, ng = tiles_n * 8;
+            const bool per_tile = tiles_n <= 16;
             const float4_t c4 = *reinterpret_cast<const float4_t*>(rowc + row * 4);
-            float bv = -1.f, umax = 0.f;
+            float bv = -1.f, umax = 0.f, um = 0.f;
             int bi = 0x7fffffff;
             if (tid == 0) *fail = 0;
             __syncthreads();                                                   // the records of every lane are complete (vmcnt(0)) and visible to the workgroup
+            const int g_lo = half * (ng >> 1), g_hi = (half + 1) * (ng >> 1);
 #pragma unroll 2
-            for (int g = half * (ng >> 1); g < (half + 1) * (ng >> 1); ++g) {
+            for (int g = g_lo; g < g_hi; ++g) {
                 // (plain loads: the records were written through this CU's L1 by this workgroup and the barrier above waited for them)
                 const float* rp = rec_wg + ((size_t)g * 256 + row) * 8;
                 const float4_t a = *reinterpret_cast<const float4_t*>(rp);
@@ -265,6 +279,8 @@ __global__ __launch_bounds__(512, 2) void classify_panel_kernel(const half_t* __
                 if (p1 > bv || (p1 == bv && i1 < bi)) { bv = p1; bi = i1; }
                 if (p2 > bv || (p2 == bv && i2 < bi)) { bv = p2; bi = i2; }
                 umax = fmaxf(umax, u);
+                um = fmaxf(um, u);
+                if (per_tile && ((g & 7) == 7 || g + 1 == g_hi)) { umt[(half * 256 + row) * 16 + (g >> 3)] = um; um = 0.f; }     // (a tile's groups are consecutive)
             }
             if (half) { scr[row * 4] = bv; reinterpret_cast<int*>(scr)[row * 4 + 1] = bi; scr[row * 4 + 2] = umax; }
             __syncthreads();
@@ -273,14 +289,27 @@ __global__ __launch_bounds__(512, 2) void classify_panel_kernel(const half_t* __
                 const int oi = reinterpret_cast<const int*>(scr)[row * 4 + 1];
                 if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
                 umax = fmaxf(umax, ou);
-                if (m0 + row < Q && (!(umax < bv) || mode == 2)) *fail = 1;     // (mode 2, tests: every panel takes the second pass)
+                scr[row * 4 + 3] = bv;                                         // the row's best candidate, for the other half's tile test
+                candb[row * 2] = bv;
+                reinterpret_cast<int*>(candb)[row * 2 + 1] = bi;
+                if (m0 + row < Q && !per_tile && (!(umax < bv) || mode == 2)) atomicOr(fail, (int)all_tiles);
             }
             __syncthreads();
-            second_pass = *fail != 0;
+            if (per_tile && m0 + row < Q) {
+                const float bvf = scr[row * 4 + 3];
+                unsigned mk = 0;
+                for (int t = g_lo >> 3; t <= (g_hi - 1) >> 3; ++t)
+                    if (!(umt[(half * 256 + row) * 16 + t] < bvf)) mk |= 1u << t;
+                if (mode == 2) mk = all_tiles;                                  // (mode 2, tests: every panel takes the whole second pass)
+                if (mk) atomicOr(fail, (int)mk);
+            }
+            __syncthreads();
+            tmask2 = (unsigned)__builtin_amdgcn_readfirstlane(*fail);
+            second_pass = tmask2 != 0;
             if (!second_pass && !half && m0 + row < Q) argmax[m0 + row] = bi;
-            if (stats && tid == 0) { atomicAdd(stats, 1); if (second_pass) atomicAdd(stats + 1, 1); }
+            if (stats && tid == 0) { atomicAdd(stats, 1); if (second_pass) { atomicAdd(stats + 1, 1); atomicAdd(stats + 2, __builtin_popcount(tmask2)); } }
             __syncthreads();                                                   // the scratch is a K-tile buffer again; `fail` may be rewritten by the next panel
-            if (second_pass) issue(m0, 0, zpar);                               // the prefetched tile was the next panel's: this panel's first tile again (same buffer, same strip: in order)
+            if (second_pass) issue(m0, __builtin_ctz(tmask2), zpar);           // the prefetched tile was the next panel's: this panel's first second-pass tile (same buffer, same strip: in order)
         }
         // ---- pass 2: p = alpha e_i / S_i + (1 - alpha) e_t / S_t, running (best, class) per row ----
         if (second_pass) {
@@ -288,7 +317,7 @@ __global__ __launch_bounds__(512, 2) void classify_panel_kernel(const half_t* __
             int besti[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { best[k] = -1.f; besti[k] = 0x7fffffff; }
-            walk(std::integral_constant<int, 1>{}, false, [&](int tn, int k, const float (&d)[2][16]) {
+            walk(std::integral_constant<int, 1>{}, false, tmask2, [&](int tn, int k, const float (&d)[2][16]) {
                 const float4_t c4 = *reinterpret_cast<const float4_t*>(rowc + row_of(k) * 4);
                 const int cls0 = tn * (C::BN / 2) + (wn * 128 + 4 * (lane >> 4)) / 2;
 #pragma unroll
@@ -315,6 +344,12 @@ __global__ __launch_bounds__(512, 2) void classify_panel_kernel(const half_t* __
                     const int ix = reinterpret_cast<const int*>(scr)[(tid * 8 + x) * 2 + 1];
                     if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }           // lowest class among equal maxima (main.py:190 on the CPU)
                 }
+                if (cand) {                                                             // the candidates' best: the classes of the tiles this pass did not walk
+                    const float* candb = rowc + 1024 + 16;
+                    const float cv = candb[tid * 2];
+                    const int cx = reinterpret_cast<const int*>(candb)[tid * 2 + 1];
+                    if (cv > bv || (cv == bv && cx < bi)) { bv = cv; bi = cx; }
+                }
                 argmax[m0 + tid] = bi;
             }
             pgemm::lds_barrier();                          // the scratch is a K-tile buffer again
@@ -339,10 +374,10 @@ extern "C" int pclip_classify_panel_passes(int mode) {
     if (mode >= 0) g_panel_passes = mode > 2 ? 0 : mode;
     return before;
 }
-__device__ int g_panel_stats[2];               // panels classified | panels that took the second pass (since the last reset)
-extern "C" int pclip_classify_panel_stats(int* out2, int reset) {
-    int z[2] = {0, 0};
-    if (out2 && hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_panel_stats), sizeof(z)) != hipSuccess) return PCLIP_E_LAUNCH;
+__device__ int g_panel_stats[3];               // panels classified | panels that took a second pass | class tiles those second passes walked (since the last reset)
+extern "C" int pclip_classify_panel_stats(int* out3, int reset) {
+    int z[3] = {0, 0, 0};
+    if (out3 && hipMemcpyFromSymbol(out3, HIP_SYMBOL(g_panel_stats), sizeof(z)) != hipSuccess) return PCLIP_E_LAUNCH;
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_panel_stats), z, sizeof(z)) != hipSuccess) return PCLIP_E_LAUNCH;
     return PCLIP_OK;
 }
@@ -395,7 +430,7 @@ int pclip_classify_panel_launch(const void* q, const void* zi, const void* zt, i
     int cus = pclip_device_cus();
     if (cus <= 0) cus = 256;
     const int npanels = Qp / 256, grid = npanels < cus ? npanels : cus;
-    constexpr int LDS = CP::LDS_BYTES + 8192 + 64;
+    constexpr int LDS = CP::LDS_BYTES + 8192 + 64 + 2048;              // K-tile ring | norm strips + per-row constants | tile mask | the candidates' best per row
     // d2 = max(||q||^2 + ||z||^2 - 2 q.z, 0) by default: without torch.cdist's sqrt -> square round trip (<= 1 fp32 ulp from the two-stage path's distances, whose
     // correctly rounded sqrtf costs twelve VALU instructions per element: 371 vs 250 us on the ImageNet split — the arithmetic this kernel is bound by);
     // PCLIP_CLASSIFY_PANEL_EXACT=1 keeps the round trip (bit-identical distances)

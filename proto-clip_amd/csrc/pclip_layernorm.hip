@@ -131,72 +131,6 @@ __global__ __launch_bounds__(256) void layernorm_pf_kernel(const half_t* __restr
 }
 
 
-// (mean, rstd) of every row: what is left of a LayerNorm whose affine part has been folded into the consuming linear (ln_fold).
-// One wave per row: the values do not depend on how many rows the call carries, and they are the values stats_finalize_kernel
-// derives from the partials a residual GEMM wrote (same association order, stats_chunk).
-template <int NCH>
-__global__ __launch_bounds__(256) void row_stats_kernel(const half_t* __restrict__ x, int ld_x, float eps, float* __restrict__ stats, int R,
-                                                        int D) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
-        const half_t* xr = x + (size_t)row * ld_x;
-        half8_t hv[NCH];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int d = c * 512 + lane * 8;
-            if (d < D) hv[c] = ld_half8(xr + d);
-        }
-        const float2_t ms = row_mean_rstd<NCH>(hv, D, lane, eps);
-        if (lane == 0) *reinterpret_cast<float2_t*>(stats + (size_t)row * 2) = ms;
-    }
-}
-
-// partials [R][D / 64][2] (sum, sum of squares per 64 columns, written by the act-9 epilogues) -> stats [R][2] = (mean, rstd):
-// per 256-column block the tree (g0 + g1) + (g2 + g3), blocks left to right.  One thread per row.
-__global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ partials, int R, int D, float eps,
-                                                             float* __restrict__ stats) {
-    const int row = blockIdx.x * 256 + threadIdx.x;
-    if (row >= R) return;
-    const int ns = D >> 6;
-    const float2_t* p = reinterpret_cast<const float2_t*>(partials) + (size_t)row * ns;
-    float S = 0.f, Q = 0.f;
-    for (int b = 0; b < ns; b += 4) {
-        float2_t g[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) g[k] = b + k < ns ? p[b + k] : float2_t{0.f, 0.f};
-        S += (g[0][0] + g[1][0]) + (g[2][0] + g[3][0]);
-        Q += (g[0][1] + g[1][1]) + (g[2][1] + g[3][1]);
-    }
-    *reinterpret_cast<float2_t*>(stats + (size_t)row * 2) = stats_from_sums(S, Q, D, eps);
-}
-
-// Wf[n, :] = r16(gamma . W[n, :]),  colsum[n] = sum_k Wf[n, k] (of the ROUNDED values: it cancels the mean against exactly the
-// weights the GEMM multiplies),  bfold[n] = sum_k beta[k] W[n, k] + bias[n];  fp32 sums, one wave per output row, fixed order.
-__global__ __launch_bounds__(256) void ln_fold_weights_kernel(const half_t* __restrict__ W, int ldw, int N, int K, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, const half_t* __restrict__ bias,
-                                                              half_t* __restrict__ Wf, float* __restrict__ colsum, float* __restrict__ bfold) {
-    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
-    float cs = 0.f, bs = 0.f;
-    for (int k = lane * 8; k < K; k += 512) {
-        const half8_t w = ld_half8(W + (size_t)n * ldw + k);
-        half8_t o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            o[j] = (half_t)(gamma[k + j] * (float)w[j]);
-            cs += (float)o[j];
-            bs = fmaf(beta[k + j], (float)w[j], bs);
-        }
-        st_half8(Wf + (size_t)n * K + k, o);
-    }
-    cs = wave_sum(cs);
-    bs = wave_sum(bs);
-    if (lane == 0) {
-        colsum[n] = cs;
-        bfold[n] = bs + (bias ? (float)bias[n] : 0.f);
-    }
-}
-
 // Residual add fused into the next LayerNorm (clip/model.py:188-189 followed by ln_2 / the next block's ln_1 /
 // ln_post / ln_final): xs = r16(x + delta) is (optionally) stored back and y = r16(LN(xs)).  Keeping the
 // residual out of the GEMM epilogues lets those run without a single ordinary vector load.
@@ -279,32 +213,6 @@ extern "C" int pclip_layernorm_f16(const void* x, int ld_x, const float* gamma, 
     DISPATCH_NCH(D, (layernorm_kernel<NCH, float, 0><<<row_grid(R), 256, 0, (hipStream_t)stream>>>(
                         (const half_t*)x, ld_x, gamma, beta, eps, (half_t*)y, R, D, nullptr, 0.f, 0.f, 0, nullptr)));
     return pclip_check_launch("layernorm");
-}
-
-extern "C" int pclip_row_stats_f16(const void* x, int ld_x, float eps, float* stats, int R, int D, pclip_stream_t stream) {
-    PCLIP_REQUIRE(x && stats, "pclip_row_stats_f16: null pointer");
-    PCLIP_REQUIRE(R >= 0 && D > 0 && D % 8 == 0 && D <= 4096 && ld_x >= D && ld_x % 8 == 0, "pclip_row_stats_f16: bad R=%d D=%d ld=%d", R, D, ld_x);
-    if (R == 0) return PCLIP_OK;
-    hipStream_t s = (hipStream_t)stream;
-    DISPATCH_NCH(D, (row_stats_kernel<NCH><<<row_grid(R), 256, 0, s>>>((const half_t*)x, ld_x, eps, stats, R, D)));
-    return pclip_check_launch("row_stats_f16");
-}
-
-extern "C" int pclip_row_stats_finalize(const float* partials, int R, int D, float eps, float* stats, pclip_stream_t stream) {
-    PCLIP_REQUIRE(partials && stats, "pclip_row_stats_finalize: null pointer");
-    PCLIP_REQUIRE(R >= 0 && D > 0 && D % 64 == 0, "pclip_row_stats_finalize: bad R=%d D=%d", R, D);
-    if (R == 0) return PCLIP_OK;
-    stats_finalize_kernel<<<ceil_div(R, 256), 256, 0, (hipStream_t)stream>>>(partials, R, D, eps, stats);
-    return pclip_check_launch("row_stats_finalize");
-}
-
-extern "C" int pclip_ln_fold_weights_f16(const void* W, int ldw, int N, int K, const float* gamma, const float* beta, const void* bias,
-                                         void* Wf, float* colsum, float* bfold, pclip_stream_t stream) {
-    PCLIP_REQUIRE(W && gamma && beta && Wf && colsum && bfold, "pclip_ln_fold_weights_f16: null pointer");
-    PCLIP_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && ldw >= K && ldw % 8 == 0, "pclip_ln_fold_weights_f16: bad N=%d K=%d ldw=%d", N, K, ldw);
-    ln_fold_weights_kernel<<<ceil_div(N, 4), 256, 0, (hipStream_t)stream>>>((const half_t*)W, ldw, N, K, gamma, beta, (const half_t*)bias,
-                                                                            (half_t*)Wf, colsum, bfold);
-    return pclip_check_launch("ln_fold_weights_f16");
 }
 
 extern "C" int pclip_add_layernorm_f16(const void* x, const void* delta, int ld, void* x_out, const float* gamma,

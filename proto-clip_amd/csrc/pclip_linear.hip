@@ -22,22 +22,9 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
                                                                      const float* __restrict__ scale,
                                                                      const float* __restrict__ shift,
                                                                      half_t* Cout, int ldc, int tiles_n,
-                                                                     int ntiles, const half_t* residual = nullptr,
-                                                                     const float* __restrict__ rowstats = nullptr,
-                                                                     float* __restrict__ partials = nullptr, int band = 0,
-                                                                     LnPanel lnp = LnPanel{}) {
-    // ACT 10: ACT 6, and the LayerNorm that follows the residual add in a transformer block (clip/model.py:188-189: ln_2 behind `x + attn`, the next block's ln_1
-    // behind `x + mlp`) WITHOUT a pass of its own over x: a row panel (BM rows x N) is complete when its N / BN tiles — computed by as many workgroups at about the same
-    // time, which is what lets them share the A rows in L2 — have all been stored; every workgroup counts its finished tiles into the panel's counter (device-scope
-    // atomic), and the one whose increment completes the panel normalises the panel's rows: it reads them back (device-scope loads; they are a few tens of microseconds
-    // old and still on the chip) and writes y with ordinary streaming stores that drain while the launch multiplies on.  The separate pass was bound by HBM (620 MB at
-    // 6 TB/s = 102 us); here the 310 MB of reads never reach HBM and the writes overlap the K-loops.  Row arithmetic = ln_row_pf, the pass's own: same bits.
-    // No workgroup ever WAITS for another (nothing spins), so there is no forward-progress assumption.  A tile is counted two tiles late — after the K-loop of the
-    // NEXT tile, whose last iteration drained the vector-memory counter of every wave (wait_vm<0> + barrier), i.e. without a wait of its own for the stores — and the
-    // returned count is looked at another tile later; the last two tiles of a workgroup are settled behind the loop.
+                                                                     int ntiles, const half_t* residual = nullptr, int band = 0) {
     // ACT 5: relu(r16(r16(r16(acc) * scale + shift) + residual)) — bn3 + `out += identity` + ReLU of a bottleneck (clip/model.py:49-52)
     // in the epilogue of its conv3 GEMM; the residual rows are read row-major in the coalesced store pass.
-    // ACT 9: ACT 6 + the row-statistics partials of the updated rows (stats_chunk / stats_butterfly) into `partials` [M][N/64][2]
     // ACT 6: r16(residual + r16(acc + bias)) — `x = x + attn(..)` / `x = x + mlp(..)` of a transformer block (clip/model.py:188-189)
     // in the epilogue of out_proj / c_proj; Cout may BE residual (the residual stream is updated in place: every 16-byte chunk is
     // read and then written by the same thread)
@@ -45,18 +32,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     constexpr bool M16 = true;                                               // 16x16x32 MFMAs (accumulator layout of pgemm::mainloop_sr)
     half_t* bias_lds = reinterpret_cast<half_t*>(smem + C::LDS_BYTES);       // [2][BN] fp16
     float* affine_lds = reinterpret_cast<float*>(smem + C::LDS_BYTES);       // ACT >= 2: [2][ scale BN | shift BN ] fp32
-    constexpr bool LNF = ACT == 7 || ACT == 8;                                // LayerNorm folded into this linear (ln_fold)
-    constexpr bool AFFINE = ACT == 2 || ACT == 3 || ACT == 5 || LNF;          // LNF: the strips hold colsum(Wf) | folded bias
-    constexpr int STRIP_BYTES = AFFINE ? 2 * 2 * C::BN * 4 : 2 * C::BN * 2;   // then 256 bytes of scrap for the L2 prefetch
-    constexpr int NSTAT = LNF ? (C::BM * 8 + 1023) / 1024 : 0;                // LDS-DMA pieces of a tile's (mean, rstd) rows
-    float* stats_lds = reinterpret_cast<float*>(smem + C::LDS_BYTES + STRIP_BYTES + 256);   // LNF: [2][BM][2] fp32
-    constexpr bool LNP = ACT == 10;
-    // LNP: [2][2] panels to normalise behind this tile's epilogue (-1: none) | thread 0's bookkeeping: [8] owned panels not yet complete, their number, the one whose
-    // count is on its way back | [12] + number: the panels settled behind the loop
-    int* lnp_flag = reinterpret_cast<int*>(smem + C::LDS_BYTES + STRIP_BYTES + 256);
-    int* lnp_own = lnp_flag + 4;
-    float* lnp_gb = reinterpret_cast<float*>(smem + C::LDS_BYTES + STRIP_BYTES + 256 + 128);   // LNP: [gamma | beta][plane][2 * 256] fp32 for the whole launch (layernorm_pf_kernel's layout)
-    constexpr int LNP_OQ = 8, LNP_NOWN = 8, LNP_CHK = 9, LNP_LIST = 10, LNP_NL = 22, LNP_ORPH = 1 << 16;
+    constexpr bool AFFINE = ACT == 2 || ACT == 3 || ACT == 5;
     const int G = gridDim.x;
     int tile = pgemm::xcd_remap(blockIdx.x, G);
     if (tile >= ntiles) return;
@@ -97,27 +73,8 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(shift + tn * C::BN + lane * 4), (pgemm::lds_ptr_t)(affine_lds + par * 2 * C::BN + C::BN), 16, 0, 0);
         }
     };
-    // LNF: the (mean, rstd) pairs of the tile's BM rows, one tile ahead like the strips; rowstats is allocated in whole 256-row
-    // blocks, so the last tile reads (never used) padding instead of running off the end
-    auto copy_stats = [&](int t, int par) {
-        int tm, tn_;
-        decomp(t, tm, tn_);
-#pragma unroll
-        for (int i = 0; i < NSTAT; ++i)
-            if (NSTAT * 128 == C::BM || lane < (C::BM - i * 128) / 2)
-                __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(rowstats + ((size_t)tm * C::BM + i * 128 + lane * 2) * 2),
-                                                 (pgemm::lds_ptr_t)(stats_lds + par * C::BM * 2 + i * 256), 16, 0, 0);
-    };
-    if constexpr (LNP) {
-        for (int i = tid; i < 2 * 512; i += C::NTHREADS) {
-            const int pos = (i >> 9) * 256 + ((i & 511) >> 3) * 4 + (i & 3), plane = (i >> 2) & 1;
-            lnp_gb[plane * 2 * 256 + pos] = i < N ? lnp.gamma[i] : 0.f;
-            lnp_gb[(2 + plane) * 2 * 256 + pos] = i < N ? lnp.beta[i] : 0.f;
-        }
-    }
     if (HAS_BIAS || AFFINE) {
         if (AFFINE) copy_affine(tile, 0); else copy_bias(tile, 0);
-        if (LNF) copy_stats(tile, 0);
         pgemm::wait_vm<0>();
         pgemm::lds_barrier();
     }
@@ -127,137 +84,10 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         tp.prepare(A, lda, B, ldb, M, N, tm * C::BM, tn * C::BN, wave, lane);
         tp.stage(0, smem + p * C::STAGE_BYTES, wave);
     }
-    constexpr int PST = ACT == 9 ? 1 : 0;                                     // act 9: one store of statistics partials per pass
     // vector-memory operations a wave issues between a tile's K-tile 0 pieces and the first wait of its K-loop: the previous tile's stores + the strip copies
-    constexpr int YOUNGER = C::NH * C::NPASS * (1 + PST) + (AFFINE ? 2 : (HAS_BIAS ? 1 : 0)) + NSTAT;
+    constexpr int YOUNGER = C::NH * C::NPASS + (AFFINE ? 2 : (HAS_BIAS ? 1 : 0));
     bool prev_full = false;
     int parity = 0;
-    // LNP: `stored` = panel of the tile whose stores are in flight (not yet counted), `counted` = panel of the tile whose count is on its way back in `ticket` (thread 0)
-    int stored = -1, counted = -1, ticket = 0, chkv = 0;
-    if (LNP && tid == 0) { lnp_own[LNP_NOWN] = 0; lnp_own[LNP_CHK] = -1; }
-    // WHO normalises a complete panel.  "The workgroup whose count completes it" piles the work up: a workgroup that has normalised one panel is late from then on, so
-    // it is the last to arrive at its following panels too and normalises those as well (measured: 0 - 7 panels per workgroup, the launch as slow as the busiest).  So
-    // every panel has an OWNER — the workgroup that computes one designated tile of it (below), a third of everybody's tiles at N = 768 — which looks at
-    // the counter of its oldest unfinished panel once per tile (a device-scope load, requested behind one K-loop and read behind the next) and normalises the panel
-    // once it reads the full count.  Still nobody waits: behind its last tile an owner adds LNP_ORPH to the counters of the panels it still holds — complete ones
-    // it normalises on the spot, incomplete ones are now ORPHANS, normalised by the workgroup whose count completes them (it sees the flag in the value its
-    // atomic returns).  The atomics on one counter are totally ordered, so exactly one of the two happens.
-    // (Which tile: in round r — r = (LAST tile of the panel) / G — the column tile (r (G % tiles_n + 1)) % tiles_n.  In the ascending order a workgroup's column
-    // tile advances by G % tiles_n per round, so it owns a panel exactly every tiles_n-th round: 3 of its 9 tiles at N = 768, nobody more.  With the round of the
-    // panel's FIRST tile the two workgroups at a round's seam owned 7 and 0.)
-    auto owner_tile = [&](int tm, int tn) { return tn == (((tm * tiles_n + tiles_n - 1) / G) * (G % tiles_n + 1)) % tiles_n; };
-    // rows of panel lp (complete: every tile of it has been counted) -> lnp.y.  No barrier: a wave reads x, the launch's gamma / beta copy in LDS, and writes y.
-    auto ln_panel = [&](int lp) {
-        if constexpr (LNP) {
-            constexpr int NCH = 2;                                      // 512 <= N <= 1024, N % 128 == 0 (launcher)
-            const float* gb = lnp_gb;
-            int lt = tid;                                             // opaque copy: the constants below are formed here, not hoisted across the K-loop (they spilled)
-#if defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("" : "+v"(lt));
-#endif
-            const int ln = lt & 63;
-            const int r0 = lp * C::BM, rows = M - r0 < C::BM ? M - r0 : C::BM;
-            // FOUR rows per wave instruction: the 16 lanes of a DPP row own one row of x, lane p of them the columns of ln_row_pf's lanes p, p + 16, p + 32, p + 48
-            // ("slots" 0 - 3: 8 columns of the first 512 each, 8 more of the columns beyond for the slots those reach) — every lane is busy at N = 768 (a quarter
-            // idles in the one-row-per-wave form), the per-row scalars (two divisions, a square root) and the reductions cost a quarter, and a reduction is two
-            // in-lane levels + four DPP levels.  SAME BITS as ln_row_pf: a slot's partial sums run over its columns in ln_row_pf's order, and
-            // (P0 + P2) + (P1 + P3) followed by row16_sum_x is wave_sum's tree (levels ^ 32, ^ 16 pair slots, ^ 8 ... ^ 1 pair lanes of the row).
-            // Rows and columns beyond the panel / N fail the descriptors' bounds checks (loads answer zeros, stores are dropped): every quad issues the SAME eight
-            // loads and eight stores, so the waits are counted.  Loads: inline assembly, device scope (sc1) — issued through builtins hipcc serialised them with
-            // vmcnt(0); their destination registers are not touched before the counted wait and the pin behind it.
-            uint4_t rx;
-            pgemm::rsrc_t ry;
-#if defined(__HIP_DEVICE_COMPILE__)
-            {
-                const uint64_t ax = (uint64_t)(Cout + (size_t)r0 * ldc), ay = (uint64_t)(lnp.y + (size_t)r0 * N);
-                rx = uint4_t{(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ax), (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ax >> 32)) & 0xffffu,
-                             (uint32_t)__builtin_amdgcn_readfirstlane(rows * ldc * 2), 0x00020000u};
-                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)ay), hi = __builtin_amdgcn_readfirstlane((uint32_t)(ay >> 32));
-                ry = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(rows * N * 2), 0x00020000);
-            }
-#endif
-            constexpr int NIT = C::BM / (C::NWAVES * 4), NOP = 8;       // quads per wave; vector-memory operations of a quad (loads, and stores)
-            static_assert(C::BM % (C::NWAVES * 8) == 0, "quads are walked in pairs (two register buffers)");
-            const int ns1 = (N - 512) >> 7;                           // slots that reach beyond column 512 (uniform): 2 at N = 768
-            const int p16 = ln & 15, g4 = ln >> 4;
-            const float fN = (float)N;
-            half8_t bufa[8], bufb[8];
-            auto load = [&](half8_t (&h)[8], int it) {
-                const int r = (it * C::NWAVES + wave) * 4 + g4;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int d = (q >> 2) * 512 + ((q & 3) * 16 + p16) * 8;
-                    const int off = d < N ? (r * ldc + d) * 2 : 0x7ffffff0;
-#if defined(__HIP_DEVICE_COMPILE__)
-                    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen sc1" : "=v"(h[q]) : "v"(off), "s"(rx));
-#endif
-                }
-            };
-            auto quad = [&](half8_t (&h)[8], int it) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-                for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(h[q]));                 // the values exist from here on (behind the wait)
-#endif
-                const int r = (it * C::NWAVES + wave) * 4 + g4;
-                float P[4];
-#pragma unroll
-                for (int sl = 0; sl < 4; ++sl) {
-                    float a = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) a += (float)h[sl][j];
-                    if (sl < ns1) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) a += (float)h[4 + sl][j];
-                    }
-                    P[sl] = a;
-                }
-                const float mean = row16_sum_x((P[0] + P[2]) + (P[1] + P[3])) / fN;
-                float t[8][8];
-#pragma unroll
-                for (int sl = 0; sl < 4; ++sl) {
-                    float a = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { t[sl][j] = (float)h[sl][j] - mean; a = ln_sq_acc(t[sl][j], a); }
-                    if (sl < ns1) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) { t[4 + sl][j] = (float)h[4 + sl][j] - mean; a = ln_sq_acc(t[4 + sl][j], a); }
-                    }
-                    P[sl] = a;
-                }
-                const float rstd = 1.f / sqrtf(row16_sum_x((P[0] + P[2]) + (P[1] + P[3])) / fN + lnp.eps);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int sl = q & 3, c = q >> 2, d = c * 512 + (sl * 16 + p16) * 8;
-                    half8_t o;
-                    if (c == 0 || sl < ns1) {
-                        const float* gp = gb + c * 256 + (sl * 16 + p16) * 4;
-                        const float4_t ga = *reinterpret_cast<const float4_t*>(gp), gc = *reinterpret_cast<const float4_t*>(gp + NCH * 256);
-                        const float4_t ba = *reinterpret_cast<const float4_t*>(gp + 2 * NCH * 256), bc = *reinterpret_cast<const float4_t*>(gp + 3 * NCH * 256);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            o[j] = (half_t)r16(ln_affine_dev(t[q][j], rstd, ga[j], ba[j]));
-                            o[j + 4] = (half_t)r16(ln_affine_dev(t[q][j + 4], rstd, gc[j], bc[j]));
-                        }
-                    }
-#if defined(__HIP_DEVICE_COMPILE__)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o), ry, d < N ? (r * N + d) * 2 : 0x7ffffff0, 0, PCLIP_NT_STORE ? 2 : 0);
-#endif
-                }
-            };
-            // issue order per wave: L0 L1 | quad 0, S0, L2 | quad 1, S1, L3 | ...: counted waits — first quad vmcnt(NOP) (only L1 is younger), middle quads
-            // vmcnt(2 NOP) (S(b-1) and L(b+1)), last quad vmcnt(NOP) (S(b-1))
-            load(bufa, 0);
-#pragma unroll 1
-            for (int it = 0; it < NIT; it += 2) {
-                load(bufb, it + 1);
-                if (it == 0) pgemm::wait_vm<NOP>(); else pgemm::wait_vm<2 * NOP>();
-                quad(bufa, it);
-                if (it + 2 < NIT) { load(bufa, it + 2); pgemm::wait_vm<2 * NOP>(); } else pgemm::wait_vm<NOP>();
-                quad(bufb, it + 1);
-            }
-            if (lt == 0) lnp.cnt[lp] = 0;                            // the counter is this workgroup's now: zero for the next launch
-        }
-    };
     for (; tile < ntiles; tile += G, parity ^= 1) {
         int tile_m, tile_n;
         decomp(tile, tile_m, tile_n);
@@ -284,37 +114,11 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             copy_bias(tile + G < ntiles ? tile + G : tile, parity ^ 1);
         }
         if (AFFINE) copy_affine(tile + G < ntiles ? tile + G : tile, parity ^ 1);
-        if (LNF) copy_stats(tile + G < ntiles ? tile + G : tile, parity ^ 1);
         // (Measured and rejected, profiles/r03_ab_rejected.txt: pulling the residual tile's 1024 lines into L2 during the K-loop with one
         // 4-byte LDS-DMA per line — out_proj 301 -> 341 us, c_proj 854 -> 879 us: 1024 more requests per tile in the queue the operand
         // DMAs wait in.)
         const int next = tile + G;
         pgemm::mainloop_sr<C, YOUNGER, !HAS_BIAS, TP>(tp, K / pgemm::BK, smem, acc, p, prev_full, wave, lane);
-        if constexpr (LNP) {
-            // K >= 2 K-tiles (launcher): the last iteration began with wait_vm<0> + barrier — every store of the previous tile, from every wave, has completed
-            if (tid == 0) {
-                // the count of tile i - 2 is back: did it complete a panel nobody owns any more?
-                lnp_flag[2 * parity] = counted >= 0 && (ticket & 0xffff) == tiles_n - 1 && (ticket & LNP_ORPH) ? counted : -1;
-                int no = lnp_own[LNP_NOWN], ck = lnp_own[LNP_CHK], f1 = -1;
-                if (ck >= 0 && (chkv & 0xffff) == tiles_n) {          // my oldest panel is complete (it cannot be an orphan: only I could have made it one)
-                    f1 = ck;
-                    for (int k = 0; k + 1 < no; ++k) lnp_own[k] = lnp_own[k + 1];
-                    --no;
-                }
-                lnp_flag[2 * parity + 1] = f1;
-                if (owner_tile(tile_m, tile_n)) {
-                    if (no < LNP_OQ) lnp_own[no++] = tile_m;
-                    else __hip_atomic_fetch_add(lnp.cnt + tile_m, LNP_ORPH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (list full: this tile is not counted yet, so the panel cannot be complete)
-                }
-                lnp_own[LNP_NOWN] = no;
-                if (stored >= 0) ticket = __hip_atomic_fetch_add(lnp.cnt + stored, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ck = no > 0 ? lnp_own[0] : -1;
-                if (ck >= 0) chkv = __hip_atomic_load(lnp.cnt + ck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                lnp_own[LNP_CHK] = ck;
-            }
-            counted = stored;
-            stored = tile_m;
-        }
         if (next < ntiles) {                                  // buffer p is free: prefetch the next tile's K-tile 0
             int tm, tn;
             decomp(next, tm, tn);
@@ -327,42 +131,9 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         asm volatile("" : "+v"(etid));
 #endif
         const int col = n0 + 8 * (etid % C::CPR);
-        // LNF: the lane's column strips (colsum | folded bias for its 4 columns of every (j, g & 1)) and row statistics ((mean, rstd)
-        // of its row in every (i, g >> 1)) are read from LDS ONCE per tile into registers (the K-loop's fragment registers are free
-        // here): read inside `pre` they were 96 LDS reads per lane and slab, re-issued behind every staging write, and the epilogue
-        // cost as much as the LayerNorm pass it replaces.
-        float4_t lcs[LNF ? C::TN : 1][2], lbf[LNF ? C::TN : 1][2];
-        float2_t lms[LNF ? C::TM : 1][2];
-        if (LNF) {
-            const int cq = 4 * (lane >> 4), rq = lane & 15;
-#pragma unroll
-            for (int j = 0; j < C::TN; ++j)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const float* st = affine_lds + parity * 2 * C::BN + wn * (C::BN / C::WN) + j * 32 + b * 16 + cq;
-                    lcs[j][b] = *reinterpret_cast<const float4_t*>(st);
-                    lbf[j][b] = *reinterpret_cast<const float4_t*>(st + C::BN);
-                }
-#pragma unroll
-            for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-                    lms[i][a] = *reinterpret_cast<const float2_t*>(stats_lds + (parity * C::BM + (wave / C::WN) * (C::BM / C::WM) + i * 32 + a * 16 + rq) * 2);
-        }
         auto pre = [&](int i, int j, int coff, float4_t v, int rl, int g) {
             if (ACT == 1) return quick_gelu16x4(v);
             half4_t h;
-            if (LNF) {
-                const float4_t cs = lcs[j][g & 1], bf = lbf[j][g & 1];
-                const float2_t ms = lms[i][g >> 1];
-                float4_t y;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = ln_fold(v[e], ms[0], ms[1], cs[e], bf[e]);
-                if (ACT == 8) return quick_gelu16x4(y);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = (half_t)y[e];
-                return h;
-            }
             if (AFFINE) {
                 const float* st = affine_lds + parity * 2 * C::BN + wn * (C::BN / C::WN) + j * 32 + coff;
                 const float4_t sc = *reinterpret_cast<const float4_t*>(st), sh = *reinterpret_cast<const float4_t*>(st + C::BN);
@@ -382,10 +153,10 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
         // the slab is staged (they fly during the LDS write pass) — Cout may alias residual (in-place residual stream), so the
         // compiler cannot hoist a later pass's load above an earlier pass's store by itself: load -> wait -> store per pass was
         // 16 dependent round trips per tile.
-        constexpr bool RES = ACT == 5 || ACT == 6 || ACT == 9 || ACT == 10;
+        constexpr bool RES = ACT == 5 || ACT == 6;
         // (measured, profiles/r03_ab_epilogue_pipe.txt: c_fc + QuickGELU 1001 -> 972 us; the bias-only and residual epilogues do not profit — their phases
         // are bound by the LDS write rate / the stores' address path / the residual loads' latency one after the other either way — and keep epilogue_f16)
-        constexpr bool PIPE = PCLIP_EPI_PIPE && (ACT == 1 || ACT == 8 || PCLIP_EPI_PIPE == 2) && !LNP && C::BM == 256 && C::BN == 256 && C::WM == 2 && C::WN == 4;
+        constexpr bool PIPE = PCLIP_EPI_PIPE && (ACT == 1 || PCLIP_EPI_PIPE == 2) && C::BM == 256 && C::BN == 256 && C::WM == 2 && C::WN == 4;
         half8_t rr[RES ? C::NPASS : 1];
         // PIPE: slab k = 32-row block k of both wave rows, four passes of 16 rows; its residual chunks go to rr[(k & 1) * 4 + ps], requested one interval ahead
         auto ahead = [&](int k) {
@@ -413,16 +184,6 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             }
             return h;
         };
-        // act 9: (sum, sum of squares) of the row segment this tile covers, from the values just stored; the CPR lanes of a row are
-        // consecutive, lane c == 0 of each writes the segment's slots (every lane takes part in the butterfly: `valid` only
-        // predicates the store)
-        auto put_partials = [&](int r, int c, const half8_t& hv, bool valid) {
-            float ps, pq;
-            stats_chunk(hv, ps, pq);
-            stats_butterfly<8>(ps, pq);                        // the 8 lanes of a 64-column group
-            if (valid && (c & 7) == 0)
-                *reinterpret_cast<float2_t*>(partials + ((size_t)(m0 + r) * (N >> 6) + (n0 >> 6) + (c >> 3)) * 2) = float2_t{ps, pq};
-        };
         if constexpr (PIPE) {
             static_assert(C::NPASS == 8, "rr[pass % NPASS] pairs slab parity and pass");
             if (full)
@@ -430,14 +191,12 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
                     const size_t o = (size_t)(m0 + r) * ldc + col;
                     if (RES) h = add_res(pass, h);
                     st_out(Cout + o, h);
-                    if (ACT == 9) put_partials(r, c, h, true);
                 });
             else
                 pgemm::epilogue_pipe<C>(acc, stg, ahead, pre, [&](int r, int c, int pass, half8_t h) {
                     const size_t o = (size_t)(m0 + r) * ldc + col;
                     if (RES) h = add_res(pass, h);
                     if (m0 + r < M) st_out(Cout + o, h);
-                    if (ACT == 9) put_partials(r, c, h, m0 + r < M);
                 });
             prev_full = full;
             continue;
@@ -446,45 +205,15 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             pgemm::epilogue_f16<C, M16>(acc, stg, slab, pre, [&](int r, int c, int pass, half8_t h) {
                 const size_t o = (size_t)(m0 + r) * ldc + col;
                 if (RES) h = add_res(pass, h);
-                if (LNP) st_out_dev(Cout + o, h); else st_out(Cout + o, h);
-                if (ACT == 9) put_partials(r, c, h, true);
+                st_out(Cout + o, h);
             });
         else
             pgemm::epilogue_f16<C, M16>(acc, stg, slab, pre, [&](int r, int c, int pass, half8_t h) {
                 const size_t o = (size_t)(m0 + r) * ldc + col;
                 if (RES) h = add_res(pass, h);
-                if (m0 + r < M) { if (LNP) st_out_dev(Cout + o, h); else st_out(Cout + o, h); }
-                if (ACT == 9) put_partials(r, c, h, m0 + r < M);
+                if (m0 + r < M) st_out(Cout + o, h);
             });
         prev_full = full;
-        if constexpr (LNP) {
-#pragma unroll 1
-            for (int k = 0; k < 2; ++k) {
-                const int lp = __builtin_amdgcn_readfirstlane(lnp_flag[2 * parity + k]);       // written before this epilogue's barriers
-                if (lp >= 0) ln_panel(lp);
-            }
-        }
-    }
-    if constexpr (LNP) {
-        // behind the loop: the last tile's stores, then both outstanding counts
-        pgemm::wait_vm<0>();
-        __syncthreads();
-        if (tid == 0) {
-            int* list = lnp_own + LNP_LIST;
-            int nl = 0;
-            auto mine = [&](int t) { return (t & 0xffff) == tiles_n - 1 && (t & LNP_ORPH); };
-            if (counted >= 0 && mine(ticket)) list[nl++] = counted;
-            if (stored >= 0 && mine(__hip_atomic_fetch_add(lnp.cnt + stored, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) list[nl++] = stored;
-            // the panels this workgroup still owns: complete -> normalised here; incomplete -> orphans from now on
-            const int no = lnp_own[LNP_NOWN];
-            for (int k = 0; k < no; ++k)
-                if ((__hip_atomic_fetch_add(lnp.cnt + lnp_own[k], LNP_ORPH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffff) == tiles_n) list[nl++] = lnp_own[k];
-            lnp_own[LNP_NL] = nl;
-        }
-        __syncthreads();
-        const int nl = __builtin_amdgcn_readfirstlane(lnp_own[LNP_NL]);
-#pragma unroll 1
-        for (int k = 0; k < nl; ++k) ln_panel(__builtin_amdgcn_readfirstlane(lnp_own[LNP_LIST + k]));
     }
 }
 
@@ -622,11 +351,12 @@ using CfgSmall = pgemm::CfgSmall;
 
 // Tile-order switches (PCLIP_GEMM_BAND, PCLIP_GEMM_REV): read from the environment ONCE; only under PCLIP_GEMM_CFG_LIVE (the A/B tools flip
 // them between calls of one process) are they re-read per launch — no getenv on the product's launch path.
-struct TileOrder { int band, rev; };
+struct TileOrder { int band, rev, band_n; };      // band: launches with >= 8 column tiles (c_fc); band_n: narrower ones (in_proj: 9 -> 8 counts as wide; out_proj / c_proj: 3)
 static TileOrder read_tile_order() {
     const char* b = getenv("PCLIP_GEMM_BAND");
     const char* r = getenv("PCLIP_GEMM_REV");
-    return TileOrder{b ? atoi(b) : 0, r ? atoi(r) : 2};
+    const char* bn = getenv("PCLIP_GEMM_BAND_N");
+    return TileOrder{b ? atoi(b) : 0, r ? atoi(r) : 2, bn ? atoi(bn) : 0};
 }
 static const TileOrder& tile_order() {
     static const bool live = getenv("PCLIP_GEMM_CFG_LIVE") != nullptr;
@@ -639,9 +369,7 @@ template <class C, bool HAS_BIAS, int ACT>
 static int launch_fast2(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const LinearEpi& epi,
                         int slots, hipStream_t s) {
     static DevOnce attr;
-    constexpr bool LNF = ACT == 7 || ACT == 8;
-    constexpr int LDS = C::LDS_BYTES + ((ACT == 2 || ACT == 3 || ACT == 5 || LNF) ? 2 * 2 * C::BN * 4 : 2 * C::BN * 2) + 256 +
-                        (LNF ? 2 * C::BM * 8 : 0) + (ACT == 10 ? 128 + 8192 : 0);   // K-tile ring + double-buffered bias / affine strips + prefetch scrap + (mean, rstd) rows | panel flags
+    constexpr int LDS = C::LDS_BYTES + ((ACT == 2 || ACT == 3 || ACT == 5) ? 2 * 2 * C::BN * 4 : 2 * C::BN * 2) + 256;   // K-tile ring + double-buffered bias / affine strips + prefetch scrap
     if (!attr.done()) {
         if (hipFuncSetAttribute((const void*)linear_fast_kernel<C, HAS_BIAS, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS) != hipSuccess) {
@@ -659,12 +387,10 @@ static int launch_fast2(const void* A, int lda, const void* B, int ldb, int M, i
     // rows to be evicted, its low rows fresh for the ascending pass behind it).  Same bits (tile order only); bench +0.4 % (profiles/r03_bench_rev.txt).  Default 2.
     const int rev_mode = order.rev;
     // 1: every launch descending; 2: only the launches that read a LayerNorm / attention output (K <= 1024: in_proj, c_fc, out_proj), c_proj ascending behind the descending c_fc
-    // act 10 writes the LayerNorm output its consumer reads next (descending): ascending here, whatever it reads itself (PCLIP_LNP_REV=1: as act 6)
-    static const bool lnp_rev = getenv("PCLIP_LNP_REV") && getenv("PCLIP_LNP_REV")[0] == '1';
-    const bool rev = (rev_mode == 1 || (rev_mode == 2 && K <= 1024)) && (ACT != 10 || lnp_rev);
+    const bool rev = rev_mode == 1 || (rev_mode == 2 && K <= 1024);
     linear_fast_kernel<C, HAS_BIAS, ACT><<<grid, C::NTHREADS, LDS, s>>>(
         (const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi.bias, epi.scale, epi.shift, epi.C, epi.ldc, tiles_n, ntiles, epi.residual,
-        epi.rowstats, epi.partials, rev ? -1 : (tiles_n >= 8 ? band : 0), LnPanel{epi.ln_gamma, epi.ln_beta, epi.ln_y, epi.ln_cnt, epi.ln_eps});
+        rev ? -1 : (tiles_n >= 8 ? band : 0));
     return pclip_check_launch("gemm_f16");
 }
 
@@ -675,14 +401,6 @@ static int launch_fast(const void* A, int lda, const void* B, int ldb, int M, in
     if (epi.act == 3) return launch_fast2<C, false, 3>(A, lda, B, ldb, M, N, K, epi, slots, s);
     if (epi.act == 5) return launch_fast2<C, false, 5>(A, lda, B, ldb, M, N, K, epi, slots, s);
     if (epi.act == 6) return launch_fast2<C, true, 6>(A, lda, B, ldb, M, N, K, epi, slots, s);
-    if (epi.act == 9) return launch_fast2<C, true, 9>(A, lda, B, ldb, M, N, K, epi, slots, s);
-    if (epi.act == 10) {
-        // instantiated for the two tiles the N <= 1024 residual GEMMs of a tower run on (256 x 256 rounds + 128 x 128 tail); gemm_dispatch sends every other choice the two-launch way
-        if constexpr (std::is_same_v<C, CfgBig> || std::is_same_v<C, CfgSmall>) return launch_fast2<C, true, 10>(A, lda, B, ldb, M, N, K, epi, slots, s);
-        else { pclip_set_error("pclip_gemm_res_ln_f16: no fused form for this tile"); return PCLIP_E_INVALID; }
-    }
-    if (epi.act == 7) return launch_fast2<C, false, 7>(A, lda, B, ldb, M, N, K, epi, slots, s);
-    if (epi.act == 8) return launch_fast2<C, false, 8>(A, lda, B, ldb, M, N, K, epi, slots, s);
     if (epi.bias) {
         if (epi.act == 1) return launch_fast2<C, true, 1>(A, lda, B, ldb, M, N, K, epi, slots, s);
         return launch_fast2<C, true, 0>(A, lda, B, ldb, M, N, K, epi, slots, s);
@@ -716,9 +434,8 @@ constexpr int kNumCfgs = 5;                  // configurations the cost model ch
 constexpr TileCfg kTileCfgs[kNumCfgs] = {{128, 128, 2, 0.85}, {256, 128, 1, 0.85}, {256, 256, 1, 1.0}, {256, 64, 1, 0.6}, {256, 32, 2, 0.4}};
 constexpr double kLaunchCost = 0.5;          // extra launch of a split, in the same units
 
-thread_local int g_min_bn = 0;               // act 9 (statistics partials per 64 columns): tiles narrower than 64 columns are excluded
 inline double tile_cost(const TileCfg& c, long M, int N, int cus) {
-    if (N % c.bn || c.bn < g_min_bn) return 1e30;
+    if (N % c.bn) return 1e30;
     const long slots = (long)c.wg_per_cu * cus, nt = ((M + c.bm - 1) / c.bm) * (N / c.bn);
     // two workgroups per CU share its matrix pipe — unless the launch has no more tiles than CUs: then every workgroup has a CU to itself
     // (the 60-tile tail of the N = 768 GEMMs as 240 tiles of 128 x 128: 10.6 / 28.8 us against 11.7 / 33.1 us as 256 x 64, K = 768 / 3072)
@@ -744,34 +461,19 @@ int launch_small_one(const half_t* A, int lda, const half_t* B, int ldb, int M, 
 // four-wave 256 x 256 tile with the asm K-loop (pclip_gemm4w.hip)
 bool pclip_gemm4w_supports(int M, int N, int K, int lda, int ldb, int ldc, const void* C, const void* bias, const void* residual, int act);
 int pclip_gemm4w_launch(const half_t* A, int lda, const half_t* B, int ldb, int M, int N, int K, const half_t* bias, half_t* C, int ldc, int act,
-                        const half_t* residual, int slots, int rev, hipStream_t s);
+                        const half_t* residual, int slots, int rev, int band, hipStream_t s);
 namespace {
 int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int N, int K, LinearEpi epi, int cus, int forced,
                   bool may_split, hipStream_t s) {
-    struct MinBn { int old; MinBn(int v) : old(g_min_bn) { g_min_bn = v; } ~MinBn() { g_min_bn = old; } } min_bn(epi.act == 9 ? 64 : 0);
-    const bool aligned = (!epi.residual || ((epi.act == 5 || epi.act == 6 || epi.act == 9 || epi.act == 10) && ((uintptr_t)epi.residual & 15) == 0)) && epi.ldc % 8 == 0 && ((uintptr_t)epi.C & 15) == 0 &&
+    const bool aligned = (!epi.residual || ((epi.act == 5 || epi.act == 6) && ((uintptr_t)epi.residual & 15) == 0)) && epi.ldc % 8 == 0 && ((uintptr_t)epi.C & 15) == 0 &&
                          (!epi.bias || ((uintptr_t)epi.bias & 15) == 0);
     static const bool small_on = !(getenv("PCLIP_GEMM_SMALL") && getenv("PCLIP_GEMM_SMALL")[0] == '0');
-    // act 10 where the panel LayerNorm has no fused form (ring / generic / other tiles, a single K-tile, N not 512 ... 1024 in steps of 128, 32-bit panel offsets): the residual GEMM, then the
-    // LayerNorm pass over the same rows — the same bits either way (ln_row_pf)
-    auto two_launches = [&](int forced_, bool may_split_) {
-        LinearEpi e6 = epi;
-        e6.act = 6;
-        const int rc = gemm_dispatch(A, lda, B, ldb, M, N, K, e6, cus, forced_, may_split_, s);
-        if (rc != PCLIP_OK) return rc;
-        return pclip_layernorm_f16(epi.C, epi.ldc, epi.ln_gamma, epi.ln_beta, epi.ln_eps, epi.ln_y, M, N, (pclip_stream_t)s);
-    };
-    if (epi.act == 10 && (!aligned || !epi.ln_cnt || K < 2 * pgemm::BK || N < 512 || N > 1024 || N % 128 || (long)pgemm::Cfg<256, 256, 2, 4>::BM * epi.ldc * 2 >= 0x7fffffffL ||
-                          (forced == -1 && small_on && small_applies(M, N, cus))))
-        return two_launches(forced, may_split);
-    if (aligned && forced == -1 && small_on && (epi.act <= 1 || epi.act == 6 || epi.act == 9 || (((uintptr_t)epi.scale | (uintptr_t)epi.shift) & 15) == 0) && small_applies(M, N, cus))
+    if (aligned && forced == -1 && small_on && (epi.act <= 1 || epi.act == 6 || (((uintptr_t)epi.scale | (uintptr_t)epi.shift) & 15) == 0) && small_applies(M, N, cus))
         return launch_small_one(A, lda, B, ldb, M, N, K, epi, s);
     double cost = 1e30;
     int pick = aligned ? best_cfg(M, N, cus, &cost) : -1;
     if (forced == -2) { may_split = false; pick = -1; }        // generic kernel
     if (epi.act == 5 && pick < 0) { pclip_set_error("pclip_gemm_bn_res_f16: N=%d / alignment not supported by the fused epilogue", N); return PCLIP_E_INVALID; }
-    if (epi.act == 9 && pick < 0) { pclip_set_error("pclip_gemm_res_stats_f16: N=%d / alignment not supported by the fused epilogue", N); return PCLIP_E_INVALID; }
-    if (epi.act >= 7 && pick < 0) { pclip_set_error("pclip_gemm_ln_f16: N=%d / alignment not supported by the fused epilogue", N); return PCLIP_E_INVALID; }
     if (forced >= 0) {
         may_split = false;
         if (aligned && forced < kNumCfgs && N % kTileCfgs[forced].bn == 0) pick = forced;
@@ -796,16 +498,9 @@ int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int
             LinearEpi tail = epi;
             tail.C = epi.C + (size_t)split_rows * epi.ldc;
             if (epi.residual) tail.residual = epi.residual + (size_t)split_rows * epi.ldc;   // act 5 / 6: same row stride as C
-            if (epi.rowstats) tail.rowstats = epi.rowstats + (size_t)split_rows * 2;         // act 7 / 8 (split_rows is a multiple of 128: 16-byte aligned)
-            if (epi.partials) tail.partials = epi.partials + (size_t)split_rows * (N / 64) * 2;   // act 9
-            if (epi.act == 10) {                                                                  // the first launch's panels are at most split_rows / 128
-                tail.ln_y = epi.ln_y + (size_t)split_rows * N;
-                tail.ln_cnt = epi.ln_cnt + split_rows / 128;
-            }
             return gemm_dispatch(A + (size_t)split_rows * lda, lda, B, ldb, M - (int)split_rows, N, K, tail, cus, -1, true, s);
         }
     }
-    if (epi.act == 10 && pick != 2 && pick != 0) return two_launches(pick < 0 ? -2 : pick, false);
     ++g_gemm_launches;
     if (pick < 0 && epi.act == 6) epi.act = 0;                  // generic kernel: bias + residual operands, same roundings
     if (pick == 2) {
@@ -814,7 +509,7 @@ int gemm_dispatch(const half_t* A, int lda, const half_t* B, int ldb, int M, int
         if (g_use4w && pclip_gemm4w_supports(M, N, K, lda, ldb, epi.ldc, epi.C, epi.bias, epi.residual, epi.act)) {
             const TileOrder& order = tile_order();
             const bool rev = order.rev == 1 || (order.rev == 2 && K <= 1024);
-            return pclip_gemm4w_launch(A, lda, B, ldb, M, N, K, epi.bias, epi.C, epi.ldc, epi.act, epi.residual, cus, rev ? 1 : 0, s);
+            return pclip_gemm4w_launch(A, lda, B, ldb, M, N, K, epi.bias, epi.C, epi.ldc, epi.act, epi.residual, cus, rev ? 1 : 0, N / 256 >= 8 ? order.band : order.band_n, s);
         }
         return launch_fast<CfgBig>(A, lda, B, ldb, M, N, K, epi, cus, s);
     }
@@ -855,63 +550,6 @@ extern "C" int pclip_gemm_f16(const void* A, int lda, const void* B, int ldb, vo
     return gemm_dispatch((const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, cus, forced, !nosplit, (hipStream_t)stream);
 }
 
-// x += A W^T + bias in place of C = residual (pclip_gemm_f16 with `residual`), and the statistics partials of the updated rows.
-extern "C" int pclip_gemm_res_stats_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
-                                        const void* bias, const void* residual, float* partials, pclip_stream_t stream) {
-    PCLIP_REQUIRE(A && B && C && bias && residual && partials, "pclip_gemm_res_stats_f16: null pointer");
-    PCLIP_REQUIRE(M >= 0 && N > 0 && K > 0, "pclip_gemm_res_stats_f16: bad shape M=%d N=%d K=%d", M, N, K);
-    PCLIP_REQUIRE(K % pgemm::BK == 0 && N % 64 == 0, "pclip_gemm_res_stats_f16: K=%d / N=%d must be multiples of 64", K, N);
-    PCLIP_REQUIRE(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0, "pclip_gemm_res_stats_f16: bad leading dims");
-    PCLIP_REQUIRE((((uintptr_t)C | (uintptr_t)residual | (uintptr_t)bias | (uintptr_t)partials) & 15) == 0, "pclip_gemm_res_stats_f16: operands must be 16-byte aligned");
-    if (M == 0) return PCLIP_OK;
-    LinearEpi epi{(const half_t*)bias, (const half_t*)residual, (half_t*)C, ldc, 9, nullptr, nullptr, nullptr, partials};
-    int cus = pclip_device_cus();
-    if (cus <= 0) cus = 256;
-    static const bool nosplit = getenv("PCLIP_GEMM_NOSPLIT") != nullptr;
-    return gemm_dispatch((const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, cus, -1, !nosplit, (hipStream_t)stream);
-}
-
-// x += A W^T + bias in place, and y = LayerNorm(x) of the updated rows without a pass of its own (linear_fast_kernel act 10): `panel_counters` = one int per 128 rows
-// of x (+ 2), zero on entry and zero again on return (the kernel resets what it counted); NULL, or PCLIP_RES_LN=0, selects the two launches it replaces — same bits.
-extern "C" int pclip_gemm_res_ln_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const void* bias,
-                                     const float* gamma, const float* beta, float eps, void* y, int32_t* panel_counters, pclip_stream_t stream) {
-    PCLIP_REQUIRE(A && B && C && bias && gamma && beta && y, "pclip_gemm_res_ln_f16: null pointer");
-    PCLIP_REQUIRE(M >= 0 && N > 0 && K > 0, "pclip_gemm_res_ln_f16: bad shape M=%d N=%d K=%d", M, N, K);
-    PCLIP_REQUIRE(K % pgemm::BK == 0 && N % 8 == 0 && N <= 4096, "pclip_gemm_res_ln_f16: K=%d must be a multiple of 64, N=%d of 8 (<= 4096)", K, N);
-    PCLIP_REQUIRE(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0, "pclip_gemm_res_ln_f16: bad leading dims");
-    PCLIP_REQUIRE((((uintptr_t)y | (uintptr_t)panel_counters) & 15) == 0, "pclip_gemm_res_ln_f16: y / panel_counters must be 16-byte aligned");
-    if (M == 0) return PCLIP_OK;
-    static const bool fused = !(getenv("PCLIP_RES_LN") && getenv("PCLIP_RES_LN")[0] == '0');
-    LinearEpi epi{(const half_t*)bias, (const half_t*)C, (half_t*)C, ldc, 10, nullptr, nullptr};
-    epi.ln_gamma = gamma;
-    epi.ln_beta = beta;
-    epi.ln_y = (half_t*)y;
-    epi.ln_cnt = fused ? panel_counters : nullptr;
-    epi.ln_eps = eps;
-    int cus = pclip_device_cus();
-    if (cus <= 0) cus = 256;
-    static const bool nosplit = getenv("PCLIP_GEMM_NOSPLIT") != nullptr;
-    return gemm_dispatch((const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, cus, -1, !nosplit, (hipStream_t)stream);
-}
-
-// LayerNorm folded into the linear that consumes it (see ln_fold): y = act(LN(x) W^T + b) from the un-normalised rows x, their
-// (mean, rstd) pairs and the folded weight / column sums / bias of pclip_ln_fold_weights_f16.
-extern "C" int pclip_gemm_ln_f16(const void* x, int ldx, const float* rowstats, const void* Wf, int ldw, void* C, int ldc, int M, int N,
-                                 int K, const float* colsum, const float* bfold, int act, pclip_stream_t stream) {
-    PCLIP_REQUIRE(x && rowstats && Wf && C && colsum && bfold, "pclip_gemm_ln_f16: null pointer");
-    PCLIP_REQUIRE(M >= 0 && N > 0 && K > 0, "pclip_gemm_ln_f16: bad shape M=%d N=%d K=%d", M, N, K);
-    PCLIP_REQUIRE(K % pgemm::BK == 0 && N % 64 == 0, "pclip_gemm_ln_f16: K=%d / N=%d must be multiples of 64", K, N);
-    PCLIP_REQUIRE(ldx >= K && ldw >= K && ldc >= N && ldx % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0, "pclip_gemm_ln_f16: bad leading dims");
-    PCLIP_REQUIRE((((uintptr_t)colsum | (uintptr_t)bfold | (uintptr_t)rowstats | (uintptr_t)C) & 15) == 0, "pclip_gemm_ln_f16: operands must be 16-byte aligned");
-    PCLIP_REQUIRE(act == 0 || act == 1, "pclip_gemm_ln_f16: unknown activation %d", act);
-    if (M == 0) return PCLIP_OK;
-    LinearEpi epi{nullptr, nullptr, (half_t*)C, ldc, act == 1 ? 8 : 7, colsum, bfold, rowstats};
-    int cus = pclip_device_cus();
-    if (cus <= 0) cus = 256;
-    static const bool nosplit = getenv("PCLIP_GEMM_NOSPLIT") != nullptr;
-    return gemm_dispatch((const half_t*)x, ldx, (const half_t*)Wf, ldw, M, N, K, epi, cus, -1, !nosplit, (hipStream_t)stream);
-}
-
 namespace {
 // ---- split-K for small M (serving: M = 197 x batch rows, the class-token tail: M = batch) ------------------------------------
 // A request of a few images gives every encoder linear 12 - 48 output tiles for 256 CUs and a K-loop of 12 - 48 dependent
@@ -935,9 +573,7 @@ __global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void linear_small_kernel(con
                                                                            half_t* Cout, int ldc,
                                                                            const float* __restrict__ scale,
                                                                            const float* __restrict__ shift,
-                                                                           const half_t* residual = nullptr,
-                                                                           const float* __restrict__ rowstats = nullptr,
-                                                                           float* __restrict__ partials = nullptr) {
+                                                                           const half_t* residual = nullptr) {
     using C = CfgSplit;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = blockIdx.x / S, ks = blockIdx.x - tile * S;
@@ -966,19 +602,6 @@ __global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void linear_small_kernel(con
         auto pre = [&](int i, int j, int coff, float4_t v, int rl, int g) {
             if (ACT == 1) return quick_gelu16x4(v);
             half4_t h;
-            if (ACT == 7 || ACT == 8) {                     // LayerNorm folded into the linear: ln_fold, as linear_fast_kernel
-                const int n = n0 + wn * (C::BN / C::WN) + j * 32 + coff;
-                const float4_t cs = *reinterpret_cast<const float4_t*>(scale + n), bf = *reinterpret_cast<const float4_t*>(shift + n);
-                const int m = m0 + wm * (C::BM / C::WM) + i * 32 + rl;
-                const float2_t ms = *reinterpret_cast<const float2_t*>(rowstats + (size_t)(m < M ? m : M - 1) * 2);
-                float4_t y;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = ln_fold(v[e], ms[0], ms[1], cs[e], bf[e]);
-                if (ACT == 8) return quick_gelu16x4(y);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = (half_t)y[e];
-                return h;
-            }
             if (ACT == 2 || ACT == 3 || ACT == 5) {         // eval BatchNorm (+ReLU) as in linear_fast_kernel: same roundings
                 const int n = n0 + wn * (C::BN / C::WN) + j * 32 + coff;
                 const float4_t sc = *reinterpret_cast<const float4_t*>(scale + n), sh = *reinterpret_cast<const float4_t*>(shift + n);
@@ -998,7 +621,7 @@ __global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void linear_small_kernel(con
         pgemm::epilogue_f16<C, true>(acc, smem, [](int) {}, pre, [&](int r, int c, int, half8_t h) {
             const bool valid = m0 + r < M;
             const size_t o = (size_t)(m0 + r) * ldc + col;
-            if ((ACT == 5 || ACT == 6 || ACT == 9) && valid) {
+            if ((ACT == 5 || ACT == 6) && valid) {
                 const half8_t rr = ld_half8(residual + o);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -1007,12 +630,6 @@ __global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void linear_small_kernel(con
                 }
             }
             if (valid) st_half8(Cout + o, h);
-            if (ACT == 9) {                                  // statistics partials of the updated row segment: as linear_fast_kernel (CPR = 8: one slot)
-                float ps, pq;
-                stats_chunk(h, ps, pq);
-                stats_butterfly<8>(ps, pq);
-                if (valid && c == 0) *reinterpret_cast<float2_t*>(partials + ((size_t)(m0 + r) * (N >> 6) + (n0 >> 6)) * 2) = float2_t{ps, pq};
-            }
         });
         return;
     }
@@ -1132,11 +749,8 @@ int launch_small_one(const half_t* A, int lda, const half_t* B, int ldb, int M, 
     ++g_gemm_launches;
 #define PCLIP_SMALL_LAUNCH(ACT)                                                                                                          \
     linear_small_kernel<ACT><<<grid, CfgSplit::NTHREADS, kSmallLds, s>>>(A, lda, B, ldb, M, N, K, tiles_n, 1, steps, nullptr, epi.bias, epi.C, \
-                                                                        epi.ldc, epi.scale, epi.shift, epi.residual, epi.rowstats, epi.partials)
+                                                                        epi.ldc, epi.scale, epi.shift, epi.residual)
     if (epi.act == 5) PCLIP_SMALL_LAUNCH(5);
-    else if (epi.act == 9) PCLIP_SMALL_LAUNCH(9);
-    else if (epi.act == 7) PCLIP_SMALL_LAUNCH(7);
-    else if (epi.act == 8) PCLIP_SMALL_LAUNCH(8);
     else if (epi.act == 6) PCLIP_SMALL_LAUNCH(6);
     else if (epi.act == 1) PCLIP_SMALL_LAUNCH(1);
     else if (epi.act == 2) PCLIP_SMALL_LAUNCH(2);

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void vit_embed_ln_kernel(const half_t* __restr
                                                            const half_t* __restrict__ pos, int B, int G2, int W,
                                                            const float* __restrict__ g0, const float* __restrict__ b0,
                                                            const float* __restrict__ g1, const float* __restrict__ b1, float eps,
-                                                           half_t* __restrict__ x0, half_t* __restrict__ h, float* __restrict__ stats) {
+                                                           half_t* __restrict__ x0, half_t* __restrict__ h) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int L = G2 + 1;
     const size_t R = (size_t)B * L;
@@ -147,10 +147,6 @@ __global__ __launch_bounds__(256) void vit_embed_ln_kernel(const half_t* __restr
                 for (int j = 0; j < 8; ++j) xh[c][j] = (half_t)v[c][j];
                 st_half8(x0 + row * W + d, xh[c]);
             }
-        }
-        if (stats) {                                         // the first block's ln_1 is folded into its in_proj: (mean, rstd) of x0 instead of h
-            const float2_t ms = row_mean_rstd<NCH>(xh, W, lane, eps);
-            if (lane == 0) *reinterpret_cast<float2_t*>(stats + row * 2) = ms;
         }
         if (!h) continue;
         ln_row_inplace<NCH>(v, W, lane, g1, b1, eps);
@@ -240,8 +236,8 @@ extern "C" int pclip_vit_assemble_tokens_f16(const void* patch_emb, const void* 
 
 extern "C" int pclip_vit_embed_ln_f16(const void* patch_emb, const void* class_emb, const void* pos_emb, int B, int G2, int W,
                                       const float* gamma_pre, const float* beta_pre, const float* gamma_1, const float* beta_1, float eps,
-                                      void* x0, void* h, float* stats, pclip_stream_t stream) {
-    PCLIP_REQUIRE(patch_emb && class_emb && pos_emb && gamma_pre && beta_pre && x0 && (h || stats) && (!h || (gamma_1 && beta_1)),
+                                      void* x0, void* h, pclip_stream_t stream) {
+    PCLIP_REQUIRE(patch_emb && class_emb && pos_emb && gamma_pre && beta_pre && x0 && (!h || (gamma_1 && beta_1)),
                   "pclip_vit_embed_ln_f16: null pointer");
     PCLIP_REQUIRE(B >= 0 && G2 > 0 && W > 0 && W % 8 == 0 && W <= 4096, "pclip_vit_embed_ln_f16: bad shape B=%d G2=%d W=%d", B, G2, W);
     if (B == 0) return PCLIP_OK;
@@ -251,13 +247,13 @@ extern "C" int pclip_vit_embed_ln_f16(const void* patch_emb, const void* class_e
     if (PCLIP_LN_LDS && W <= 1024 && ln_grid > 0 && R >= (size_t)16 * ln_grid) {     // whole batch: resident-size grid, affine vectors from LDS (<= 16 KB per workgroup)
         grid = ln_grid;
         if (W <= 512) vit_embed_ln_kernel<1, true><<<grid, 256, 0, (hipStream_t)stream>>>((const half_t*)patch_emb, (const half_t*)class_emb, (const half_t*)pos_emb, B, G2, W, gamma_pre,
-                                                                                          beta_pre, gamma_1, beta_1, eps, (half_t*)x0, (half_t*)h, stats);
+                                                                                          beta_pre, gamma_1, beta_1, eps, (half_t*)x0, (half_t*)h);
         else vit_embed_ln_kernel<2, true><<<grid, 256, 0, (hipStream_t)stream>>>((const half_t*)patch_emb, (const half_t*)class_emb, (const half_t*)pos_emb, B, G2, W, gamma_pre,
-                                                                                 beta_pre, gamma_1, beta_1, eps, (half_t*)x0, (half_t*)h, stats);
+                                                                                 beta_pre, gamma_1, beta_1, eps, (half_t*)x0, (half_t*)h);
         return pclip_check_launch("vit_embed_ln");
     }
 #define PCLIP_VEL(NCH) vit_embed_ln_kernel<NCH><<<grid, 256, 0, (hipStream_t)stream>>>((const half_t*)patch_emb, (const half_t*)class_emb, \
-        (const half_t*)pos_emb, B, G2, W, gamma_pre, beta_pre, gamma_1, beta_1, eps, (half_t*)x0, (half_t*)h, stats)
+        (const half_t*)pos_emb, B, G2, W, gamma_pre, beta_pre, gamma_1, beta_1, eps, (half_t*)x0, (half_t*)h)
     if (W <= 512) PCLIP_VEL(1);
     else if (W <= 1024) PCLIP_VEL(2);
     else if (W <= 2048) PCLIP_VEL(4);

@@ -32,17 +32,11 @@ def evict_workspace(stream_obj):
     """Forget the scratch buffer cached for `stream_obj` (a torch.cuda.Stream that will not be used again)."""
     for key in [k for k in _ws_cache if k[1] == stream_obj.cuda_stream]:
         del _ws_cache[key]
-    for key in [k for k in _panel_counters if k[1] == stream_obj.cuda_stream]:
-        del _panel_counters[key]
-    for key in [k for k in _sync_words if k[1] == stream_obj.cuda_stream]:
-        del _sync_words[key]
 
 
 def release_workspaces():
     """Drop the cached scratch buffers (e.g. after a warm-up on a side stream that will not be used again)."""
     _ws_cache.clear()
-    _panel_counters.clear()
-    _sync_words.clear()          # (the arena of graph-recorded calls stays: recorded nodes keep pointing into it)
 
 
 def _f16c(t: torch.Tensor) -> torch.Tensor:
@@ -255,13 +249,16 @@ class classify_two_stage:
 
 
 class classify_fused:
-    """`with ops.classify_fused():` — the fused row-panel kernel for EVERY argmax-only call it can run (by default only calls with enough panels to fill the chip)."""
+    """`with ops.classify_fused():` — the fused row-panel kernel for EVERY argmax-only call it can run (by default only calls with enough panels to fill the chip;
+    the one-launch mid-N kernel, which would take N <= 256 first, is switched off inside)."""
     def __enter__(self):
         self.before = _lib.load().pclip_classify_panel_config(2)
+        self.before_mid = _lib.load().pclip_classify_mid_config(0)
         return self
 
     def __exit__(self, *exc):
         _lib.load().pclip_classify_panel_config(self.before if self.before >= 0 else 1)
+        _lib.load().pclip_classify_mid_config(self.before_mid if self.before_mid >= 0 else 1)
         return False
 
 
@@ -279,12 +276,12 @@ class classify_panel_passes:
         return False
 
 
-def classify_panel_stats(reset: bool = False):
-    """(panels classified by the fused kernel, panels that needed its second pass) since the last reset; synchronises."""
+def classify_panel_stats(reset: bool = False, tiles: bool = False):
+    """(panels classified by the fused kernel, panels that needed a second pass[, class tiles those second passes walked]) since the last reset; synchronises."""
     import ctypes
-    out = (ctypes.c_int * 2)()
+    out = (ctypes.c_int * 3)()
     check(_lib.load().pclip_classify_panel_stats(ctypes.cast(out, ctypes.c_void_p), int(reset)), "pclip_classify_panel_stats")
-    return int(out[0]), int(out[1])
+    return (int(out[0]), int(out[1]), int(out[2])) if tiles else (int(out[0]), int(out[1]))
 
 
 def classify_panel_distances(q, zi, zt, exact: bool = False):
@@ -499,119 +496,6 @@ def layernorm(x, gamma, beta, eps: float = 1e-5, out=None, rows: int = None, ld:
     return out
 
 
-def ln_fold_weights(w, bias, gamma, beta):
-    """(Wf, colsum, bfold) of a LayerNorm folded into the linear that consumes it (pclip_ln_fold_weights_f16): done once per
-    (LayerNorm, Linear) pair; gamma / beta fp32, w fp16 [N, K], bias fp16 [N] or None."""
-    require_cuda(w, gamma, beta)
-    N, K = w.shape
-    wf = torch.empty(N, K, dtype=torch.float16, device=w.device)
-    cs = torch.empty(N, dtype=torch.float32, device=w.device)
-    bf = torch.empty(N, dtype=torch.float32, device=w.device)
-    check(_lib.load().pclip_ln_fold_weights_f16(ptr(w), w.stride(0), N, K, ptr(gamma), ptr(beta), ptr(bias), ptr(wf), ptr(cs), ptr(bf),
-                                                stream()), "pclip_ln_fold_weights_f16")
-    return wf, cs, bf
-
-
-def stats_rows(R: int) -> int:
-    """Rows a (mean, rstd) buffer for R rows must hold: the linear stages whole 256-row tiles of it, and a call whose last round
-    of tiles is split off starts its second launch at a multiple of 128 rows."""
-    return (R + 255) // 256 * 256 + 256
-
-
-def row_stats(x, eps: float = 1e-5, rows: int = None, ld: int = None):
-    """(mean, rstd) per row of x [R, D] fp16 — the statistics half of LayerNorm (clip/model.py:155-161) for `gemm_ln`.
-    Returns [stats_rows(R), 2] fp32 of which the first R rows are filled."""
-    require_cuda(x)
-    D = x.shape[-1]
-    R = x.numel() // D if rows is None else rows
-    ld = D if ld is None else ld
-    stats = torch.empty(stats_rows(R), 2, dtype=torch.float32, device=x.device)
-    check(_lib.load().pclip_row_stats_f16(ptr(x), ld, eps, ptr(stats), R, D, stream()), "pclip_row_stats_f16")
-    return stats
-
-
-def gemm_res_partials(a, w, bias, x):
-    """x += a @ w^T + bias IN PLACE and returns the statistics partials [M, N/64, 2] fp32 its epilogue wrote (pclip_gemm_res_stats_f16)."""
-    M, K = a.shape
-    N = w.shape[0]
-    partials = torch.empty(M, N // 64, 2, dtype=torch.float32, device=x.device)
-    check(_lib.load().pclip_gemm_res_stats_f16(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(x), x.stride(0), M, N, K, ptr(bias), ptr(x),
-                                               ptr(partials), stream()), "pclip_gemm_res_stats_f16")
-    return partials
-
-
-def finalize_stats(partials, eps: float = 1e-5):
-    """partials [R, D/64, 2] -> `row_stats`-shaped (mean, rstd) buffer (pclip_row_stats_finalize)."""
-    R, D = partials.shape[0], partials.shape[1] * 64
-    stats = torch.empty(stats_rows(R), 2, dtype=torch.float32, device=partials.device)
-    check(_lib.load().pclip_row_stats_finalize(ptr(partials), R, D, eps, ptr(stats), stream()), "pclip_row_stats_finalize")
-    return stats
-
-
-def gemm_res_stats(a, w, bias, x, eps: float = 1e-5):
-    """x += a @ w^T + bias IN PLACE (the residual add of clip/model.py:188-189 in the GEMM epilogue) and returns the `row_stats` of
-    the updated x, produced by that same epilogue (partials per 64 columns) + one tiny finishing launch — bit-identical to
-    `row_stats(x)` afterwards.  Returns None (after doing the add) when the shape has no fused form; the caller then takes
-    `row_stats`."""
-    require_cuda(a, w, bias, x)
-    N = w.shape[0]
-    if N % 64 or x.stride(0) % 8 or (x.data_ptr() | bias.data_ptr()) & 15 or a.stride(0) % 8 or w.stride(0) % 8:
-        gemm(a, w, bias, residual=x, out=x)
-        return None
-    return finalize_stats(gemm_res_partials(a, w, bias, x), eps)
-
-
-_panel_counters = {}
-
-
-def _counters(n: int, device) -> torch.Tensor:
-    """Zeroed int32 arrival counters for pclip_gemm_res_ln_f16: the kernel leaves them zero, so one array per (device, stream) serves every call
-    on that stream (calls on one stream are ordered).  During a hipGraph capture: a fresh zeroed array of the capture's own pool."""
-    if torch.cuda.is_current_stream_capturing():
-        return torch.zeros(n, dtype=torch.int32, device=device)
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    buf = _panel_counters.get(key)
-    if buf is None or buf.numel() < n:
-        buf = torch.zeros(max(n, 4096), dtype=torch.int32, device=device)
-        _panel_counters[key] = buf
-    return buf
-
-
-def gemm_res_ln(a, w, bias, x, gamma, beta, eps: float = 1e-5, out=None):
-    """x += a @ w^T + bias IN PLACE (clip/model.py:188-189) and returns r16(LayerNorm(x)) of the updated rows (the ln_2 / next ln_1 the following
-    linear reads) from the SAME launch (pclip_gemm_res_ln_f16: the workgroup that completes a row panel normalises it) — bit-identical to
-    `gemm(a, w, bias, residual=x, out=x)` followed by `layernorm(x, gamma, beta)`, which is also what the library runs for shapes without a fused form."""
-    require_cuda(a, w, bias, x, gamma, beta)
-    M, K = a.shape
-    N = w.shape[0]
-    if out is None:
-        out = torch.empty(M, N, dtype=torch.float16, device=x.device)
-    # (N > 4096 is outside the entry point's contract; for 1024 < N <= 4096 the LIBRARY itself runs the two launches — include/pclip.h — with the same bits)
-    if gamma.dtype != torch.float32 or beta.dtype != torch.float32 or x.stride(0) % 8 or a.stride(0) % 8 or w.stride(0) % 8 or N % 8 or N > 4096 or \
-            not out.is_contiguous():
-        gemm(a, w, bias, residual=x, out=x)
-        return layernorm(x, gamma.float(), beta.float(), eps, out=out, rows=M, ld=x.stride(0))   # x may be a row-strided view (ADVICE r4); the kernel takes fp32 parameters
-    cnt = _counters(M // 128 + 2, x.device)
-    cnt.zero_()                      # the kernel leaves them zero only when it runs to completion: a launch that faulted must not poison every later call (ADVICE r4)
-    check(_lib.load().pclip_gemm_res_ln_f16(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(x), x.stride(0), M, N, K, ptr(bias), ptr(gamma), ptr(beta),
-                                            eps, ptr(out), ptr(cnt), stream()), "pclip_gemm_res_ln_f16")
-    return out
-
-
-def gemm_ln(x, stats, wf, colsum, bfold, act: int = 0, out=None):
-    """out = act(LayerNorm(x) @ W^T + b) from the un-normalised rows x, their `row_stats` and `ln_fold_weights(W, b, gamma, beta)`."""
-    require_cuda(x, stats, wf, colsum, bfold)
-    M, K = x.shape
-    N = wf.shape[0]
-    if stats.shape[0] < stats_rows(M):
-        raise _lib.PclipError(f"gemm_ln: stats holds {stats.shape[0]} rows, needs {stats_rows(M)}")
-    if out is None:
-        out = torch.empty(M, N, dtype=torch.float16, device=x.device)
-    check(_lib.load().pclip_gemm_ln_f16(ptr(x), x.stride(0), ptr(stats), ptr(wf), wf.stride(0), ptr(out), out.stride(0), M, N, K,
-                                        ptr(colsum), ptr(bfold), act, stream()), "pclip_gemm_ln_f16")
-    return out
-
-
 def add_layernorm(x, delta, gamma, beta, eps: float = 1e-5, out=None, update_x: bool = True, rows: int = None,
                   ld: int = None):
     """xs = r16(x + delta) (written back into x when update_x) and returns r16(LayerNorm(xs)): the residual add of
@@ -677,19 +561,16 @@ def vit_assemble_tokens(patch_emb, class_emb, pos_emb, B: int, G2: int, W: int) 
     return tokens
 
 
-def vit_embed_ln(patch_emb, class_emb, pos_emb, B: int, G2: int, W: int, g_pre, b_pre, g_1=None, b_1=None, eps: float = 1e-5,
-                 want_stats: bool = False):
-    """(x0, h) = (ln_pre(tokens), ln_1(x0)) with tokens = [class ; patches] + pos, one pass (clip/model.py:225-227, 188).
-    want_stats: (x0, stats) instead — the `row_stats` of x0 for a first block whose ln_1 is folded into its in_proj (`gemm_ln`)."""
+def vit_embed_ln(patch_emb, class_emb, pos_emb, B: int, G2: int, W: int, g_pre, b_pre, g_1, b_1, eps: float = 1e-5):
+    """(x0, h) = (ln_pre(tokens), ln_1(x0)) with tokens = [class ; patches] + pos, one pass (clip/model.py:225-227, 188)."""
     R = B * (G2 + 1)
     x0 = torch.empty(R, W, dtype=torch.float16, device=patch_emb.device)
     f = lambda t: t if t is None or t.dtype == torch.float32 else t.float()
     g_pre, b_pre, g_1, b_1 = f(g_pre), f(b_pre), f(g_1), f(b_1)
-    h = None if want_stats else torch.empty_like(x0)
-    stats = torch.empty(stats_rows(R), 2, dtype=torch.float32, device=x0.device) if want_stats else None
+    h = torch.empty_like(x0)
     check(_lib.load().pclip_vit_embed_ln_f16(ptr(patch_emb), ptr(class_emb), ptr(pos_emb), B, G2, W, ptr(g_pre), ptr(b_pre), ptr(g_1),
-                                             ptr(b_1), eps, ptr(x0), ptr(h), ptr(stats), stream()), "pclip_vit_embed_ln_f16")
-    return x0, (stats if want_stats else h)
+                                             ptr(b_1), eps, ptr(x0), ptr(h), stream()), "pclip_vit_embed_ln_f16")
+    return x0, h
 
 
 def text_embed(tokens, tok_emb, pos_emb) -> torch.Tensor:

@@ -1,7 +1,6 @@
-"""Study (not a collected test; run on a GPU box: `python tests/fold_parity_study.py [n_seeds]`): does folding the LayerNorms into
-the linears (clip/model.py LN_FOLD, pclip_gemm_ln_f16) move the image -> logits chain away from the reference CPU path?
-For several seeded weight sets / image sets of the e2e case (tests/golden/spec.py::E2E) the GPU chain runs with the fold on and
-off; both are compared with the ORACLE's fp32 towers (pinned to the reference's fp32 model at 5e-6, tests/test_oracle_golden.py)
+"""Study (imported by tests/test_gpu_e2e.py; also `python tests/chain_parity_study.py [n_seeds]` on a GPU box): how far is the GPU's
+image -> logits chain from the reference CPU path over several seeded weight sets / image sets of the e2e case
+(tests/golden/spec.py::E2E)?  It is compared with the ORACLE's fp32 towers (pinned to the reference's fp32 model at 5e-6, tests/test_oracle_golden.py)
 with the features cast to fp16 — the reference CPU path of SURVEY 8d — and with the oracle's fp16 towers.  Prints one line per
 seed and the maxima; the summary is kept in profiles/."""
 import json
@@ -65,17 +64,12 @@ def run(n):
         p16 = oracle_chain(sd, sup_x, sup_y, test_x, tok, ad_sd, case, half=True)
         model = build_model({k: v.clone() for k, v in sd.items()}).cuda()
         res = {"seed": s, "oracle16_vs_32": (p16 - p32).abs().max().item()}
-        was = M.LN_FOLD
-        for fold in (False, True):
-            M.LN_FOLD = fold
-            p = gpu_chain(model, sup_x, sup_y, test_x, tok, adapter, case)
-            tag = "fold" if fold else "unfolded"
-            res[tag + "_vs_32"] = (p - p32).abs().max().item()
-            res[tag + "_vs_16"] = (p - p16).abs().max().item()
-            srt = p32.sort(dim=1).values
-            decided = (srt[:, -1] - srt[:, -2]) > 2e-3
-            res[tag + "_top1_flips_decided"] = int((p.max(1)[1][decided] != p32.max(1)[1][decided]).sum())
-        M.LN_FOLD = was
+        p = gpu_chain(model, sup_x, sup_y, test_x, tok, adapter, case)
+        res["gpu_vs_32"] = (p - p32).abs().max().item()
+        res["gpu_vs_16"] = (p - p16).abs().max().item()
+        srt = p32.sort(dim=1).values
+        decided = (srt[:, -1] - srt[:, -2]) > 2e-3
+        res["gpu_top1_flips_decided"] = int((p.max(1)[1][decided] != p32.max(1)[1][decided]).sum())
         rows.append(res)
         print(json.dumps(res), flush=True)
     keys = [k for k in rows[0] if k != "seed"]
@@ -87,7 +81,7 @@ def main():
     rows, summary = run(int(sys.argv[1]) if len(sys.argv) > 1 else 6)
     print("SUMMARY " + json.dumps(summary))
     os.makedirs("gpurun_out", exist_ok=True)
-    json.dump({"rows": rows, "summary": summary}, open("gpurun_out/fold_parity_study.json", "w"), indent=1)
+    json.dump({"rows": rows, "summary": summary}, open("gpurun_out/chain_parity_study.json", "w"), indent=1)
 
 
 if __name__ == "__main__":

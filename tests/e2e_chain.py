@@ -72,23 +72,18 @@ def main():
         if not os.path.exists(os.path.join(HERE, "golden", name + ".npz")):
             continue
         row = {}
-        was = M.LN_FOLD
-        for fold in (False, True):
-            M.LN_FOLD = fold
-            r = run_variant(name)
-            srt = r["p16"].sort(dim=1).values
-            margin = srt[:, -1] - srt[:, -2]
-            tol = max(2 * r["gap"], 1e-3)
-            decided = margin > 2 * tol
-            ref_am = torch.from_numpy(r["g"]["argmax_f16"]).long()
-            row["folded" if fold else "unfolded"] = dict(d16=r["d16"], d32=r["d32"], stage=r["stage"],
-                                                         top1_flips_decided=int((r["am"][decided] != ref_am[decided]).sum()))
-            row.update(gap=r["gap"], jitter=r["jitter"], tol=tol, stage_gap=r["stage_gap"], decided=int(decided.sum()))
-        M.LN_FOLD = was
+        r = run_variant(name)
+        srt = r["p16"].sort(dim=1).values
+        margin = srt[:, -1] - srt[:, -2]
+        tol = max(2 * r["gap"], 1e-3)
+        decided = margin > 2 * tol
+        ref_am = torch.from_numpy(r["g"]["argmax_f16"]).long()
+        row["gpu"] = dict(d16=r["d16"], d32=r["d32"], stage=r["stage"], top1_flips_decided=int((r["am"][decided] != ref_am[decided]).sum()))
+        row.update(gap=r["gap"], jitter=r["jitter"], tol=tol, stage_gap=r["stage_gap"], decided=int(decided.sum()))
         out[name] = row
         print(name, json.dumps(row), flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(out, open("gpurun_out/e2e_fold_study.json", "w"), indent=1)
+    json.dump(out, open("gpurun_out/e2e_chain_study.json", "w"), indent=1)
 
 
 if __name__ == "__main__":

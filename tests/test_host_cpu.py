@@ -45,15 +45,6 @@ def test_argument_validation_is_loud_and_precedes_any_launch():
     assert lib.pclip_classify_f16(buf, buf, buf, 4, 3, 64, None, None, None, 0.5, 0.5, 1.0, None, buf, None, None, 0,
                                   buf, 16, None) == -3       # workspace too small
     assert lib.pclip_workspace_bytes(2, 50000, 1000, 512) >= 2 * 50000 * 1000 * 4
-    # the LayerNorm-fold entry points (round 2)
-    assert lib.pclip_gemm_ln_f16(buf, 768, buf, buf, 768, buf, 2304, 8, 2300, 768, buf, buf, 0, None) == -1
-    assert b"multiples of 64" in lib.pclip_last_error()
-    assert lib.pclip_gemm_ln_f16(buf, 768, buf, buf, 768, buf, 2304, 8, 2304, 768, buf, buf, 2, None) == -1      # unknown activation
-    assert lib.pclip_gemm_ln_f16(buf, 768, None, buf, 768, buf, 2304, 8, 2304, 768, buf, buf, 0, None) == -1     # no statistics
-    assert lib.pclip_gemm_res_stats_f16(buf, 768, buf, 768, buf, 768, 8, 768, 768, buf, buf, None, None) == -1   # no partials buffer
-    assert lib.pclip_row_stats_finalize(buf, 8, 100, 1e-5, buf, None) == -1
-    assert lib.pclip_row_stats_f16(buf, 768, 1e-5, buf, 8, 4100, None) == -1
-    assert lib.pclip_ln_fold_weights_f16(buf, 768, 8, 700, buf, buf, None, buf, buf, buf, None) == -1
     assert lib.pclip_attention_config(3, 0) == -1 and lib.pclip_attention_config(-1, 0) == 0
 
 

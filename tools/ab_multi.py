@@ -46,34 +46,6 @@ if mode == "attn":
         base = next(iter(libs))
         print(f"{name:9s} " + " | ".join(f"{x} {med[x]:7.1f} us (d_base {(out[x].float() - out[base].float()).abs().max().item():.1e}, err {(out[x][:nb * L].float() - ref).abs().max().item():.1e})"
                                          for x in libs), flush=True)
-elif mode == "resln":
-    # x += a W^T + b ; y = LN(x): the fused launch of every build against the two launches of the first one
-    for l in libs.values():
-        l.pclip_gemm_res_ln_f16.argtypes = [P, ctypes.c_int, P, ctypes.c_int, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, P, P, P, ctypes.c_float, P, P, P]
-        l.pclip_gemm_f16.argtypes = [P, ctypes.c_int, P, ctypes.c_int, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, P, ctypes.c_int, P, P]
-        l.pclip_layernorm_f16.argtypes = [P, ctypes.c_int, P, P, ctypes.c_float, P, ctypes.c_int, ctypes.c_int, P]
-    base = next(iter(libs))
-    for m, n, k in [(201728, 768, 768), (201728, 768, 3072)]:
-        a = torch.randn(m, k, device="cuda").half(); w = (torch.randn(n, k, device="cuda") * k ** -0.5).half()
-        bias = torch.randn(n, device="cuda").half(); x = torch.randn(m, n, device="cuda").half(); y = torch.empty_like(x)
-        g, b = 1 + 0.1 * torch.randn(n, device="cuda"), 0.1 * torch.randn(n, device="cuda")
-        cnt = torch.zeros(m // 128 + 2, dtype=torch.int32, device="cuda")
-        def call(t):
-            if t == "two":
-                assert libs[base].pclip_gemm_f16(P(a.data_ptr()), k, P(w.data_ptr()), k, P(x.data_ptr()), n, m, n, k, P(bias.data_ptr()), 0, P(x.data_ptr()), st()) == 0
-                assert libs[base].pclip_layernorm_f16(P(x.data_ptr()), n, P(g.data_ptr()), P(b.data_ptr()), 1e-5, P(y.data_ptr()), m, n, st()) == 0
-            elif t == "gemm":
-                assert libs[base].pclip_gemm_f16(P(a.data_ptr()), k, P(w.data_ptr()), k, P(x.data_ptr()), n, m, n, k, P(bias.data_ptr()), 0, P(x.data_ptr()), st()) == 0
-            else:
-                assert libs[t].pclip_gemm_res_ln_f16(P(a.data_ptr()), k, P(w.data_ptr()), k, P(x.data_ptr()), n, m, n, k, P(bias.data_ptr()), P(g.data_ptr()), P(b.data_ptr()),
-                                                     1e-5, P(y.data_ptr()), P(cnt.data_ptr()), st()) == 0
-        order = ["two", "gemm"] + list(libs)
-        res = {t: [] for t in order}
-        for r in range(5):
-            for t in (order if r % 2 == 0 else order[::-1]):
-                cnt.zero_()
-                res[t].append(timeit(lambda: call(t), iters=8, warm=2) * 1e6)
-        print(f"{m}x{n}x{k} " + " | ".join(f"{t} {sorted(v)[len(v) // 2]:7.1f}" for t, v in res.items()), flush=True)
 elif mode == "ln":
     for l in libs.values():
         l.pclip_layernorm_f16.argtypes = [P, ctypes.c_int, P, P, ctypes.c_float, P, ctypes.c_int, ctypes.c_int, P]

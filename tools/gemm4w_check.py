@@ -37,10 +37,6 @@ def check(M, N, K, act, use_bias, use_res):
     gemm4w(a, w, bias, act, res, out[:M])
     torch.cuda.synchronize()
     same = torch.equal(ref, out[:M]) and bool((out[M] == 7.0).all())
-    if K == 768 and not use_res and use_bias and VAR == 0:       # the unrolled statement with the deferred half (variant 7)
-        out7 = torch.full((M + 1, N), 7.0, device="cuda", dtype=torch.float16)
-        gemm4w(a, w, bias, act, res, out7[:M], 7)
-        same = same and torch.equal(ref, out7[:M]) and bool((out7[M] == 7.0).all())
     err = (ref.float() - out[:M].float()).abs().max().item()
     # independent check of the reference itself (fp32 matmul) so that "identical" is not "identically wrong"
     sl = slice(0, min(M, 512))

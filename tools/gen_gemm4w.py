@@ -49,7 +49,7 @@ class Ops:
 
 
 class Gen:
-    def __init__(self, dma_spread=6, dma_first=9, read_stride=2, sleep=0, cold=False, b1=False, b1_early=False, defer_nt=0, first_vm=8):
+    def __init__(self, dma_spread=6, dma_first=9, read_stride=2, sleep=0, cold=False, b1=False, b1_early=False, first_vm=8):
         self.lines = []
         self.dma_spread = dma_spread      # MFMAs between two LDS-DMA pieces of a block
         self.dma_first = dma_first        # MFMA index behind which the first piece's M0 write sits
@@ -58,9 +58,6 @@ class Gen:
         self.cold = cold or b1                # statements without MFMAs: the first tile's prefetch (cold) / the next tile's B'(1) out of the epilogue (b1)
         self.b1 = b1
         self.b1_early = b1_early              # B(1) is requested by the PREVIOUS tile's epilogue (PCLIP_GEMM4W_B1), not by this statement's first block
-        # defer_nt = nt > 0: the statement is UNROLLED for exactly nt K-tiles and carries, behind the A pieces of its first nt - 3 iterations, the direct stores of the
-        # PREVIOUS output tile's deferred half (rows 64 .. 127 of every wave, packed fp16 in 64 registers): half of the epilogue's store issue under the K-loop
-        self.defer_nt = defer_nt
         # counted wait behind the statement's first block: 8 = only A(2) stays in flight; with b1_early on tiles whose last epilogue slab issues exactly eight stores per
         # wave (bias / QuickGELU tiles: one bounds-checked descriptor, no branch) 24 = those eight stores + the eight bias loads + A(2): B(1) is OLDER than all of them
         self.first_vm = first_vm
@@ -73,8 +70,6 @@ class Gen:
             for k in range(4): o.out(f"vr{k}", "=&v", f"vr[{k}]")
         if not b1:
             for k in range(8): o.out(f"nb{k}", "=&v", f"nb[{k}]")
-        if defer_nt:
-            for k in range(4): o.out(f"soc{k}", "=&s", f"soc[{k}]")
         for k in range(8): o.out(f"so{k}", "=&s", f"so[{k}]")
         for n in ("cnt", "tmp", "scr"): o.out(n, "=&s", f"st_{n}")
         for n in ("wr", "rda", "rdb"): o.out(n, "+s", f"ring_{n}")
@@ -86,9 +81,6 @@ class Gen:
         o.inp("wbase", "s", "wbase")
         for n in ("voffa0", "voffa1", "voffb0", "voffb1"): o.inp(n, "v", n)
         if not b1: o.inp("biasp", "v", "biasp")
-        if defer_nt:
-            for k in range(16): o.inp(f"dq{k}", "v", f"dq[{k}]")
-            o.inp("rcp", "s", "rcp_s"); o.inp("cvoff", "v", "cvoff"); o.inp("crow16", "s", "crow16")
         if not cold:
             o.inp("lanea", "v", "lanea"); o.inp("laneb", "v", "laneb")
         self.ops = o
@@ -140,12 +132,7 @@ class Gen:
     @staticmethod
     def place(fillers, m, ins): fillers.setdefault(min(m, 63), []).append(ins)
 
-    def deferred_store(self, n):
-        """store n (0 .. 15) of the previous tile's deferred half: 16-row block 4 + (n >> 2), the PAIR of 16-column blocks 2 (n & 3), 2 (n & 3) + 1 — the caller has
-        exchanged the lanes' quads (v_permlane32_swap + v_permlane16_swap) so that a lane holds 16 contiguous bytes: 16 rows x 64 bytes per instruction"""
-        return f"buffer_store_dwordx4 {self.r(f'dq{n}')}, {self.r('cvoff')}, {self.r('rcp')}, {self.r(f'soc{n >> 2}')} offen offset:{(n & 3) * 64} nt"
-
-    def block(self, buf, read_buf, read_ks, dmas, salu, stores=()):
+    def block(self, buf, read_buf, read_ks, dmas, salu):
         """one 64-MFMA block on fragment buffer `buf`: the 16 fragment reads of (read_buf, read_ks) behind the even MFMAs; the half-tiles `dmas` = [(op, next_tile,
         pre)] one after the other behind the odd ones — [pre, M0 base] + 8 x (M0 write, two gaps, piece) + [ring advance, k advance]; `salu` behind the last piece"""
         f = {}
@@ -164,10 +151,6 @@ class Gen:
             g = max(g, g - spread + 4)                          # first gap behind the last piece
             for ins in self.ring_next_wr() + self.advance_k(op): self.place(f, g - 1, ins)
         for ins in salu: self.place(f, max(g, 33), ins)
-        gs = max(g, 33) + 1
-        for n in stores:                                        # behind the block's pieces (they are YOUNGER than the pieces: the counted wait leaves them in flight)
-            self.place(f, gs, self.deferred_store(n))
-            gs += 2
         self.mfma_block(buf, f)
 
     def set_read_addresses(self):
@@ -189,17 +172,15 @@ class Gen:
             self.e(f"s_sleep {self.sleep}")
             self.e("9:")
 
-    def iteration(self, dma1, dma2, barrier, extra1=(), extra2=(), stores=()):
-        """loop body for one K-tile, entered right behind barrier B(t); dma1 / dma2: (op, next_tile, pre) or None; stores: deferred stores behind dma2's pieces"""
+    def iteration(self, dma1, dma2, barrier, extra1=(), extra2=()):
+        """loop body for one K-tile, entered right behind barrier B(t); dma1 / dma2: (op, next_tile, pre) or None"""
         self.set_read_addresses()
-        # the deferred stores sit BETWEEN the block-1 pieces (B) and the block-2 pieces (A): younger than what this iteration's wait needs, and two K-tiles old when the
-        # next-but-one wait needs them gone (behind the A pieces they had one K-tile: -8 ... -13 %)
-        self.block(buf=1, read_buf=0, read_ks=0, dmas=[dma1] if dma1 else [], salu=list(extra1), stores=stores)
+        self.block(buf=1, read_buf=0, read_ks=0, dmas=[dma1] if dma1 else [], salu=list(extra1))
         self.e("s_waitcnt lgkmcnt(0)")
         self.block(buf=0, read_buf=1, read_ks=1, dmas=[dma2] if dma2 else [], salu=list(extra2) + self.ring_next_rd("rda") + self.ring_next_rd("rdb"))
         if barrier:
             self.jitter(1)
-            self.e(f"s_waitcnt vmcnt({8 + len(stores)}) lgkmcnt(0)")      # the A pieces and the stores behind them stay in flight
+            self.e("s_waitcnt vmcnt(8) lgkmcnt(0)")                 # the A pieces stay in flight
             self.jitter(2)
             self.e("s_barrier")
         else:
@@ -259,28 +240,16 @@ class Gen:
         self.jitter(6)
         e("s_barrier")                                          # B(0)
         # ---- steady iterations t = 0 .. nt - 4
-        if self.defer_nt:
-            # unrolled: iteration t carries its share of the 32 deferred stores (row-block offsets: (4 + ii) * 16 rows of C)
-            e(f"s_lshl_b32 {self.r('soc0')}, {self.r('crow16')}, 2")
-            for k in range(1, 4): e(f"s_add_u32 {self.r(f'soc{k}')}, {self.r(f'soc{k - 1}')}, {self.r('crow16')}")
-            nit = self.defer_nt - 3
-            done = 0
-            for t in range(nit):
-                n = (16 - done + (nit - t) - 1) // (nit - t)
-                self.iteration(('B', False, []), ('A', False, []), barrier=True, stores=list(range(done, done + n)))
-                done += n
-            assert done == 16
-        else:
-            cnt = self.r("cnt")
-            e(f"s_sub_u32 {cnt}, {self.r('nt')}, 3")
-            e(f"s_cmp_eq_u32 {cnt}, 0")
-            e("s_cbranch_scc1 2f")
-            e("1:")
-            self.iteration(('B', False, []), ('A', False, []), barrier=True)
-            e(f"s_sub_u32 {cnt}, {cnt}, 1")
-            e(f"s_cmp_lg_u32 {cnt}, 0")
-            e("s_cbranch_scc1 1b")
-            e("2:")
+        cnt = self.r("cnt")
+        e(f"s_sub_u32 {cnt}, {self.r('nt')}, 3")
+        e(f"s_cmp_eq_u32 {cnt}, 0")
+        e("s_cbranch_scc1 2f")
+        e("1:")
+        self.iteration(('B', False, []), ('A', False, []), barrier=True)
+        e(f"s_sub_u32 {cnt}, {cnt}, 1")
+        e(f"s_cmp_lg_u32 {cnt}, 0")
+        e("s_cbranch_scc1 1b")
+        e("2:")
         # ---- t = nt - 3: B(nt - 1), then the NEXT output tile's A'(0)
         self.iteration(('B', False, []), ('A', True, self.reset_k('A')), barrier=True)
         # ---- t = nt - 2: B'(0), A'(1); no barrier behind it (nothing is published or freed)
@@ -313,7 +282,9 @@ VARIANTS = {
     #         every gap; B'(1) out of the epilogue with and without a relaxed first wait; batched LDS reads on residual tiles; un-staged 8-byte stores) — all within +-1.5 %
     #         or slower: profiles/r05_gemm4w_variants.txt, r05_gemm4w_epilogue.txt
     6: dict(),                                # the product loop WITHOUT the epilogue (nothing is stored): ablation — what a fully hidden epilogue would buy at most
-    7: dict(defer_nt=12),                     # K = 768 (12 K-tiles), bias / QuickGELU tiles: unrolled, the previous tile's second half stored from registers under the loop
+    8: dict(),                                # the product loop in a kernel that keeps time stamps of its tile phases (tools/gemm4w_stamps.py)
+    # 7 (round 5, removed in round 6): K = 768 unrolled with the previous tile's second half stored from registers under the loop — bit-identical and 5 - 13 % SLOWER in
+    #    every form (profiles/r05_gemm4w_defer.txt: the scattered stores cost the LDS-DMA stream more than the half epilogue they hide)
 }
 B1_EARLY = {v: kw.get("b1_early", False) for v, kw in VARIANTS.items()}
 

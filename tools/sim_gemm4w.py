@@ -140,11 +140,7 @@ def check(gen: Gen, nt: int, wr0=0, rda0=0, rdb0=0x8000, **kw):
     mfma_seen = {}
     reads_in_step = []
     stores = [e[1] for e in ev if e[0] == "store"]
-    if gen.defer_nt:
-        # the 16 deferred stores, each once: 16-row block 4 + (n >> 2) through the scalar offset, the pair of 16-column blocks n & 3 through the immediate, previous tile's descriptor
-        exp = [dict(reg=f"dq{n}", voff="cvoff", rs="rcp", soff=(4 + (n >> 2)) * S["crow16"], off=(n & 3) * 64, nt=True) for n in range(16)]
-        if stores != exp: raise ProtocolError(f"deferred stores: {[x for x in zip(stores, exp) if x[0] != x[1]][:2]}")
-    elif stores: raise ProtocolError("stores in a statement without a deferred half")
+    if stores: raise ProtocolError("stores inside the K-loop statement")
     for kind, p in ev:
         if kind in ("vmem", "store"): issued.append(None)
         elif kind == "dma":
@@ -225,7 +221,6 @@ def check_all(variants=None, nts=(3, 4, 5, 6, 7, 12, 13, 48)):
             g = Gen(**kw)
             check_mfma_wait(g, nt)
             wr, rda, rdb = check(Gen(cold=True), 0, wr0=0)
-            if kw.get("defer_nt") and kw["defer_nt"] != nt: continue          # unrolled for one K-tile count
             # chain five statements: the ring phase advances by 2 nt mod 5 from tile to tile
             for _ in range(5):
                 if kw.get("b1_early", False): wr, _, _ = check(Gen(b1=True), 0, wr0=wr)          # out of the previous tile's epilogue (the first tile's: behind the cold prefetch)
