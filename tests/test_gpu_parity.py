@@ -613,8 +613,16 @@ def test_full_size_default_routing_C3(ops, structured):
         q = dev(torch.nn.functional.normalize(torch.randn(Q, D, generator=g), dim=-1).half())
     ops.classify_panel_stats(reset=True)
     _, am, _, _ = ops.classify(q, zi, zt, alpha, beta, want_p=False, want_argmax=True)         # no context manager: the product's own routing
-    npan, nsecond = ops.classify_panel_stats()
+    npan, nsecond, ntiles2 = ops.classify_panel_stats(tiles=True)
     assert npan == (Q + 255) // 256, f"the fused row-panel kernel did not take the call ({npan} panels counted)"
+    # a second pass walks only the class tiles that hold a bound its panel could not beat (round 6): on this split fewer than all eight; and the merge of its
+    # result with the candidates is the argmax of the WHOLE second pass (mode 2: forced over every tile) and of two passes without candidates (mode 1), bit for bit
+    observe(f"C3 full size, {'structured' if structured else 'structureless'}: class tiles walked per second pass (of 8)", ntiles2 / max(nsecond, 1), 8.0)
+    assert nsecond <= ntiles2 <= 8 * nsecond
+    for mode in (1, 2):
+        with ops.classify_panel_passes(mode):
+            _, am_m, _, _ = ops.classify(q, zi, zt, alpha, beta, want_p=False, want_argmax=True)
+        assert torch.equal(am, am_m), (mode, int((am != am_m).sum()))
     observe(f"C3 full size, default routing, {'structured' if structured else 'structureless'} queries: fraction of panels that needed the second pass", nsecond / npan, 1.0)
     if structured:
         assert nsecond < npan // 2               # class-structured rows: most panels are proven by their candidates (this split: 23 of 196 are not)
