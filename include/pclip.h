@@ -117,7 +117,7 @@ int pclip_classify_panel_passes(int mode);
 int pclip_classify_panel_stats(int* out3, int reset);
 
 /* One-launch classification for mid-sized class counts (csrc/pclip_classify_mid.hip; utils.py:225-244 + main.py:190): pclip_classify_f16 takes it by itself for
- * 32 < N <= 256 with both banks, p and / or argmax (no top-k), Q N <= 2e6.  mode 1 = that routing (default; env PCLIP_CLASSIFY_MID), 2 = every shape the kernel can
+ * 16 < N <= 256 with both banks, D % 128 == 0, p and / or argmax (no top-k), Q N <= 2e6.  mode 1 = that routing (default; env PCLIP_CLASSIFY_MID), 2 = every shape the kernel can
  * run (tests), 0 = off (two stages), < 0 = query only.  Returns the previous setting (-1 = not decided yet). */
 int pclip_classify_mid_config(int mode);
 

@@ -544,6 +544,9 @@ extern "C" int pclip_classify_f16(const void* q, const void* zi, const void* zt,
     const size_t need = pclip_workspace_bytes(PCLIP_OP_CLASSIFY, Q, N, D);
     if (ws_bytes < need) { pclip_set_error("pclip_classify_f16: workspace %zu < %zu", ws_bytes, need); return PCLIP_E_WORKSPACE; }
     if (Q == 0) return PCLIP_OK;
+    // mid-sized class counts (32 < N <= 256; tests / probes: any N <= 256), p and / or argmax: one launch, norms in-kernel (pclip_classify_mid.hip).  PCLIP_CLASSIFY_MID=0: off.
+    if (q && zi && (p || argmax) && pclip_classify_mid_applies(Q, N, D, zt != nullptr, topk_p || topk_i || k > 0))
+        return pclip_classify_mid_launch(q, zi, zt, Q, N, D, alpha, one_minus_alpha, beta, p, argmax, (hipStream_t)stream);
     {   // small class counts: one launch (env PCLIP_CLASSIFY_SMALL=0 switches it off)
         static int mode = -1, cus = 0;
         if (mode < 0) {
@@ -564,9 +567,6 @@ extern "C" int pclip_classify_f16(const void* q, const void* zi, const void* zt,
 #undef PCLIP_SMALL
         }
     }
-    // mid-sized class counts (32 < N <= 256), p and / or argmax: one launch, norms in-kernel (pclip_classify_mid.hip).  PCLIP_CLASSIFY_MID=0: two stages.
-    if (q && zi && (p || argmax) && pclip_classify_mid_applies(Q, N, D, zt != nullptr, topk_p || topk_i || k > 0))
-        return pclip_classify_mid_launch(q, zi, zt, Q, N, D, alpha, one_minus_alpha, beta, p, argmax, (hipStream_t)stream);
     SqWs w = carve_sq(ws, Q, N);
     // large class counts, argmax only: the fused row-panel kernel (pclip_classify_panel.hip) — no distance rows in HBM.  PCLIP_CLASSIFY_PANEL=0: two stages.
     if (zt && argmax && !p && !topk_p && !topk_i && q && zi && pclip_classify_panel_applies(Q, N, D, alpha, one_minus_alpha, beta) &&

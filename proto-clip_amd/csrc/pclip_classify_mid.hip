@@ -14,19 +14,28 @@
 // What bounds it: a workgroup streams both banks (2 N D 2 bytes: 410 KB for Caltech-101 / RN50, 608 KB for FewSOL-198 / ViT-L/14) through its CU's vector-memory
 // path whatever the number of queries — measured 25 B/clk per CU with full-line loads (14 B/clk in the MFMA operand layout): 7 / 10 us of the kernel's 12.6 / 15.9 us
 // (tools/mid_probe.py, profiles/r06_mid_probe.txt); the rest is the launch (~2 us) and the correctly rounded sqrt / exp / division chains of the softmax.
-#include "pclip_common.h"
+#include "pclip_gemm.h"
 #include "pclip_classify_small.h"
 #include <stdlib.h>
 #include <type_traits>
 
 namespace {
 
+#ifndef PCLIP_MID_DMA
+#define PCLIP_MID_DMA 1          // bank rows by LDS-DMA into a wave-private ring (0: through registers + ds_write, the first form; A/B tools/mid_probe.py)
+#endif
 constexpr int MID_U = 4;                                                            // U: k-steps (32 wide) per register buffer = 128 of D (generic-width path)
 
-// LDS: the query group [16][D] fp16 | red [2 banks][4 slots][16 queries][2] fp32 | xch [4 slots][TPW * 4][64] fp32 | best [4 slots][16][2] | per wave two
-// [16 rows][128 B] transposition buffers
-__host__ __device__ constexpr size_t classify_mid_lds(int D, int tpw, int sl) {
-    return (size_t)16 * D * 2 + 2 * sl * 16 * 2 * 4 + (size_t)sl * tpw * 4 * 64 * 4 + sl * 16 * 2 * 4 + 2 * sl * 2 * 2048;
+// slots of a wave's private ring of [16 rows][128 B] blocks: LDS-DMA form = blocks in flight + 1 — eight waves: 3 + 1 (64 KB: two workgroups per CU at D = 512, which
+// is what a call with more query groups than CUs runs on), sixteen waves: 2 + 1 (96 KB); deeper rings (7 + 1 / 3 + 1 = 128 KB) measured the same single-group latency
+// (14.5 vs 14.6 us at FewSOL-198's size) and cost the second resident workgroup (N = 64, Q = 20 000: 25.2 vs 18.9 us).  The softmax's exchange buffers alias the ring,
+// which is dead by then.  Register form = 2.
+__host__ __device__ constexpr int mid_ring_slots(int sl) { return PCLIP_MID_DMA ? (sl == 8 ? 3 : 4) : 2; }
+// LDS: the query group [16][D] fp16 | then EITHER the waves' rings (main loop) OR red [2 banks][SL][16 queries][2] fp32 | xch [SL][TPW * 4][64] fp32 |
+// best [SL][16][2] (softmax: behind a barrier)  (the rings exist for the unrolled widths only: D = 512 / 768 / 1024)
+__host__ __device__ constexpr size_t classify_mid_lds(int D, int tpw, int sl, bool ring) {
+    const size_t aux = 2 * sl * 16 * 2 * 4 + (size_t)sl * tpw * 4 * 64 * 4 + sl * 16 * 2 * 4, rings = ring ? (size_t)2 * sl * mid_ring_slots(sl) * 2048 : 0;
+    return (size_t)16 * D * 2 + (aux > rings ? aux : rings);
 }
 
 // TPW: class tiles per wave (ceil(ceil(N / 16) / 4): 1 .. 4).  NCH: D / 128 when it is a compile-time constant (4 / 6 / 8: D = 512 / 768 / 1024 — the loop over the
@@ -49,7 +58,7 @@ __global__ __launch_bounds__(2 * SL * 64) void classify_mid_kernel(const half_t*
     float* red = reinterpret_cast<float*>(smem + 16 * qstride);                        // [bank][slot][query][2]
     float* xch = red + 2 * MID_SLOTS * 16 * 2;                                         // [slot][TPW * 4][64]
     float* bst = xch + MID_SLOTS * TPW * 4 * 64;                                       // [slot][query][2]
-    char* tbuf = reinterpret_cast<char*>(bst + MID_SLOTS * 16 * 2) + wave * 2 * 2048;  // this wave's two transposition buffers
+    char* tbuf = smem + 16 * qstride + wave * mid_ring_slots(SL) * 2048;               // this wave's private ring of transposition blocks (aliases red / xch / bst)
     const half_t* z = bank ? zt : zi;
     const int cls0 = 4 * kg;
     const int cpr = D >> 3;                                                            // 16-byte chunks per query row; 16 cpr = 2 D chunks per group, D / 256 per thread
@@ -112,9 +121,67 @@ __global__ __launch_bounds__(2 * SL * 64) void classify_mid_kernel(const half_t*
             // (tools/mid_probe.py: one workgroup, 608 KB, 17.8 us; the vector-memory path pays per line touched).  Each wave transposes its blocks — 16 classes x 64 k:
             // two loads — through two private 2 KB LDS buffers (pgemm's swizzle: chunk ^ ((row >> 1) & 7), conflict-free for both patterns); LDS operations of one wave
             // execute in order, so the block loop has no barrier.  Blocks b = kb * TPW + i (k-block kb of the wave's tile i), PF blocks of loads in flight.
-            constexpr int NKB = NCH * 2, NBLK = NKB * TPW, PF = SL == 8 ? (TPW == 1 ? 3 : 4) : 8;                // (sixteen waves: 128 registers per lane)
-            half8_t pre[PF][2];
+            constexpr int NKB = NCH * 2, NBLK = NKB * TPW;
             const int lrow = lane >> 3, lch = lane & 7;
+            int roff[2];                                                               // read offsets of the lane's two fragments (k-steps 0 / 1 of a block)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) roff[j] = qr * 128 + (((j * 4 + kg) ^ ((qr >> 1) & 7)) << 4);
+            auto block_math = [&](const char* tb, int kb, int i) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const half8_t zf = *reinterpret_cast<const half8_t*>(tb + roff[s2]);
+                    const int ch = (kb * 2 + s2) * 4 + kg;
+                    const half8_t qf = *reinterpret_cast<const half8_t*>(qrowl + ((ch ^ qr) << 4));
+                    if (i == 0) qs = sq8(qf, qs);
+                    znp[i] = sq8(zf, znp[i]);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zf, qf, acc[i], 0, 0, 0);
+                }
+            };
+#if PCLIP_MID_DMA
+            // LDS-DMA form: a block's two pieces (8 rows x 128 B each) go straight from L2 into the wave's ring — no registers, no ds_write (13 LDS cycles per
+            // kilobyte on the store path).  The swizzle sits on the SOURCE side (lane = LDS row l >> 3, LDS chunk l & 7 fetches source chunk (l & 7) ^ key(row):
+            // pgemm::stage_tile's addressing), the hardware places lane l at base + 16 l.  PFD blocks in flight; block b + PFD lands in the slot block b - 1 was read
+            // from (its fragments are in registers: the MFMAs that consumed them precede the request).  Every wait is the wave's own counted vmcnt — the ring is private.
+            constexpr int PFD = mid_ring_slots(SL) - 1, NSLOT = PFD + 1;
+            const half_t* zsrc[TPW][2];
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    int r = lrow + 8 * j;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("" : "+v"(r));                                         // opaque: see zrow
+#endif
+                    const int c = (slot + MID_SLOTS * i) * 16 + r;
+                    zsrc[i][j] = z + (size_t)(c < N ? c : N - 1) * D + ((lch ^ ((r >> 1) & 7)) << 3);
+                }
+            auto request = [&](int b) {
+                const int kb = b / TPW, i = b % TPW;
+                char* dst = tbuf + (b % NSLOT) * 2048;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(zsrc[i][j] + kb * 64), (pgemm::lds_ptr_t)(dst + j * 1024), 16, 0, 0);
+            };
+#pragma unroll
+            for (int b = 0; b < PFD && b < NBLK; ++b) request(b);
+            // (plain loads behind the first blocks' requests: hipcc waits for them with vmcnt(0), i.e. for those blocks too — which block 0 needs anyway: ONE round trip)
+            stage_q(std::integral_constant<int, (NCH * 256 + MID_WAVES * 64 - 1) / (MID_WAVES * 64)>{});      // 2 D chunks over the workgroup's threads
+            pgemm::lds_barrier();                                                      // the query rows are staged (LDS-only: the first blocks stay in flight)
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) {
+                constexpr int dummy = 0; (void)dummy;
+                const int younger = (NBLK - 1 - b < PFD - 1 ? NBLK - 1 - b : PFD - 1) * 2;     // pieces requested behind block b's
+                if (younger >= 12) pgemm::wait_vm<12>(); else if (younger == 10) pgemm::wait_vm<10>(); else if (younger == 8) pgemm::wait_vm<8>(); else if (younger == 6) pgemm::wait_vm<6>();
+                else if (younger == 4) pgemm::wait_vm<4>(); else if (younger == 2) pgemm::wait_vm<2>(); else pgemm::wait_vm<0>();
+                asm volatile("" ::: "memory");
+                block_math(tbuf + (b % NSLOT) * 2048, b / TPW, b % TPW);
+                __builtin_amdgcn_sched_barrier(0);
+                if (b + PFD < NBLK) request(b + PFD);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#else
+            constexpr int PF = SL == 8 ? (TPW == 1 ? 3 : 4) : 8;                       // (sixteen waves: 128 registers per lane)
+            half8_t pre[PF][2];
             const half_t* zsrc[TPW][2];                                                // the lane's source rows (opaque: see zrow)
 #pragma unroll
             for (int i = 0; i < TPW; ++i)
@@ -131,13 +198,11 @@ __global__ __launch_bounds__(2 * SL * 64) void classify_mid_kernel(const half_t*
 #pragma unroll
                 for (int j = 0; j < 2; ++j) pre[b % PF][j] = ld_half8(zsrc[i][j] + kb * 64);
             };
-            // write offsets of the lane's two pieces, read offsets of its two fragments (k-steps 0 / 1 of a block)
-            int woff[2], roff[2];
+            int woff[2];                                                               // write offsets of the lane's two pieces
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int r = lrow + 8 * j;
                 woff[j] = r * 128 + ((lch ^ ((r >> 1) & 7)) << 4);
-                roff[j] = qr * 128 + (((j * 4 + kg) ^ ((qr >> 1) & 7)) << 4);
             }
 #pragma unroll
             for (int b = 0; b < PF && b < NBLK; ++b) request(b);
@@ -145,24 +210,16 @@ __global__ __launch_bounds__(2 * SL * 64) void classify_mid_kernel(const half_t*
             __syncthreads();
 #pragma unroll
             for (int b = 0; b < NBLK; ++b) {
-                const int kb = b / TPW, i = b % TPW;
                 char* tb = tbuf + (b & 1) * 2048;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) *reinterpret_cast<half8_t*>(tb + woff[j]) = pre[b % PF][j];
                 __builtin_amdgcn_sched_barrier(0);
                 if (b + PF < NBLK) request(b + PF);
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const half8_t zf = *reinterpret_cast<const half8_t*>(tb + roff[s2]);
-                    const int ch = (kb * 2 + s2) * 4 + kg;
-                    const half8_t qf = *reinterpret_cast<const half8_t*>(qrowl + ((ch ^ qr) << 4));
-                    if (i == 0) qs = sq8(qf, qs);
-                    znp[i] = sq8(zf, znp[i]);
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zf, qf, acc[i], 0, 0, 0);
-                }
+                block_math(tb, b / TPW, b % TPW);
                 __builtin_amdgcn_sched_barrier(0);
             }
+#endif
         } else {
             half8_t za[U][TPW], zb[U][TPW];
             load(za, 0);
@@ -182,6 +239,7 @@ __global__ __launch_bounds__(2 * SL * 64) void classify_mid_kernel(const half_t*
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (NCH > 0) pgemm::lds_barrier();                                              // every wave is through with its ring: the exchange buffers below alias it
         // ---- norms into the accumulator layout, cdist epilogue (classify_small's expressions)
         qs += lane_xor<16>(qs);
         qs += lane_xor<32>(qs);
@@ -295,10 +353,10 @@ __global__ __launch_bounds__(2 * SL * 64) void classify_mid_kernel(const half_t*
 template <int TPW, int NCH, int SL>
 int launch_mid2(const void* q, const void* zi, const void* zt, int Q, int N, int D, float alpha, float oma, float beta, float* p, int32_t* argmax, int cus,
                 hipStream_t s) {
-    const size_t lds = classify_mid_lds(D, TPW, SL);
+    const size_t lds = classify_mid_lds(D, TPW, SL, NCH > 0);
     static DevOnce attr;
     if (!attr.done()) {
-        if (hipFuncSetAttribute((const void*)classify_mid_kernel<TPW, NCH, SL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)classify_mid_lds(2048, TPW, SL)) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)classify_mid_kernel<TPW, NCH, SL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)classify_mid_lds(NCH > 0 ? NCH * 128 : 2048, TPW, SL, NCH > 0)) != hipSuccess) {
             pclip_set_error("pclip_classify_f16: cannot raise the dynamic LDS limit (mid-N kernel)");
             return PCLIP_E_LAUNCH;
         }
@@ -331,14 +389,17 @@ extern "C" int pclip_classify_mid_config(int mode) {
     return before;
 }
 
-// Shapes the one-launch mid-N kernel takes: both banks, p and / or argmax (top-k goes to the two stages), 32 < N <= 256, D a multiple of 128 up to 2048.  Routed
+// Shapes the one-launch mid-N kernel takes: both banks, p and / or argmax (top-k goes to the other routes), N <= 256, D a multiple of 128 up to 2048.  Routed
 // by size: a workgroup streams both banks per 16 queries, so the kernel's time grows with Q / (16 x 2 CUs) bank passes where the two stages amortise the banks
 // over 128 x 128 tiles — beyond Q N ~ 2e6 the two stages (or, from 2e6 x tiles - 1e6, the fused row panels) take over (tools/small_bench.py).
 bool pclip_classify_mid_applies(int Q, int N, int D, bool has_zt, bool topk) {
     if (g_mid_mode < 0) { const char* e = getenv("PCLIP_CLASSIFY_MID"); g_mid_mode = e ? atoi(e) : 1; if (g_mid_mode < 0 || g_mid_mode > 2) g_mid_mode = 1; }
     if (!g_mid_mode || !has_zt || topk) return false;
-    if (!(N > 32 && N <= 256 && D >= 128 && D % 128 == 0 && D <= 2048 && Q >= 1)) return false;
-    return g_mid_mode == 2 || (double)Q * (double)N <= 2.0e6;
+    if (!(N >= 1 && N <= 256 && D >= 128 && D % 128 == 0 && D <= 2048 && Q >= 1)) return false;
+    if (g_mid_mode == 2) return true;
+    // N <= 16 stays with classify_small (ONE tile of bank fragments per wave: EuroSAT 6.4 vs 8.6 us, N = 10 / D = 1024 / Q = 8100: 9.6 vs 14.2); from two tiles on this
+    // kernel measures faster (N = 17, D = 512, Q = 300: 5.5 vs 8.5 us; N = 32, Q = 4000: 5.9 vs 9.8; N = 24, D = 1024, Q = 20 000: 31.3 vs 37.2) — tools/mid_probe.py
+    return N > 16 && (double)Q * (double)N <= 2.0e6;
 }
 
 int pclip_classify_mid_launch(const void* q, const void* zi, const void* zt, int Q, int N, int D, float alpha, float oma, float beta, float* p, int32_t* argmax,

@@ -190,28 +190,29 @@ def test_classify_single_launch_small_N(ops, Q, N, D, alpha, beta):
     """N <= 64 takes the one-launch kernel (classify_small_kernel: banks in LDS, a wave per 16 queries) for N <= 32 by default and
     for every N <= 64 with PCLIP_CLASSIFY_SMALL=2: same results as the two-stage path (distance rows + softmax pass) up to fp32
     summation order, p within 1e-5 of the oracle, top-1 / top-k identical wherever the runner-up is not within 1e-6."""
-    q = po.l2norm_rows(torch.from_numpy(synth.normal((Q, D), 21, 0)).half())
-    zi = po.l2norm_rows(torch.from_numpy(synth.normal((N, D), 21, 1)).half() + 0.3 * q[:1])
-    zt = (po.l2norm_rows(torch.from_numpy(synth.normal((N, D), 21, 2)).half()).float() * 1.2).half()    # non-unit bank
-    k = min(3, N)
-    p, am, tp, ti = ops.classify(dev(q), dev(zi), dev(zt), alpha, beta, want_p=True, want_argmax=True, topk=k)
-    p_or = po.P(q, zi, zt, alpha, beta)
-    assert (p.cpu() - p_or).abs().max().item() <= 1e-5
-    top2 = p_or.topk(min(2, N), dim=1)[0]
-    clear = (top2[:, 0] - top2[:, -1] > 1e-6) if N > 1 else torch.ones(Q, dtype=torch.bool)
-    assert torch.equal(am.cpu().long()[clear], p_or.max(1)[1][clear])
-    assert torch.equal(p.cpu().max(1)[1], am.cpu().long())                        # argmax of the p it wrote: first index on ties
-    rv, ri = p_or.topk(k, dim=1)
-    torch.testing.assert_close(tp.cpu(), rv, rtol=0, atol=1e-5)
-    assert torch.equal(tp.cpu()[:, 0], p.cpu().max(1)[0])
-    assert (ti.cpu() == ri).float().mean().item() > 0.99
-    _, am_only, _, _ = ops.classify(dev(q), dev(zi), dev(zt), alpha, beta, want_p=False, want_argmax=True)
-    assert torch.equal(am_only, am)
-    if D % 64 == 0:                                                                # the two-stage entry points need D % 64 == 0
-        d2i, d2t, _ = ops.sqdist(dev(q), dev(zi), dev(zt))
-        p2, am2, _, _ = ops.fuse_probs(d2i, d2t, N, alpha, beta, want_p=True, want_argmax=True)
-        assert (p - p2).abs().max().item() <= 2e-6
-        assert (am != am2).sum().item() <= (~clear).sum().item()
+    with ops.classify_mid(0):                                                      # this is classify_small's test: the mid-N kernel (which takes N > 16 by default) is tested below
+        q = po.l2norm_rows(torch.from_numpy(synth.normal((Q, D), 21, 0)).half())
+        zi = po.l2norm_rows(torch.from_numpy(synth.normal((N, D), 21, 1)).half() + 0.3 * q[:1])
+        zt = (po.l2norm_rows(torch.from_numpy(synth.normal((N, D), 21, 2)).half()).float() * 1.2).half()    # non-unit bank
+        k = min(3, N)
+        p, am, tp, ti = ops.classify(dev(q), dev(zi), dev(zt), alpha, beta, want_p=True, want_argmax=True, topk=k)
+        p_or = po.P(q, zi, zt, alpha, beta)
+        assert (p.cpu() - p_or).abs().max().item() <= 1e-5
+        top2 = p_or.topk(min(2, N), dim=1)[0]
+        clear = (top2[:, 0] - top2[:, -1] > 1e-6) if N > 1 else torch.ones(Q, dtype=torch.bool)
+        assert torch.equal(am.cpu().long()[clear], p_or.max(1)[1][clear])
+        assert torch.equal(p.cpu().max(1)[1], am.cpu().long())                        # argmax of the p it wrote: first index on ties
+        rv, ri = p_or.topk(k, dim=1)
+        torch.testing.assert_close(tp.cpu(), rv, rtol=0, atol=1e-5)
+        assert torch.equal(tp.cpu()[:, 0], p.cpu().max(1)[0])
+        assert (ti.cpu() == ri).float().mean().item() > 0.99
+        _, am_only, _, _ = ops.classify(dev(q), dev(zi), dev(zt), alpha, beta, want_p=False, want_argmax=True)
+        assert torch.equal(am_only, am)
+        if D % 64 == 0:                                                                # the two-stage entry points need D % 64 == 0
+            d2i, d2t, _ = ops.sqdist(dev(q), dev(zi), dev(zt))
+            p2, am2, _, _ = ops.fuse_probs(d2i, d2t, N, alpha, beta, want_p=True, want_argmax=True)
+            assert (p - p2).abs().max().item() <= 2e-6
+            assert (am != am2).sum().item() <= (~clear).sum().item()
 
 
 @pytest.mark.parametrize("Q,N,D", [(2465, 100, 1024), (666, 198, 768), (32, 198, 768), (3669, 37, 512), (1692, 47, 512), (17, 33, 128), (5000, 256, 512), (100, 129, 384),
