@@ -106,6 +106,13 @@ int pclip_classify_f16(const void* q, const void* zi, const void* zt, int Q, int
                        float one_minus_alpha, float beta, float* p, int32_t* argmax, float* topk_p,
                        int32_t* topk_i, int k, void* ws, size_t ws_bytes, pclip_stream_t stream);
 
+/* The route pclip_classify_f16 takes for a call of this shape under the current settings: 0 = two stages (pclip_sqdist_f16 + pclip_fuse_probs), 1 = one launch for
+ * small class counts (N <= 16; N <= 32 with top-k), 2 = one launch for 16 < N <= 256, 3 = fused row panels (argmax only, Q N large).  The routes agree with the
+ * reference's p to 1e-5 and with each other up to fp32 summation order: a query whose top two classes are closer than ~1e-6 in p may get either of them depending
+ * on the route, i.e. on the batch it is classified in.  Callers that need one arithmetic for every batch size force the two stages (pclip_classify_mid_config(0),
+ * pclip_classify_panel_config(0), env PCLIP_CLASSIFY_SMALL=0).  ws_bytes: the workspace the call would pass. */
+int pclip_classify_route(int Q, int N, int D, float alpha, float one_minus_alpha, float beta, int has_zt, int want_p, int want_argmax, int topk, size_t ws_bytes);
+
 /* The fused row-panel classification walks the class tiles ONCE where it can prove the result (csrc/pclip_classify_panel.hip: per group of 16 classes the nearest
  * class of each bank is kept as a candidate, everybody else is bounded through the group's second smallest distances; a panel whose rows all satisfy
  * max bound < best candidate is finished from the candidates — the very argmax of the second pass — and only the others walk the tiles again).

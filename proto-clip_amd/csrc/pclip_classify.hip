@@ -582,6 +582,22 @@ extern "C" int pclip_classify_f16(const void* q, const void* zi, const void* zt,
     return pclip_fuse_probs(d2i, d2t, Q, N, ldd, alpha, one_minus_alpha, beta, p, argmax, topk_p, topk_i, k, stream);
 }
 
+// Which kernels pclip_classify_f16 takes for a call of this shape under the current settings (the routes differ in fp32 summation order — the same
+// query can get a different argmax at a near-tie of p (margin < 1e-6) depending on the batch it travels in — so callers can ask): 0 two stages (pclip_sqdist_f16 +
+// pclip_fuse_probs: torch.cdist's arithmetic operation for operation), 1 one launch for N <= 16 / top-k up to N = 32 (classify_small), 2 one launch for 16 < N <= 256
+// (classify_mid), 3 fused row panels (argmax only, large Q N; distances without cdist's sqrt round trip unless PCLIP_CLASSIFY_PANEL_EXACT=1).
+extern "C" int pclip_classify_route(int Q, int N, int D, float alpha, float one_minus_alpha, float beta, int has_zt, int want_p, int want_argmax, int topk,
+                                    size_t ws_bytes) {
+    if (Q <= 0 || N <= 0) return 0;
+    if ((want_p || want_argmax) && pclip_classify_mid_applies(Q, N, D, has_zt != 0, topk > 0)) return 2;
+    static const int small_mode = getenv("PCLIP_CLASSIFY_SMALL") ? atoi(getenv("PCLIP_CLASSIFY_SMALL")) : 1;
+    if (small_mode > 0 && N <= 32 && D > 0 && D % 32 == 0 && topk >= 0 && topk <= N && topk <= 16) return 1;
+    if (has_zt && want_argmax && !want_p && topk == 0 && pclip_classify_panel_applies(Q, N, D, alpha, one_minus_alpha, beta) &&
+        ws_bytes >= carve_sq(nullptr, Q, N).bytes + pclip_classify_panel_workspace(Q, N, D))
+        return 3;
+    return 0;
+}
+
 // Test entry: the distances the fused row-panel kernel forms for its first tile (query rows 0 .. 255 x classes 0 .. 127 of both banks, [2][256][128] fp32): exact != 0
 // — with torch.cdist's sqrt -> square round trip — they must be the bits pclip_sqdist_f16 writes, exact == 0 (the product's arithmetic) within one fp32 ulp of them.
 extern "C" int pclip_classify_panel_dump_f16(const void* q, const void* zi, const void* zt, int Q, int N, int D, float* dump, int exact, void* ws, size_t ws_bytes,

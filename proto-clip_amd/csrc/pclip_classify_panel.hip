@@ -216,8 +216,11 @@ __global__ __launch_bounds__(512, 2) void classify_panel_kernel(const half_t* __
                     }
                     const float m2 = fminf(mn[k][bank], t);
                     float s = sm[k][bank] * __builtin_amdgcn_exp2f((m2 - mn[k][bank]) * w);
+                    // exponent argument as ONE fma per element (m2 w - d w; round 6: was a subtraction and a multiplication — 2 of the ~14 VALU slots an element
+                    // of this pass costs): the statistics S change in their last bits only, and every later expression (proof, second pass) reads S through rowc
+                    const float m2w = m2 * w, nw = -w;
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) s += __builtin_amdgcn_exp2f((m2 - d[bank][c]) * w);
+                    for (int c = 0; c < 16; ++c) s += __builtin_amdgcn_exp2f(__builtin_fmaf(d[bank][c], nw, m2w));
                     mn[k][bank] = m2;
                     sm[k][bank] = s;
                 }

@@ -220,6 +220,18 @@ def proto_classify(mem, N: int, K: int, q, zt, alpha: float, beta: float, per_sh
     return (zi,) + tuple(classify(q, zi, zt, alpha, beta, want_p=want_p, want_argmax=want_argmax, topk=topk))
 
 
+CLASSIFY_ROUTES = ("two stages", "one launch, small N", "one launch, mid N", "fused row panels")
+
+
+def classify_route(Q: int, N: int, D: int, alpha: float, beta: float, want_p=False, want_argmax=True, topk: int = 0, has_zt: bool = True) -> str:
+    """The kernels `classify` takes for a call of this shape under the current settings (pclip_classify_route).  The routes differ in fp32 summation order only —
+    at a near-tie of p (top-2 margin < ~1e-6) the argmax may depend on the route, i.e. on the batch size; `classify_two_stage()` pins one arithmetic."""
+    a32, oma32 = float(np.float32(alpha)), float(np.float32(1 - float(alpha)))
+    r = _lib.load().pclip_classify_route(Q, N, D, a32, oma32, float(np.float32(beta)), int(has_zt), int(bool(want_p)), int(bool(want_argmax)), topk,
+                                         _lib.workspace_bytes(_lib.OP_CLASSIFY, Q, N, D))
+    return CLASSIFY_ROUTES[r]
+
+
 class classify_mid:
     """`with ops.classify_mid(mode):` — routing of the one-launch mid-N kernel (32 < N <= 256): 0 off (two stages), 1 by size (default), 2 every shape it can run."""
     def __init__(self, mode: int):

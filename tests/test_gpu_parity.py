@@ -251,6 +251,20 @@ def test_classify_one_launch_mid_N(ops, Q, N, D, alpha, beta):
         torch.testing.assert_close(tp.cpu(), rv, rtol=0, atol=1e-5)
 
 
+def test_classify_route_is_reported(ops):
+    """ops.classify_route names the kernels a call takes (the routes differ in summation order, callers can ask / pin)."""
+    assert ops.classify_route(8100, 10, 512, 1.0, 0.7) == "one launch, small N"
+    assert ops.classify_route(2465, 100, 1024, 0.8, 9.0) == "one launch, mid N"
+    assert ops.classify_route(666, 198, 768, 0.2, 12.0, want_p=True) == "one launch, mid N"
+    assert ops.classify_route(50000, 1000, 512, 0.5, 12.0) == "fused row panels"
+    assert ops.classify_route(50000, 1000, 512, 0.5, 12.0, want_p=True) == "two stages"
+    assert ops.classify_route(50000, 1000, 512, 1.2, 12.0) == "two stages"                    # alpha outside [0, 1]: the candidate proof does not apply
+    assert ops.classify_route(1024, 1000, 512, 0.5, 12.0) == "two stages"                      # the bench's step: too few panels for the fused kernel
+    assert ops.classify_route(300, 100, 1024, 0.8, 9.0, topk=5) == "two stages"
+    with ops.classify_two_stage():
+        assert ops.classify_route(2465, 100, 1024, 0.8, 9.0) == "two stages" and ops.classify_route(50000, 1000, 512, 0.5, 12.0) == "two stages"
+
+
 def test_classify_mid_default_routing_and_graph_replay(ops):
     """The product's own routing takes the one-launch kernel at the C1 / C5 shapes (no context manager), also inside a captured graph; a second launch on fresh
     queries leaves no state behind."""
