@@ -218,7 +218,11 @@ __global__ __launch_bounds__(512, 2) void classify_panel_kernel(const half_t* __
                     float s = sm[k][bank] * __builtin_amdgcn_exp2f((m2 - mn[k][bank]) * w);
                     // exponent argument as ONE fma per element (m2 w - d w; round 6: was a subtraction and a multiplication — 2 of the ~14 VALU slots an element
                     // of this pass costs): the statistics S change in their last bits only, and every later expression (proof, second pass) reads S through rowc
-                    const float m2w = m2 * w, nw = -w;
+                    // m2w = m2 w rounded DOWN (w >= 0, m2 >= 0): exact(-d w) + m2w <= 0 for every d >= m2, so no argument comes out positive — a lane group of padding
+                    // classes (d = m2 = 1e30) has a rounding gap of ~1e24 between the two products, and exp2(+1e24) is inf
+                    float m2w = m2 * w;
+                    if (__builtin_fmaf(m2, w, -m2w) < 0.f) m2w = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, m2w) - 1u);
+                    const float nw = -w;
 #pragma unroll
                     for (int c = 0; c < 16; ++c) s += __builtin_amdgcn_exp2f(__builtin_fmaf(d[bank][c], nw, m2w));
                     mn[k][bank] = m2;

@@ -2,7 +2,8 @@
 (csrc/pclip_gemm.h stress_jitter: every counted s_waitcnt vmcnt(N), every LDS-only barrier and every LDS-DMA burst of the persistent kernels first pauses its wave
 for 0 / 256 / 1024 cycles, pseudo-randomly per wave and call).  A wait that is a piece too weak or a barrier that does not cover a refill reads stale LDS in some
 launch; here every such kernel must reproduce the NORMAL library's bits, repeatedly: the eight-wave GEMM in every tile configuration (staggered refill, ring
-kernel, residual / QuickGELU epilogues), sqdist_big's norm strips, the fused row-panel classification, attention in
+kernel, residual / QuickGELU epilogues), sqdist_big's norm strips, the fused row-panel classification, the one-launch mid-N classification (wave-private LDS-DMA
+rings, counted per-wave waits), attention in
 every piece-count class (query-first and looping kernels, causal).  The four-wave asm loop has its own jittered variant (test_gpu_encoder.py)."""
 import ctypes
 import os
@@ -89,6 +90,29 @@ def test_sqdist_big_and_fused_classify_under_jitter(ops, slib):
                                      ws.numel(), _lib.stream())
         assert rc == 0, slib.pclip_last_error()
         assert torch.equal(am, am_ref)
+
+
+@pytest.mark.parametrize("Q,N,D", [(2465, 100, 1024), (666, 198, 768), (5000, 64, 512), (9000, 37, 512), (300, 256, 1024), (40, 129, 768)])
+def test_classify_mid_under_jitter(ops, slib, Q, N, D):
+    """The one-launch mid-N classification streams its bank rows by LDS-DMA into wave-private rings and waits with hand-counted vmcnt (csrc/pclip_classify_mid.hip):
+    in the stress build every counted wait and LDS barrier first pauses its wave at random — p and argmax must be the normal library's bits, launch after launch,
+    for the eight- and the sixteen-wave form, one and several query groups per workgroup."""
+    g = torch.Generator(device="cuda").manual_seed(Q + N + D)
+    nrm = torch.nn.functional.normalize
+    zi = nrm(torch.randn(N, D, device="cuda", generator=g), dim=-1).half()
+    zt = nrm(torch.randn(N, D, device="cuda", generator=g), dim=-1).half()
+    q = nrm(torch.randn(Q, D, device="cuda", generator=g) + 2 * zi[torch.arange(Q, device="cuda") % N].float(), dim=-1).half()
+    with ops.classify_mid(2):
+        p_ref, am_ref, _, _ = ops.classify(q, zi, zt, 0.5, 12.0, want_p=True, want_argmax=True)
+    ws = torch.empty(_lib.workspace_bytes(_lib.OP_CLASSIFY, Q, N, D), dtype=torch.uint8, device="cuda")
+    slib.pclip_classify_mid_config(2)
+    for rep in range(4):
+        p = torch.full((Q, N), float("nan"), device="cuda")
+        am = torch.full((Q,), -1, dtype=torch.int32, device="cuda")
+        rc = slib.pclip_classify_f16(_lib.ptr(q), _lib.ptr(zi), _lib.ptr(zt), Q, N, D, None, None, None, 0.5, 0.5, 12.0, _lib.ptr(p), _lib.ptr(am), None, None, 0,
+                                     _lib.ptr(ws), ws.numel(), _lib.stream())
+        assert rc == 0, slib.pclip_last_error()
+        assert torch.equal(p, p_ref) and torch.equal(am, am_ref), f"launch {rep}"
 
 
 @pytest.mark.parametrize("B,L,H,causal", [(64, 197, 12, False), (32, 257, 16, False), (128, 50, 12, False), (256, 77, 8, True), (16, 129, 12, False), (16, 224, 12, True),
