@@ -80,33 +80,47 @@ def step(st):
 
 
 def measure_gemm(st):
-    """The MFMA-GEMM launches of one step, timed WITHOUT per-launch event overhead (an event pair around every launch puts ~33 us of gap between
-    consecutive GEMMs — 31.4 ms of "GEMM time" where rocprofv3 sums the same kernels to 28.9 ms).  An instrumented step (outside the timed region) records every
-    `ops.gemm` call; calls are grouped by (M, N, K, epilogue); each group's FIRST call is then replayed `reps` times back to back between ONE pair of HIP events on the
-    launch stream (residual GEMMs into a scratch output, so the residual stream is not accumulated into).  Per-launch time of a group = elapsed / reps — the figure
-    `rocprofv3 --kernel-trace --stats` reports as that kernel's average (profiles/r06_bench_*_kernel_stats.csv); step total = sum over groups of calls x time."""
+    """The MFMA-GEMM launches of one step, timed IN the step by the kernels themselves.  Anything put between consecutive GEMMs — a HIP event pair
+    (round 5), a one-lane stamp kernel — costs ~33 us per GEMM (31.4 ms of "GEMM time" where rocprofv3 summed the same kernels to 28.9), and replaying a GEMM back
+    to back outside the step runs it at ANOTHER clock (the chip is at its power cap: a train of identical GEMMs holds a lower clock than the same GEMMs between
+    LayerNorm / attention launches: +10 % on one box, -1 % on another).  So the GEMM kernels carry a measurement hook (`pclip_gemm_timing`, csrc pgemm::time_begin /
+    time_end): with a slot pointer, every workgroup folds the device's constant 100 MHz counter into slot[0] (minimum = the launch's first instruction) and slot[1]
+    (maximum = its last) — the span `rocprofv3 --kernel-trace` reports as the kernel's duration, with nothing between the kernels.  An instrumented step (outside
+    the timed region, behind twelve plain steps so that the clock has settled) runs with the hook on; a call's time = the sum over its launches (a call whose
+    last round of tiles is split = two).
+    tools/roofline_check.py compares the line with the rocprofv3 summary of the same command (profiles/r06_roofline_check_*.txt)."""
     from proto_clip_amd import ops, _lib
+    lib = _lib.load()
     real = ops.gemm
     rec = []
+    dev = st["images"].device
+    NS = 1024
+    buf = torch.zeros(NS, 2, dtype=torch.int64, device=dev)
+    buf[:, 0] = torch.iinfo(torch.int64).max                    # begin words: minimum of non-negative 63-bit stamps
+    torch.cuda.synchronize()
 
-    def grab(a, w, bias=None, act=0, residual=None, out=None):
-        rec.append((a, w, bias, act, residual))
-        return real(a, w, bias, act, residual, out)
+    def timed(a, w, bias=None, act=0, residual=None, out=None):
+        i0 = lib.pclip_gemm_timing_count()
+        y = real(a, w, bias, act, residual, out)
+        rec.append(((a.shape[0], w.shape[0], a.shape[1], act, bias is not None, residual is not None), i0, lib.pclip_gemm_timing_count()))
+        return y
 
-    lib = _lib.load()
-    ops.gemm = grab
+    # The chip's DVFS loop needs ~0.2 s of load to settle (a first step after a pause runs ~10 % slow: tools/gemm4w_stamps.py met the same): twelve plain steps
+    # go ahead of the instrumented one in the same train of launches, no synchronisation in between (the hook is a host-side switch)
+    for _ in range(12):
+        step(st)
+    ops.gemm = timed
     n0 = lib.pclip_gemm_kernel_launches()
+    _lib.check(lib.pclip_gemm_timing(buf.data_ptr(), NS), "pclip_gemm_timing")
     try:
         step(st)
         torch.cuda.synchronize()
     finally:
+        lib.pclip_gemm_timing(None, 0)
         ops.gemm = real
     launches = lib.pclip_gemm_kernel_launches() - n0           # a call whose last round is split = two kernel launches
-    groups = {}
-    for a, w, bias, act, residual in rec:
-        key = (a.shape[0], w.shape[0], a.shape[1], act, bias is not None, residual is not None)
-        groups.setdefault(key, []).append((a, w, bias, act, residual))
-    W = st["model"].visual.width if hasattr(st["model"].visual, "width") else 0
+    t = buf.cpu().numpy()
+    W = getattr(st["model"].visual, "width", 0)
 
     def name_of(M, N, K, act, has_bias, has_res):
         if W and M > 4096:
@@ -114,42 +128,29 @@ def measure_gemm(st):
             if (N, K) == (W, W) and has_res: return "out_proj"
             if (N, K, act) == (4 * W, W, 1): return "c_fc"
             if (N, K) == (W, 4 * W) and has_res: return "c_proj"
-        return f"other {M}x{N}x{K}" + (" +gelu" if act == 1 else "") + (" +res" if has_res else "")
+        return "other"
 
-    per, total_ms, total_fl = {}, 0.0, 0.0
-    for key, calls in groups.items():
-        M, N, K, act, has_bias, has_res = key
-        a, w, bias, act, residual = calls[0]
-        out = torch.empty(M, N, dtype=torch.float16, device=a.device)
-        fl = gemm_flops(M, N, K)
-        reps = 10 if fl > 1e11 else 30
-        for _ in range(2):
-            real(a, w, bias, act, residual, out)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            real(a, w, bias, act, residual, out)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        nm = name_of(*key)
-        d = per.setdefault(nm, dict(calls=0, ms_per_step=0.0, flops_per_step=0.0))
-        d["calls"] += len(calls)
-        d["ms_per_step"] += ms * len(calls)
-        d["flops_per_step"] += fl * len(calls)
-        total_ms += ms * len(calls)
-        total_fl += fl * len(calls)
-    for d in per.values():
+    per, total_ms, total_fl, timed_launches = {}, 0.0, 0.0, 0
+    for key, i0, i1 in rec:
+        ms = sum(max(int(t[i][1] - t[i][0]), 0) for i in range(i0, i1)) * 1e-5           # 10 ns ticks -> ms
+        timed_launches += i1 - i0
+        fl = gemm_flops(*key[:3])
+        d = per.setdefault(name_of(*key), dict(calls=0, ms_per_step=0.0, flops_per_step=0.0))
+        d["calls"] += 1
+        d["ms_per_step"] += ms
+        d["flops_per_step"] += fl
+        total_ms += ms
+        total_fl += fl
+    for nm, d in per.items():
         d["avg_call_us"] = 1e3 * d["ms_per_step"] / d["calls"]
-        d["tflops"] = d["flops_per_step"] / (d["ms_per_step"] * 1e-3) / 1e12
-        d["frac"] = d["tflops"] / MFMA_PEAK_TFLOPS
+        if nm != "other":
+            d["tflops"] = d["flops_per_step"] / (d["ms_per_step"] * 1e-3) / 1e12
+            d["frac"] = d["tflops"] / MFMA_PEAK_TFLOPS
         d.pop("flops_per_step")
-    small = {k: v for k, v in per.items() if k.startswith("other")}
-    big = {k: v for k, v in per.items() if not k.startswith("other")}
-    if small:
-        big["other (patch embedding, class-row tail, projection)"] = dict(calls=sum(v["calls"] for v in small.values()), ms_per_step=sum(v["ms_per_step"] for v in small.values()))
+    if "other" in per:
+        per["other (patch embedding, class-row tail, projection)"] = per.pop("other")
     return dict(launches=launches, calls=len(rec), total_ms=total_ms, avg_us=1e3 * total_ms / max(launches, 1),
-                tflops=total_fl / (total_ms * 1e-3) / 1e12, flops=total_fl, per_variant=big)
+                tflops=total_fl / (total_ms * 1e-3) / 1e12, flops=total_fl, per_variant=per, timed_launches=timed_launches)
 
 
 def self_check(st, n=64):
@@ -564,7 +565,8 @@ def run(args, hooks, out=None):
                          "launches_per_step": gm["launches"], "avg_launch_us": gm["avg_us"],
                          "gemm_ms_per_step": gm["total_ms"], "algorithmic_gflop_per_step": gm["flops"] / 1e9,
                          "per_variant": gm.get("per_variant"),
-                         "method": "every distinct GEMM call of one instrumented step replayed 10 - 30 x back to back between ONE pair of HIP events on the launch stream (no per-launch event gap): avg_call_us is what rocprofv3 --stats reports as the kernel's average"},
+                         "timed_launches": gm.get("timed_launches"),
+                         "method": "the GEMM kernels' own measurement hook (pclip_gemm_timing): every workgroup of every GEMM launch of one instrumented step folds the device's 100 MHz counter into (min begin, max end) — the kernel's span as rocprofv3 --kernel-trace reports it, with nothing between the kernels"},
             "whole_path": {"note": "reference-equivalent = the FLOPs the REFERENCE module spends per image (every token through all 12 blocks); executed = what the HIP path runs "
                                    "(GEMM launches of the instrumented step + attention contractions + adapter + similarity: the last block works on the class rows only)",
                            "reference_equivalent_gflop_per_image": ref_gflop, "reference_equivalent_tflops": imgs_per_s / world * ref_gflop / 1e3,

@@ -35,6 +35,12 @@ int pclip_abi_version(void);
 const char* pclip_last_error(void);
 /* number of compute units of the current device (used by host code to size batches) */
 int pclip_device_cus(void);
+/* Measurement hook of the GEMM kernels (bench.py's roofline): buf = [nslots][2] unsigned 64-bit of device memory, begin words pre-set to ~0 and end words to 0
+ * by the caller; every GEMM kernel launch made while the buffer is set takes the next slot and its workgroups fold the device's constant 100 MHz counter
+ * (s_memrealtime) into it — slot[0] = first instruction of the launch, slot[1] = its last: the span rocprofv3 reports as the kernel's duration, taken inside the
+ * running step without a launch or event between the kernels.  pclip_gemm_timing(NULL, 0) switches it off (the product); pclip_gemm_timing_count() = slots taken. */
+int pclip_gemm_timing(void* buf, int nslots);
+int pclip_gemm_timing_count(void);
 /* cumulative number of GEMM KERNEL launches issued by pclip_gemm_f16 in this process (one call may be split into
  * two launches, see the dispatch in csrc/pclip_encoder.hip); bench.py uses the delta to quote per-launch figures */
 long pclip_gemm_kernel_launches(void);

@@ -42,6 +42,8 @@ _SIGS = {
     "pclip_classify_panel_passes": [c_int],
     "pclip_classify_panel_stats": [_P, c_int],
     "pclip_classify_panel_dump_f16": [_P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, c_size_t, _P],
+    "pclip_gemm_timing": [_P, c_int],
+    "pclip_gemm_timing_count": [],
     "pclip_classify_route": [c_int, c_int, c_int, c_float, c_float, c_float, c_int, c_int, c_int, c_int, c_size_t],
     "pclip_classify_mid_config": [c_int],
     "pclip_hp_sweep": [_P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, _P],

@@ -34,3 +34,4 @@ extern "C" int pclip_device_cus(void) {
     if (dev >= 0 && dev < 64) cache[dev].store(cus, std::memory_order_relaxed);
     return cus;
 }
+

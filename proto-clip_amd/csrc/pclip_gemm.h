@@ -107,6 +107,16 @@ __device__ __forceinline__ half8_t lds_frag(const char* lds_tile, int row, int k
     return *reinterpret_cast<const half8_t*>(lds_tile + row * ROW_BYTES + ((kc ^ swz_key(row)) << 4));
 }
 
+// Measurement hook of the GEMM kernels (bench.py's roofline; pclip_gemm_timing): with a slot pointer, every workgroup folds the device's constant 100 MHz counter
+// into slot[0] (minimum: the launch's first instruction) and slot[1] (maximum: its last) — the span rocprofv3 reports as the kernel's duration, taken INSIDE the
+// step, without a launch or an event between the kernels (either puts ~33 us between consecutive GEMMs).  A null pointer (the product) costs one scalar branch.
+__device__ __forceinline__ void time_begin(unsigned long long* slot) {
+    if (slot && threadIdx.x == 0) atomicMin(slot, (unsigned long long)wall_clock64());
+}
+__device__ __forceinline__ void time_end(unsigned long long* slot) {
+    if (slot && threadIdx.x == 0) atomicMax(slot + 1, (unsigned long long)wall_clock64());
+}
+
 // XCD-aware, bijective remap of a linear workgroup id (guide §5.5 T1).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;

@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <type_traits>
 
+unsigned long long* pclip_gemm_time_slot();       // the measurement hook's next slot, or null (defined below: pclip_gemm_timing)
+
 namespace {
 // ---- fast kernel: N % BN == 0, 16-byte aligned C rows, no residual -----------------------------------------
 // Persistent: one launch = at most `slots` resident workgroups; each walks output tiles round by round
@@ -22,7 +24,8 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
                                                                      const float* __restrict__ scale,
                                                                      const float* __restrict__ shift,
                                                                      half_t* Cout, int ldc, int tiles_n,
-                                                                     int ntiles, const half_t* residual = nullptr, int band = 0) {
+                                                                     int ntiles, const half_t* residual = nullptr, int band = 0,
+                                                                     unsigned long long* tslot = nullptr) {
     // ACT 5: relu(r16(r16(r16(acc) * scale + shift) + residual)) — bn3 + `out += identity` + ReLU of a bottleneck (clip/model.py:49-52)
     // in the epilogue of its conv3 GEMM; the residual rows are read row-major in the coalesced store pass.
     // ACT 6: r16(residual + r16(acc + bias)) — `x = x + attn(..)` / `x = x + mlp(..)` of a transformer block (clip/model.py:188-189)
@@ -36,6 +39,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     const int G = gridDim.x;
     int tile = pgemm::xcd_remap(blockIdx.x, G);
     if (tile >= ntiles) return;
+    pgemm::time_begin(tslot);                                                 // (measurement hook: null in the product)
     // Linear tile id -> (row block, column tile).  band == 0: column tiles fastest (a round covers whole rows of tiles).  band > 0
     // (PCLIP_GEMM_BAND, tools/ab_band.py): the output is walked in BANDS of `band` column tiles, row blocks fastest inside a band, so
     // that for half of the launch every XCD multiplies against the same `band` weight panels (N = 3072, band 6: 2.4 MB of the 4 MiB L2
@@ -215,6 +219,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
             });
         prev_full = full;
     }
+    pgemm::time_end(tslot);
 }
 
 // ---- 3x3 convolution (stride 1, pad 1, NHWC) + eval BatchNorm (+ReLU) as an implicit GEMM -----------------------------------
@@ -390,7 +395,7 @@ static int launch_fast2(const void* A, int lda, const void* B, int ldb, int M, i
     const bool rev = rev_mode == 1 || (rev_mode == 2 && K <= 1024);
     linear_fast_kernel<C, HAS_BIAS, ACT><<<grid, C::NTHREADS, LDS, s>>>(
         (const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi.bias, epi.scale, epi.shift, epi.C, epi.ldc, tiles_n, ntiles, epi.residual,
-        rev ? -1 : (tiles_n >= 8 ? band : 0));
+        rev ? -1 : (tiles_n >= 8 ? band : 0), pclip_gemm_time_slot());
     return pclip_check_launch("gemm_f16");
 }
 
@@ -420,6 +425,21 @@ static int launch_fast(const void* A, int lda, const void* B, int ldb, int M, in
 #define PCLIP_GEMM_4W_DEFAULT 1
 #endif
 static long g_gemm_launches = 0;
+// Timing buffer of the measurement hook (pgemm::time_begin / time_end): [nslots][2] unsigned 64-bit of device memory, begin slots pre-set to ~0, end slots to 0 by
+// the caller; every instrumented GEMM launch takes the next slot.  Null = off (the product).
+static unsigned long long* g_time_buf = nullptr;
+static int g_time_cap = 0, g_time_next = 0;
+unsigned long long* pclip_gemm_time_slot() {
+    if (!g_time_buf || g_time_next >= g_time_cap) return nullptr;
+    return g_time_buf + 2 * (size_t)g_time_next++;
+}
+extern "C" int pclip_gemm_timing(void* buf, int nslots) {
+    g_time_buf = (unsigned long long*)buf;
+    g_time_cap = buf ? nslots : 0;
+    g_time_next = 0;
+    return PCLIP_OK;
+}
+extern "C" int pclip_gemm_timing_count(void) { return g_time_next; }
 static int g_use4w = -1;                    // 256 x 256 tiles on the four-wave asm-loop kernel: -1 = PCLIP_GEMM_4W / the default, decided at the first launch
 extern "C" int pclip_gemm4w_config(int mode) {
     const int before = g_use4w;
@@ -573,9 +593,10 @@ __global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void linear_small_kernel(con
                                                                            half_t* Cout, int ldc,
                                                                            const float* __restrict__ scale,
                                                                            const float* __restrict__ shift,
-                                                                           const half_t* residual = nullptr) {
+                                                                           const half_t* residual = nullptr, unsigned long long* tslot = nullptr) {
     using C = CfgSplit;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    pgemm::time_begin(tslot);                                                 // (measurement hook: null in the product)
     const int tile = blockIdx.x / S, ks = blockIdx.x - tile * S;
     const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
     const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
@@ -631,6 +652,7 @@ __global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void linear_small_kernel(con
             }
             if (valid) st_half8(Cout + o, h);
         });
+        pgemm::time_end(tslot);
         return;
     }
     // 16x16x32 accumulator layout: element group (i, j, g) of a lane = row wm*64 + i*32 + (g>>1)*16 + (lane&15),
@@ -747,9 +769,10 @@ int launch_small_one(const half_t* A, int lda, const half_t* B, int ldb, int M, 
     if (int e = small_attr()) return e;
     const int tiles_n = N / CfgSplit::BN, grid = ceil_div(M, CfgSplit::BM) * tiles_n, steps = K / pgemm::BK;
     ++g_gemm_launches;
+    unsigned long long* tslot = pclip_gemm_time_slot();
 #define PCLIP_SMALL_LAUNCH(ACT)                                                                                                          \
     linear_small_kernel<ACT><<<grid, CfgSplit::NTHREADS, kSmallLds, s>>>(A, lda, B, ldb, M, N, K, tiles_n, 1, steps, nullptr, epi.bias, epi.C, \
-                                                                        epi.ldc, epi.scale, epi.shift, epi.residual)
+                                                                        epi.ldc, epi.scale, epi.shift, epi.residual, tslot)
     if (epi.act == 5) PCLIP_SMALL_LAUNCH(5);
     else if (epi.act == 6) PCLIP_SMALL_LAUNCH(6);
     else if (epi.act == 1) PCLIP_SMALL_LAUNCH(1);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Does the bench line's `roofline` follow from the rocprofv3 summary of the same command?  usage: roofline_check.py <bench.json> <kernel_stats.csv>
-Compares, per GEMM variant, the bench's avg_call_us (grouped back-to-back replays between one HIP-event pair) with rocprofv3's average duration of that kernel, and
+Compares, per GEMM variant, the bench's avg_call_us (the GEMM kernels' own begin / end stamps inside an instrumented step: pclip_gemm_timing) with rocprofv3's average duration of that kernel, and
 the step totals (sum of every GEMM kernel in the trace / steps traced)."""
 import csv, json, sys
 line = json.load(open(sys.argv[1]))
