@@ -412,10 +412,31 @@ def cpu_baseline(batch=64, budget_s=150.0):
             import shutil
             shutil.rmtree(d, ignore_errors=True)
     best = max(rates, key=rates.get)
+
+    def numa_note():
+        # which NUMA nodes the best configuration's CPU ranges fall on: worker i is pinned to logical CPUs [16 i, 16 i + 16)
+        try:
+            import glob
+            nodes = {}
+            for path in sorted(glob.glob("/sys/devices/system/node/node[0-9]*/cpulist")):
+                nid = int(path.split("node")[-1].split("/")[0])
+                cpus = set()
+                for part in open(path).read().strip().split(","):
+                    a, _, b = part.partition("-")
+                    cpus.update(range(int(a), int(b or a) + 1))
+                nodes[nid] = cpus
+            if not nodes:
+                return "NUMA layout not exposed"
+            where = [sorted({n for n, c in nodes.items() if c & set(range(i * best[1], (i + 1) * best[1]))}) for i in range(best[0])]
+            return (f"{len(nodes)} NUMA node(s) (" + "; ".join(f"node {n}: {len(c)} logical CPUs" for n, c in sorted(nodes.items())) + "); the best configuration's "
+                    f"{best[0]} x {best[1]} CPU ranges sit on node(s) " + ", ".join("+".join(map(str, w)) for w in where))
+        except Exception as e:
+            return f"NUMA layout unreadable ({type(e).__name__})"
+
     return dict(value=rates[best], unit="query images/sec", cores=best[0] * best[1], kind="port", processes=best[0], threads_per_process=best[1],
                 sample=f"one batch per process (64 images in-process, 256 / k per worker, >= 16) through the oracle (fp32 ViT-B/16 encode_image + conv-3x adapter + P), processes x torch threads on "
                        f"disjoint logical-CPU ranges, host-level img/s: {', '.join(f'{k}x{t}: {v:.1f}' for (k, t), v in rates.items())}; host has {ncpu} logical cores; "
-                       f"the reference module itself measured 14.2 img/s on 8 threads at survey time (SURVEY.md section 6)")
+                       f"{numa_note()}; the reference module itself measured 14.2 img/s on 8 threads at survey time (SURVEY.md section 6)")
 
 
 def self_launch(args):

@@ -251,6 +251,7 @@ def test_classify_one_launch_mid_N(ops, Q, N, D, alpha, beta):
         torch.testing.assert_close(tp.cpu(), rv, rtol=0, atol=1e-5)
 
 
+@default_routing
 def test_classify_route_is_reported(ops):
     """ops.classify_route names the kernels a call takes (the routes differ in summation order, callers can ask / pin)."""
     assert ops.classify_route(8100, 10, 512, 1.0, 0.7) == "one launch, small N"
@@ -611,6 +612,11 @@ def test_full_size_properties_C3(ops):
     assert acc_lo < cnt[1, 1].item() / 50000 < acc_hi, cnt
 
 
+ROUTING_SWITCHED = any(os.environ.get(k) for k in ("PCLIP_CLASSIFY_PANEL", "PCLIP_CLASSIFY_MID", "PCLIP_CLASSIFY_SMALL", "PCLIP_CLASSIFY_PANEL_PASSES"))
+default_routing = pytest.mark.skipif(ROUTING_SWITCHED, reason="asserts the DEFAULT classification routing; a PCLIP_CLASSIFY_* switch is set (tools/gpu_r6_switches.sh)")
+
+
+@default_routing
 @pytest.mark.parametrize("structured", [True, False])
 def test_full_size_default_routing_C3(ops, structured):
     """The DEFAULT routing of `ops.classify(argmax)` at BASELINE's full size (Q = 50 000, N = 1000, D = 512; utils.py:225-244 + main.py:190): the fused row-panel kernel
