@@ -21,16 +21,13 @@
 
 namespace {
 
-#ifndef PCLIP_MID_DMA
-#define PCLIP_MID_DMA 1          // bank rows by LDS-DMA into a wave-private ring (0: through registers + ds_write, the first form; A/B tools/mid_probe.py)
-#endif
 constexpr int MID_U = 4;                                                            // U: k-steps (32 wide) per register buffer = 128 of D (generic-width path)
 
-// slots of a wave's private ring of [16 rows][128 B] blocks: LDS-DMA form = blocks in flight + 1 — eight waves: 3 + 1 (64 KB: two workgroups per CU at D = 512, which
+// slots of a wave's private ring of [16 rows][128 B] blocks = blocks in flight + 1 — eight waves: 3 + 1 (64 KB: two workgroups per CU at D = 512, which
 // is what a call with more query groups than CUs runs on), sixteen waves: 2 + 1 (96 KB); deeper rings (7 + 1 / 3 + 1 = 128 KB) measured the same single-group latency
 // (14.5 vs 14.6 us at FewSOL-198's size) and cost the second resident workgroup (N = 64, Q = 20 000: 25.2 vs 18.9 us).  The softmax's exchange buffers alias the ring,
-// which is dead by then.  Register form = 2.
-__host__ __device__ constexpr int mid_ring_slots(int sl) { return PCLIP_MID_DMA ? (sl == 8 ? 3 : 4) : 2; }
+// which is dead by then.  (The same blocks through registers + ds_write_b128 — the form before — streamed 25 instead of 30 B/clk and held 64 registers of prefetch.)
+__host__ __device__ constexpr int mid_ring_slots(int sl) { return sl == 8 ? 3 : 4; }
 // LDS: the query group [16][D] fp16 | then EITHER the waves' rings (main loop) OR red [2 banks][SL][16 queries][2] fp32 | xch [SL][TPW * 4][64] fp32 |
 // best [SL][16][2] (softmax: behind a barrier)  (the rings exist for the unrolled widths only: D = 512 / 768 / 1024)
 __host__ __device__ constexpr size_t classify_mid_lds(int D, int tpw, int sl, bool ring) {
@@ -137,8 +134,7 @@ __global__ __launch_bounds__(2 * SL * 64) void classify_mid_kernel(const half_t*
                     acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zf, qf, acc[i], 0, 0, 0);
                 }
             };
-#if PCLIP_MID_DMA
-            // LDS-DMA form: a block's two pieces (8 rows x 128 B each) go straight from L2 into the wave's ring — no registers, no ds_write (13 LDS cycles per
+            // A block's two pieces (8 rows x 128 B each) go straight from L2 into the wave's ring — no registers, no ds_write (13 LDS cycles per
             // kilobyte on the store path).  The swizzle sits on the SOURCE side (lane = LDS row l >> 3, LDS chunk l & 7 fetches source chunk (l & 7) ^ key(row):
             // pgemm::stage_tile's addressing), the hardware places lane l at base + 16 l.  PFD blocks in flight; block b + PFD lands in the slot block b - 1 was read
             // from (its fragments are in registers: the MFMAs that consumed them precede the request).  Every wait is the wave's own counted vmcnt — the ring is private.
@@ -179,47 +175,6 @@ __global__ __launch_bounds__(2 * SL * 64) void classify_mid_kernel(const half_t*
                 if (b + PFD < NBLK) request(b + PFD);
                 __builtin_amdgcn_sched_barrier(0);
             }
-#else
-            constexpr int PF = SL == 8 ? (TPW == 1 ? 3 : 4) : 8;                       // (sixteen waves: 128 registers per lane)
-            half8_t pre[PF][2];
-            const half_t* zsrc[TPW][2];                                                // the lane's source rows (opaque: see zrow)
-#pragma unroll
-            for (int i = 0; i < TPW; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    int c = (slot + MID_SLOTS * i) * 16 + lrow + 8 * j;
-#if defined(__HIP_DEVICE_COMPILE__)
-                    asm volatile("" : "+v"(c));
-#endif
-                    zsrc[i][j] = z + (size_t)(c < N ? c : N - 1) * D + lch * 8;
-                }
-            auto request = [&](int b) {
-                const int kb = b / TPW, i = b % TPW;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) pre[b % PF][j] = ld_half8(zsrc[i][j] + kb * 64);
-            };
-            int woff[2];                                                               // write offsets of the lane's two pieces
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r = lrow + 8 * j;
-                woff[j] = r * 128 + ((lch ^ ((r >> 1) & 7)) << 4);
-            }
-#pragma unroll
-            for (int b = 0; b < PF && b < NBLK; ++b) request(b);
-            stage_q(std::integral_constant<int, (NCH * 256 + MID_WAVES * 64 - 1) / (MID_WAVES * 64)>{});      // 2 D chunks over the workgroup's threads
-            __syncthreads();
-#pragma unroll
-            for (int b = 0; b < NBLK; ++b) {
-                char* tb = tbuf + (b & 1) * 2048;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) *reinterpret_cast<half8_t*>(tb + woff[j]) = pre[b % PF][j];
-                __builtin_amdgcn_sched_barrier(0);
-                if (b + PF < NBLK) request(b + PF);
-                __builtin_amdgcn_sched_barrier(0);
-                block_math(tb, b / TPW, b % TPW);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#endif
         } else {
             half8_t za[U][TPW], zb[U][TPW];
             load(za, 0);

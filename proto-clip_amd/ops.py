@@ -392,7 +392,7 @@ def gemm(a, w, bias=None, act: int = 0, residual=None, out=None):
 
 def gemm4w(a, w, bias=None, act: int = 0, residual=None, out=None, var: int = 0):
     """ops.gemm on the four-wave asm-loop kernel explicitly (csrc/pclip_gemm4w.hip; ops.gemm routes its 256 x 256 tiles there by itself).  var: 0 product loop,
-    1 race-stress build, 6 the no-epilogue ablation (stores nothing), 7 the deferred-half experiment (K = 768).  Raises PclipError for shapes outside the kernel (N % 256, K % 64, K >= 192)."""
+    1 race-stress build, 6 the no-epilogue ablation (stores nothing), 8 the stamped diagnostic build (pclip_gemm4w_stamp_buffer).  Raises PclipError for shapes outside the kernel (N % 256, K % 64, K >= 192)."""
     require_cuda(a, w)
     M, K = a.shape
     N = w.shape[0]

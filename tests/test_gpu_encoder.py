@@ -197,6 +197,26 @@ def test_gemm4w_is_the_eight_wave_kernel_bit_for_bit(ops, M, N, K):
             assert torch.equal(ops.gemm4w(ai, wi, bi, var=var)[:4096], exact)
 
 
+@pytest.mark.parametrize("M,N,K,band", [(20000, 2304, 768, 3), (20000, 3072, 768, 6), (33333, 1024, 832, 2), (70001, 768, 768, 1), (9000, 3072, 768, 5)])
+def test_gemm4w_band_tile_order_is_bit_identical(ops, M, N, K, band, monkeypatch):
+    """PCLIP_GEMM_BAND's tile order in the four-wave kernel (bands of `band` column tiles, row panels fastest inside a band): a permutation of the
+    same output tiles — every epilogue gives the bits of the default order, ragged last band and ragged last row tile included."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + band)
+    a = (torch.randn(M, K, device="cuda", generator=g) * 0.5).half()
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).half()
+    bias = torch.randn(N, device="cuda", generator=g).half()
+    res = torch.randn(M, N, device="cuda", generator=g).half()
+    for act, b, r in ((0, bias, None), (1, bias, None), (0, bias, res)):
+        monkeypatch.delenv("PCLIP_GEMM4W_BAND", raising=False)
+        ref = ops.gemm4w(a, w, b, act, r)
+        monkeypatch.setenv("PCLIP_GEMM4W_BAND", str(band))                     # (read per call by the test entry pclip_gemm4w_var_f16)
+        out = torch.full((M + 1, N), 7.0, device="cuda", dtype=torch.float16)
+        ops.gemm4w(a, w, b, act, r, out[:M])
+        assert torch.equal(out[:M], ref), (act, band)
+        assert bool((out[M] == 7.0).all())
+    monkeypatch.delenv("PCLIP_GEMM4W_BAND", raising=False)
+
+
 def test_gemm4w_in_place_residual_and_refusals(ops):
     a = torch.randn(5000, 768, device="cuda").half()
     w = (torch.randn(768, 768, device="cuda") * 0.03).half()

@@ -13,6 +13,8 @@ from oracle import proto_oracle as po
 from proto_clip_amd import synth
 
 pytestmark = pytest.mark.gpu
+ROUTING_SWITCHED = any(os.environ.get(k) for k in ("PCLIP_CLASSIFY_PANEL", "PCLIP_CLASSIFY_MID", "PCLIP_CLASSIFY_SMALL", "PCLIP_CLASSIFY_PANEL_PASSES"))
+default_routing = pytest.mark.skipif(ROUTING_SWITCHED, reason="asserts the DEFAULT classification routing; a PCLIP_CLASSIFY_* switch is set (tools/gpu_r6_switches.sh)")
 
 
 @pytest.fixture(scope="module")
@@ -610,10 +612,6 @@ def test_full_size_properties_C3(ops):
     _, am1, _, _ = ops.fuse_probs(d2i, None, 1000, 1.0, 12.0, want_p=False, want_argmax=True)
     assert cnt[2, 1].item() == (am1.long().cpu() == split.test_labels).sum().item()
     assert acc_lo < cnt[1, 1].item() / 50000 < acc_hi, cnt
-
-
-ROUTING_SWITCHED = any(os.environ.get(k) for k in ("PCLIP_CLASSIFY_PANEL", "PCLIP_CLASSIFY_MID", "PCLIP_CLASSIFY_SMALL", "PCLIP_CLASSIFY_PANEL_PASSES"))
-default_routing = pytest.mark.skipif(ROUTING_SWITCHED, reason="asserts the DEFAULT classification routing; a PCLIP_CLASSIFY_* switch is set (tools/gpu_r6_switches.sh)")
 
 
 @default_routing
