@@ -1,19 +1,23 @@
-// Classification for MID-SIZED class counts (32 < N <= 256: Caltech-101, FewSOL-198, OxfordPets, DTD ...) in ONE launch (reference
+// Classification for MID-SIZED class counts (16 < N <= 256: Caltech-101, FewSOL-198, OxfordPets, DTD ...) in ONE launch (round 6; reference
 // utils.py:225-244 `P` + main.py:190 `.max(1)[1]`; toolkit proto_clip_classifier.py:146-147).
-// The two-stage path costs five launches there (three norm passes, the distance GEMM, the softmax pass): 24 - 31 us whatever the size, for 4 - 15 MB of traffic.
-// Here a workgroup of EIGHT waves owns a group of 16 queries and walks every class of both banks once:
+// The two-stage path costs five launches there (three norm passes, the distance GEMM, the softmax pass): 24 - 31 us whatever the size, for 2 - 20 MB of traffic.
+// Here a workgroup owns a group of 16 queries and walks every class of both banks once; its 2 SL waves are (bank, class-tile slot) pairs (SL = 4 up to four
+// 16-class tiles, 8 beyond: sixteen waves halve the softmax arithmetic per wave):
 //   * the 16 query rows go to LDS once (16-byte chunks, chunk index XOR row: D % 128 == 0 makes a row whole 256-byte LDS lines, and the XOR is then conflict-free
 //     under ds_read_b128's lane groups in the MFMA operand layout, lane = row l & 15, k-chunk l >> 4);
-//   * wave w = (bank w & 1, slot w >> 1) owns the class tiles (16 classes each) slot, slot + 4, ...: its bank rows go STRAIGHT from L2 into the MFMA operand layout
-//     (lane = class l & 15, k-chunk l >> 4; 16-byte loads, double-buffered in registers) — the same dataflow as classify_small (pclip_classify_small.h), whose
-//     arithmetic this kernel repeats operation for operation: v_mfma_f32_16x16x32_f16 with the classes as the first operand (a lane ends with 4 consecutive classes
-//     of ONE query per tile), fp32 norms from the fragments the MFMAs consume (v_dot2 chains), d2 = (sqrt(max(qq + zz - 2 q.z, 0)))^2;
-//   * the softmax of a bank spans four waves: per query the (min, max) and then the sum of the exponentials cross the waves through LDS (two barriers), the textual
+//   * wave (bank, slot) owns the class tiles slot, slot + SL, ...  Its bank rows arrive by LDS-DMA as FULL-LINE pieces (8 rows x 128 B per instruction) in a
+//     wave-private ring of 2 KB blocks (16 classes x 64 k), swizzled on the source side, waited for with the wave's own counted vmcnt — no barrier in the block loop
+//     (D = 512 / 768 / 1024: unrolled; other D % 128 == 0: a plain loop that loads straight into the MFMA operand layout);
+//   * the arithmetic is classify_small's (pclip_classify_small.h), operation for operation: v_mfma_f32_16x16x32_f16 with the classes as the first operand (a lane
+//     ends with 4 consecutive classes of ONE query per tile), fp32 norms from the fragments the MFMAs consume (v_dot2 chains),
+//     d2 = (sqrt(max(qq + zz - 2 q.z, 0)))^2;
+//   * the softmax of a bank spans SL waves: per query the (min, max) and then the sum of the exponentials cross the waves through LDS (two barriers), the textual
 //     waves hand their alpha-weighted terms to the visual waves (third barrier), which add (visual + textual, the reference's order), write p and reduce the argmax
-//     (fourth barrier; lowest class among equal maxima).
-// What bounds it: a workgroup streams both banks (2 N D 2 bytes: 410 KB for Caltech-101 / RN50, 608 KB for FewSOL-198 / ViT-L/14) through its CU's vector-memory
-// path whatever the number of queries — measured 25 B/clk per CU with full-line loads (14 B/clk in the MFMA operand layout): 7 / 10 us of the kernel's 12.6 / 15.9 us
-// (tools/mid_probe.py, profiles/r06_mid_probe.txt); the rest is the launch (~2 us) and the correctly rounded sqrt / exp / division chains of the softmax.
+//     (fourth barrier; lowest class among equal maxima).  These exchange buffers alias the rings (dead by then).
+// What bounds it: a workgroup streams both banks (2 N D 2 bytes: 410 KB for Caltech-101 / RN50, 608 KB for FewSOL-198 / ViT-L/14) through ONE CU's vector-memory
+// path whatever the number of queries — 30 B/clk with the full-line LDS-DMA pieces (the MFMA operand layout's 16 half-lines per load: 14 B/clk; full lines through
+// registers + ds_write: 25): ~6 / 8 us of the kernel's 11 / 14.5 us; the rest is the launch (~2 us) and the correctly rounded sqrt / exp / division chains of the
+// softmax (tools/mid_probe.py, profiles/r06_mid_probe.txt).
 #include "pclip_gemm.h"
 #include "pclip_classify_small.h"
 #include <stdlib.h>
@@ -35,12 +39,11 @@ __host__ __device__ constexpr size_t classify_mid_lds(int D, int tpw, int sl, bo
     return (size_t)16 * D * 2 + (aux > rings ? aux : rings);
 }
 
-// TPW: class tiles per wave (ceil(ceil(N / 16) / 4): 1 .. 4).  NCH: D / 128 when it is a compile-time constant (4 / 6 / 8: D = 512 / 768 / 1024 — the loop over the
-// bank is then fully unrolled straight-line code: every wait is counted, NBUF buffers of loads in flight), 0: any D % 128 == 0 (run-time trip count, two buffers).
+// TPW: class tiles per wave (ceil(ceil(N / 16) / SL): 1 or 2).  NCH: D / 128 when it is a compile-time constant (4 / 6 / 8: D = 512 / 768 / 1024 — the loop over the
+// bank is then fully unrolled straight-line code: every wait is counted), 0: any D % 128 == 0 (run-time trip count, two register buffers).
 // Why it matters: a workgroup's run time is its chain of L2 round trips; with branches between the loads and their uses hipcc waits with vmcnt(0) at every block
 // boundary (first build: 25.8 us at FewSOL-198's size, the two stages' 26).
-// SL: waves (slots) per bank — 4 (N <= 64: eight waves) or 8 (sixteen waves: twice the loads in flight and half the softmax arithmetic per wave; the epilogue's
-// correctly rounded sqrt / exp / division chains are what a lane spends most of its time on, 13 elements per lane at FewSOL-198's size with SL = 4).
+// SL: waves (slots) per bank — 4 (up to four class tiles: eight waves) or 8 (sixteen waves).
 template <int TPW, int NCH, int SL>
 __global__ __launch_bounds__(2 * SL * 64) void classify_mid_kernel(const half_t* __restrict__ q, const half_t* __restrict__ zi, const half_t* __restrict__ zt, int Q,
                                                                       int N, int D, float alpha, float oma, float beta, float* __restrict__ p,
@@ -113,11 +116,11 @@ __global__ __launch_bounds__(2 * SL * 64) void classify_mid_kernel(const half_t*
             }
         };
         if constexpr (NCH > 0) {
-            // Bank rows by FULL-LINE loads: a load instruction covers 8 class rows x 128 B (lane = row l >> 3, 16-byte chunk l & 7: 8 whole cache lines) — the MFMA
+            // Bank rows by FULL-LINE pieces: an instruction covers 8 class rows x 128 B (lane = row l >> 3, 16-byte chunk l & 7: 8 whole cache lines) — the MFMA
             // operand layout (lane = row l & 15, chunk l >> 4: 16 rows x 64 B = 16 half lines per instruction) streamed at 14 B/clk per CU whatever the row stride
-            // (tools/mid_probe.py: one workgroup, 608 KB, 17.8 us; the vector-memory path pays per line touched).  Each wave transposes its blocks — 16 classes x 64 k:
-            // two loads — through two private 2 KB LDS buffers (pgemm's swizzle: chunk ^ ((row >> 1) & 7), conflict-free for both patterns); LDS operations of one wave
-            // execute in order, so the block loop has no barrier.  Blocks b = kb * TPW + i (k-block kb of the wave's tile i), PF blocks of loads in flight.
+            // (tools/mid_probe.py: one workgroup, 608 KB, 17.8 us; the vector-memory path pays per line touched).  Each wave passes its blocks — 16 classes x 64 k:
+            // two pieces — through its private ring (pgemm's swizzle: chunk ^ ((row >> 1) & 7), conflict-free for the fragment reads).  Blocks b = kb * TPW + i
+            // (k-block kb of the wave's tile i).
             constexpr int NKB = NCH * 2, NBLK = NKB * TPW;
             const int lrow = lane >> 3, lch = lane & 7;
             int roff[2];                                                               // read offsets of the lane's two fragments (k-steps 0 / 1 of a block)
@@ -165,10 +168,9 @@ __global__ __launch_bounds__(2 * SL * 64) void classify_mid_kernel(const half_t*
             pgemm::lds_barrier();                                                      // the query rows are staged (LDS-only: the first blocks stay in flight)
 #pragma unroll
             for (int b = 0; b < NBLK; ++b) {
-                constexpr int dummy = 0; (void)dummy;
                 const int younger = (NBLK - 1 - b < PFD - 1 ? NBLK - 1 - b : PFD - 1) * 2;     // pieces requested behind block b's
-                if (younger >= 12) pgemm::wait_vm<12>(); else if (younger == 10) pgemm::wait_vm<10>(); else if (younger == 8) pgemm::wait_vm<8>(); else if (younger == 6) pgemm::wait_vm<6>();
-                else if (younger == 4) pgemm::wait_vm<4>(); else if (younger == 2) pgemm::wait_vm<2>(); else pgemm::wait_vm<0>();
+                static_assert(PFD <= 3, "the counted waits below cover up to two younger blocks");
+                if (younger == 4) pgemm::wait_vm<4>(); else if (younger == 2) pgemm::wait_vm<2>(); else pgemm::wait_vm<0>();
                 asm volatile("" ::: "memory");
                 block_math(tbuf + (b % NSLOT) * 2048, b / TPW, b % TPW);
                 __builtin_amdgcn_sched_barrier(0);
