@@ -71,7 +71,12 @@ __device__ __forceinline__ float d2_of(float acc, float qs, float zs) {
     const float v = __fadd_rn(__fadd_rn(-2.f * acc, qs), zs);          // sqdist_kernel's expression, operation for operation
     if (!EXACT) return fmaxf(v, 0.f);
     const float d = sqrtf(fmaxf(v, 0.f));
-    return __fmul_rn(d, d);
+    // the ROUNDED product, opaque to the compiler: __fmul_rn is a plain `*` to hipcc, and under -ffp-contract=fast the second pass's `min - d * d` became one fma (the
+    // unrounded square) while the candidate records hold the rounded value — p of the same class differed by an ulp between the proof and the second pass, and the
+    // merge of the two broke exact ties towards the wrong class (tests/test_gpu_parity.py::test_classify_fused_exact_ties_take_the_lowest_class under this mode)
+    float r = d * d;
+    asm("" : "+v"(r));
+    return r;
 }
 
 // DUMP (tests): instead of classifying, the distances of panel 0 / tile 0 are written as sqdist_kernel would ([256][128] per bank) — the bit-identity check

@@ -321,7 +321,8 @@ def test_classify_fused_row_panels(ops, Q, N, D):
     for alpha, beta in ((0.5, 12.0), (0.2, 12.0), (1.0, 0.7), (0.0, 5.0), (0.35, 1.0)):
         with ops.classify_fused():
             ops.classify_panel_stats(reset=True)
-            _, am, _, _ = ops.classify(dev(q), dev(zi), dev(zt), alpha, beta, want_p=False, want_argmax=True)
+            with ops.classify_panel_passes(0):             # (the default; named so that the panel counts below hold under PCLIP_CLASSIFY_PANEL_PASSES=1 too)
+                _, am, _, _ = ops.classify(dev(q), dev(zi), dev(zt), alpha, beta, want_p=False, want_argmax=True)
             npan, nsecond = ops.classify_panel_stats()
             # one pass + candidates + proof (default) == always two passes == candidates with the second pass forced: the same argmax, bit for bit
             with ops.classify_panel_passes(1):
