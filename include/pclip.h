@@ -240,6 +240,13 @@ int pclip_gemm_bn_res_f16(const void* A, int lda, const void* B, int ldb, void* 
 int pclip_conv3x3_bn_f16(const void* x, const void* w, const void* zero_line, int B, int H, int W, int Cin, int Cout,
                          const float* scale, const float* shift, int relu, void* y, pclip_stream_t stream);
 
+/* The narrow layers of the tower (Cin, Cout in {32, 64}; H % 8 == 0, W % 56 == 0: the stem's conv2 / conv3 at 112 x 112, layer1's conv2 at 56 x 56; any batch) are routed by pclip_conv3x3_bn_f16 to a kernel of their own (csrc/pclip_conv_strip.hip: weights in registers, a tile's input block with its halo once
+ * in LDS, zero padding by out-of-range buffer loads).  Same rounding points; the fp32 accumulation order differs from the implicit GEMM's ((dx, chunk, dy) instead of
+ * (dy, dx, chunk)), so single fp16 results may differ by one ulp.  pclip_conv3x3_strip_applies: would this shape take it (1 / 0); pclip_conv3x3_strip_config: -1 the
+ * environment's choice (PCLIP_CONV_STRIP, default on), 0 off, 1 on — returns the previous mode (tests, A/B runs). */
+int pclip_conv3x3_strip_applies(int B, int H, int W, int Cin, int Cout);
+int pclip_conv3x3_strip_config(int mode);
+
 /* LayerNorm over the last dim with fp32 statistics and fp32 affine parameters, fp16 in/out
  * (clip/model.py:155-161).  x rows are ld_x elements apart (lets ln_post read only the CLS rows). */
 int pclip_layernorm_f16(const void* x, int ld_x, const float* gamma, const float* beta, float eps, void* y,

@@ -61,6 +61,8 @@ _SIGS = {
     "pclip_gemm_bn_f16": [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P],
     "pclip_gemm_bn_res_f16": [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P],
     "pclip_conv3x3_bn_f16": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P],
+    "pclip_conv3x3_strip_applies": [c_int, c_int, c_int, c_int, c_int],
+    "pclip_conv3x3_strip_config": [c_int],
     "pclip_layernorm_f16": [_P, c_int, _P, _P, c_float, _P, c_int, c_int, _P],
     "pclip_add_layernorm_f16": [_P, _P, c_int, _P, _P, _P, c_float, _P, c_int, c_int, _P],
     "pclip_attention_f16": [_P, _P, c_int, c_int, c_int, c_int, c_int, _P],

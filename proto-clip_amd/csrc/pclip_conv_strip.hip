@@ -1,0 +1,277 @@
+// 3x3 convolution (stride 1, pad 1, NHWC fp16) + eval BatchNorm (+ ReLU) for the NARROW layers of the ModifiedResNet image tower (clip/model.py:20-22, 45-46, 100-108 of
+// the reference: the stem's conv2 / conv3 at 112 x 112 and layer1's conv2 at 56 x 56; Cin, Cout in {32, 64}) — the launches where the implicit-GEMM kernel of
+// pclip_linear.hip is slowest (profiles/r06_rn50_profile.md: 0.10 - 0.14 MFMA busy, every input pixel gathered NINE times from L2, 44 % of its waves parked).
+//
+// Design (MI355X: 160 KB of LDS and 512 registers per lane at one wave per SIMD):
+//  * a workgroup (4 waves) owns output tiles of 8 rows x 56 pixels and walks them persistently; a tile's input block WITH ITS HALO (10 x 58 pixels, all channels)
+//    comes into LDS ONCE, by LDS-DMA, as contiguous row segments of the NHWC image (full 128-byte lines); two such blocks (2 x 76 KB) ping-pong, so the next tile's
+//    block lands under this tile's arithmetic.  Out-of-image pixels are buffer loads beyond the descriptor's range (zeros): the padding costs no branch in the arithmetic.
+//  * the WEIGHTS LIVE IN REGISTERS: a wave computes 32 output channels, i.e. its share of w is 32 x 9 Cin halves = 144 registers per lane at Cin = 64, loaded once
+//    per workgroup.  Nothing but pixels is ever read from LDS.
+//  * pixels are the MFMA's N side (v_mfma_f32_16x16x32_f16 with A = weights, B = pixels): a lane ends up with 8 consecutive output channels of one pixel — one
+//    16-byte store per (pixel, lane) after BatchNorm / ReLU, no staging through LDS.
+//  * a 16-pixel block is 8 consecutive pixels of row j and of row j + 4: the fragment a tap (dy, dx) needs for block j is the fragment of block j + dy at column
+//    shift dx, so the six fragments of an (8 pixels x 8 rows) sub-tile at one dx serve 4 blocks x 3 dy x 2 channel groups = 24 MFMAs: 0.26 LDS reads per MFMA (the
+//    four-wave GEMM's ratio; a tap-by-tap loop would need 0.5 and saturate LDS).
+//  * LDS layout: pixel-major, the 16-byte channel slots of a pixel XOR-swizzled by (column, row) bits so that the 16 pixels a fragment read touches per quarter-wave
+//    fall into 16 different bank groups; the swizzle is applied on the SOURCE side of the DMA (LDS-DMA writes lanes contiguously).
+// Accumulation order per output: (dx, channel chunk, dy) instead of the implicit GEMM's (dy, dx, chunk): fp32 sums differ in their last bits, the fp16 results in
+// ~1e-4 of the elements by one fp16 ulp (tests/test_gpu_encoder.py compares both kernels and the fp32 reference).
+#include "pclip_common.h"
+#include "pclip_gemm.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+constexpr int ST_ROWS = 8, ST_COLS = 56, ST_HR = ST_ROWS + 2, ST_HC = ST_COLS + 2;
+
+template <int CIN>
+struct StripGeo {
+    static constexpr int PXB = CIN * 2;                               // bytes per pixel
+    static constexpr int SPP = PXB / 16;                              // 16-byte slots per pixel
+    static constexpr int NCH = CIN / 32;                              // 32-channel chunks (one MFMA K each)
+    static constexpr int PIECES = ST_HR * ST_HC * SPP;                // 16-byte pieces of a halo block
+    static constexpr int ROUNDS = (PIECES + 255) / 256;               // DMA rounds of the workgroup (256 pieces each)
+    static constexpr int BUF = ROUNDS * 4096;                         // bytes of one block buffer (the last round's tail lands in slack)
+};
+
+// XOR key of the 16-byte slots of LDS pixel (row, col): see the header (bank groups of a fragment read)
+template <int CIN>
+__device__ __forceinline__ int strip_key(int row, int col) {
+    if (CIN == 64) return ((col >> 1) & 3) | (((row >> 2) & 1) << 2);
+    return ((col >> 2) & 1) | (((row >> 2) & 1) << 1);
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// The arithmetic of blocks B0 .. B0 + NB - 1 of a tile (block b = 4 s + j: sub-tile s = 8 pixel columns, rows j and j + 4), all taps, for the wave's 32 channels.
+// A GROUP = (column shift dx, channel chunk, sub-tile): up to six fragment reads feeding up to 24 MFMAs.  The reads of group g + 1 are issued BEFORE the MFMAs of
+// group g (two fragment sets; sched_barrier keeps hipcc from sinking them behind the MFMAs, where their latency would be exposed once per group).
+template <int CIN, int B0, int NB>
+struct StripGroups {
+    static constexpr int PXB = CIN * 2, NCH = CIN / 32, B1 = B0 + NB - 1, S0 = B0 / 4, S1 = B1 / 4, NS = S1 - S0 + 1, NG = 3 * NCH * NS;
+    static constexpr int dx(int g) { return g / (NCH * NS); }
+    static constexpr int ch(int g) { return (g / NS) % NCH; }
+    static constexpr int s(int g) { return S0 + g % NS; }
+    static constexpr int jlo(int g) { return (B0 > 4 * s(g) ? B0 : 4 * s(g)) - 4 * s(g); }
+    static constexpr int jhi(int g) { return (B1 < 4 * s(g) + 3 ? B1 : 4 * s(g) + 3) - 4 * s(g); }
+};
+
+template <int CIN, int B0, int NB>
+__device__ __forceinline__ void strip_compute(const char* __restrict__ buf, const int (&base)[3][2], const half8_t (&wr)[9][CIN / 32][2], float4_t (&acc)[NB][2]) {
+    using T = StripGroups<CIN, B0, NB>;
+    half8_t f[2][6];                                                   // [set][LDS row jlo .. jhi + 2] (lanes of the upper half: row + 4)
+    auto load = [&](auto gc) {
+        constexpr int g = decltype(gc)::value, dx = T::dx(g), ch = T::ch(g), s = T::s(g);
+        static_for<T::jlo(g), T::jhi(g) + 3>([&](auto rc) {
+            constexpr int R0 = decltype(rc)::value;
+            constexpr int X = (CIN == 64 ? ch : 0) ^ ((R0 >> 2) & 1);
+            constexpr int imm = (R0 * ST_HC + 8 * s + dx) * T::PXB;
+            f[g & 1][R0] = *reinterpret_cast<const half8_t*>(buf + base[dx][X] + imm);
+        });
+    };
+    load(std::integral_constant<int, 0>{});
+    static_for<0, T::NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value, dx = T::dx(g), ch = T::ch(g), s = T::s(g);
+        if constexpr (g + 1 < T::NG) load(std::integral_constant<int, g + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 3>([&](auto dyc) {
+            constexpr int dy = decltype(dyc)::value;
+            static_for<T::jlo(g), T::jhi(g) + 1>([&](auto jc) {
+                constexpr int j = decltype(jc)::value, b = 4 * s + j - B0;
+                acc[b][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[dy * 3 + dx][ch][0], f[g & 1][j + dy], acc[b][0], 0, 0, 0);
+                acc[b][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[dy * 3 + dx][ch][1], f[g & 1][j + dy], acc[b][1], 0, 0, 0);
+            });
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+template <int CIN, int COUT, int ACT>
+__global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w, int ldw,
+                                                               int H, int W, int ntiles, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               half_t* __restrict__ y) {
+    using Geo = StripGeo<CIN>;
+    constexpr int PXB = Geo::PXB, SPP = Geo::SPP, NCH = Geo::NCH, ROUNDS = Geo::ROUNDS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int G = gridDim.x;
+    int tile = pgemm::xcd_remap(blockIdx.x, G);
+    if (tile >= ntiles) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = W / ST_COLS, tiles_y = H / ST_ROWS, tpi = tiles_x * tiles_y;
+
+    // ---- the lane's DMA table: source offset of LDS piece (round, tid) relative to the tile's first pixel, border flags in the four low bits ----
+    int rel[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int q = r * 256 + tid;
+        int v = 0;                                                    // (the tail of the last round copies the tile's first piece into slack)
+        if (q < Geo::PIECES) {
+            const int pix = q / SPP, slot = (q - pix * SPP) ^ strip_key<CIN>(pix / ST_HC, pix % ST_HC);
+            const int row = pix / ST_HC, col = pix - row * ST_HC;
+            v = ((row - 1) * W + (col - 1)) * PXB + slot * 16;
+            v |= (row == 0 ? 1 : 0) | (row == ST_HR - 1 ? 2 : 0) | (col == 0 ? 4 : 0) | (col == ST_HC - 1 ? 8 : 0);
+        }
+        rel[r] = v;
+    }
+    // ---- the lane's fragment bases: pixel (4 (c >> 3), c & 7) of a block, channel slot kq, for the three column shifts and the two row-bit parities ----
+    const int c = lane & 15, kq = lane >> 4, ci = c & 7, hb = c >> 3;
+    int base[3][2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+            const int pixoff = (4 * hb * ST_HC + ci) * PXB;
+            int slot;
+            if (CIN == 64) slot = ((X ^ hb) << 2) | (kq ^ (((dx + ci) >> 1) & 3));
+            else slot = kq ^ ((((dx + ci) >> 2) & 1) | ((X ^ hb) << 1));
+            base[dx][X] = pixoff + slot * 16;
+        }
+    // ---- the wave's weights, BatchNorm scale / shift of the lane's 8 output channels ----
+    const int nh = COUT == 64 ? wave >> 1 : 0, mpart = COUT == 64 ? wave & 1 : wave;
+    half8_t wr[9][NCH][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int co = nh * 32 + (c >> 2) * 8 + nb * 4 + (c & 3);
+                wr[tap][ch][nb] = *reinterpret_cast<const half8_t*>(w + (size_t)co * ldw + tap * CIN + ch * 32 + kq * 8);
+            }
+    const int co0 = nh * 32 + kq * 8;                                 // the lane's output channels co0 .. co0 + 7 (index nb * 4 + e)
+    float sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sc[i] = scale[co0 + i]; sh[i] = shift[co0 + i]; }
+
+    // LDS-DMA through a BUFFER descriptor over the whole input (not global_load_lds): out-of-image pieces take an offset beyond the buffer and the hardware writes
+    // zeros — the padding needs no zero line — and hipcc keeps counting its LDS waits (lgkmcnt(N)) while the DMA is in flight: with a FLAT-encoded LDS load pending it
+    // falls back to lgkmcnt(0) before every group of MFMAs, i.e. it exposes the latency of the fragment reads it had just issued ahead.
+    pgemm::rsrc_t rs;
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+        const uint64_t addr = (uint64_t)x;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)addr), hi = __builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, (int)((unsigned)ntiles * (unsigned)(ST_ROWS * ST_COLS * PXB)), 0x00020000);
+    }
+#endif
+    auto issue = [&](int t, int pbuf) {
+        const int img = t / tpi, rem = t - img * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int tflags = (ty == 0 ? 1 : 0) | (ty == tiles_y - 1 ? 2 : 0) | (tx == 0 ? 4 : 0) | (tx == tiles_x - 1 ? 8 : 0);
+        const unsigned org = (unsigned)((img * H + ty * ST_ROWS) * W + tx * ST_COLS) * (unsigned)PXB;
+        pgemm::stress_jitter(110);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const unsigned voff = (rel[r] & tflags) ? 0xfffffff0u : org + (unsigned)(rel[r] & ~15);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (pgemm::lds_ptr_t)(smem + pbuf * Geo::BUF + (r * 256 + wave * 64) * 16), 16, (int)voff, 0, 0, 0);
+        }
+#endif
+    };
+    auto run = [&](auto b0c, auto nbc, const char* buf, half_t* yorg) {
+        constexpr int B0 = decltype(b0c)::value, NB = decltype(nbc)::value;
+        float4_t acc[NB][2];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { acc[b][0] = float4_t{0.f, 0.f, 0.f, 0.f}; acc[b][1] = float4_t{0.f, 0.f, 0.f, 0.f}; }
+        strip_compute<CIN, B0, NB>(buf, base, wr, acc);
+        // BatchNorm (+ ReLU) with the implicit-GEMM kernel's rounding points (r16(acc): the convolution's fp16 output; r16 of the affine), 16-byte stores
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int s = (B0 + b) >> 2, j = (B0 + b) & 3;
+            half8_t h;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = r16(r16(acc[b][i >> 2][i & 3]) * sc[i] + sh[i]);
+                if (ACT == 3) v = fmaxf(v, 0.f);
+                h[i] = (half_t)v;
+            }
+            *reinterpret_cast<half8_t*>(yorg + ((size_t)(j + 4 * hb) * W + 8 * s + ci) * COUT + co0) = h;
+        }
+    };
+
+    issue(tile, 0);
+    int p = 0;
+    for (; tile < ntiles; tile += G, p ^= 1) {
+        pgemm::wait_vm<0>();                                          // this wave's pieces of the block (and its stores of the previous tile)
+        pgemm::lds_barrier();                                         // everybody's pieces; everybody is done reading the other buffer
+        if (tile + G < ntiles) issue(tile + G, p ^ 1);
+        const int img = tile / tpi, rem = tile - img * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        half_t* yorg = y + ((size_t)(img * H + ty * ST_ROWS) * W + tx * ST_COLS) * COUT;
+        const char* buf = smem + p * Geo::BUF;
+        if (COUT == 64) {
+            if (mpart == 0) run(std::integral_constant<int, 0>{}, std::integral_constant<int, 14>{}, buf, yorg);
+            else run(std::integral_constant<int, 14>{}, std::integral_constant<int, 14>{}, buf, yorg);
+        } else {
+            if (mpart == 0) run(std::integral_constant<int, 0>{}, std::integral_constant<int, 7>{}, buf, yorg);
+            else if (mpart == 1) run(std::integral_constant<int, 7>{}, std::integral_constant<int, 7>{}, buf, yorg);
+            else if (mpart == 2) run(std::integral_constant<int, 14>{}, std::integral_constant<int, 7>{}, buf, yorg);
+            else run(std::integral_constant<int, 21>{}, std::integral_constant<int, 7>{}, buf, yorg);
+        }
+    }
+}
+
+int g_strip_mode = -1;                                                // -1: environment (PCLIP_CONV_STRIP, default on), 0 off, 1 on
+
+template <int CIN, int COUT, int ACT>
+int launch_strip(const void* x, const void* w, int B, int H, int W, const float* scale, const float* shift, void* y, int cus, hipStream_t s) {
+    static DevOnce attr;
+    constexpr int LDS = 2 * StripGeo<CIN>::BUF;
+    if (!attr.done()) {
+        if (hipFuncSetAttribute((const void*)conv3x3_strip_kernel<CIN, COUT, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+            pclip_set_error("pclip_conv3x3_bn_f16: cannot raise the dynamic LDS limit to %d", LDS);
+            return PCLIP_E_LAUNCH;
+        }
+        attr.set();
+    }
+    const int ntiles = B * (H / ST_ROWS) * (W / ST_COLS), ldw = (9 * CIN + 63) / 64 * 64;
+    conv3x3_strip_kernel<CIN, COUT, ACT><<<ntiles < cus ? ntiles : cus, 256, LDS, s>>>((const half_t*)x, (const half_t*)w, ldw, H, W, ntiles, scale,
+                                                                                      shift, (half_t*)y);
+    return pclip_check_launch("conv3x3_bn (strip)");
+}
+
+}  // namespace
+
+// Does the strip kernel take this convolution?  (pclip_conv3x3_bn_f16's routing; exported for the tests' route check.)
+extern "C" int pclip_conv3x3_strip_applies(int B, int H, int W, int Cin, int Cout) {
+    static const bool env_on = !(getenv("PCLIP_CONV_STRIP") && getenv("PCLIP_CONV_STRIP")[0] == '0');
+    const bool on = g_strip_mode < 0 ? env_on : g_strip_mode != 0;
+    // (by the layer's shape alone, never by the batch: an image's features do not depend on how many images are encoded with it — tests/test_gpu_encoder.py)
+    return on && (Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64) && H % ST_ROWS == 0 && W % ST_COLS == 0 && B > 0 && (long)H * W * Cin * 2 < (1L << 31);
+}
+
+// -1: the environment's choice (PCLIP_CONV_STRIP, default on); 0 / 1: off / on.  Returns the previous mode.  (Tests and A/B runs.)
+extern "C" int pclip_conv3x3_strip_config(int mode) {
+    const int prev = g_strip_mode;
+    g_strip_mode = mode < 0 ? -1 : (mode != 0);
+    return prev;
+}
+
+int pclip_conv3x3_strip_launch(const void* x, const void* w, int B, int H, int W, int Cin, int Cout, const float* scale, const float* shift, int relu,
+                               void* y, int cus, hipStream_t s) {
+    // the buffer descriptor addresses 2^31 bytes: larger batches go in slices of whole images (the same kernel, the same bits)
+    const long per_image = (long)H * W * Cin * 2;
+    const int slice = (int)((1L << 31) / per_image);
+    for (int b0 = 0; b0 < B; b0 += slice) {
+        const int nb = B - b0 < slice ? B - b0 : slice;
+        const void* xs = (const char*)x + (size_t)b0 * per_image;
+        void* ys = (char*)y + (size_t)b0 * H * W * Cout * 2;
+        int rc = PCLIP_E_INVALID;
+#define PCLIP_STRIP_CASE(CI, CO)                                                                                             \
+    if (Cin == CI && Cout == CO)                                                                                             \
+        rc = relu ? launch_strip<CI, CO, 3>(xs, w, nb, H, W, scale, shift, ys, cus, s) : launch_strip<CI, CO, 2>(xs, w, nb, H, W, scale, shift, ys, cus, s);
+        PCLIP_STRIP_CASE(64, 64)
+        PCLIP_STRIP_CASE(32, 64)
+        PCLIP_STRIP_CASE(32, 32)
+        PCLIP_STRIP_CASE(64, 32)
+#undef PCLIP_STRIP_CASE
+        if (rc != PCLIP_OK) return rc;
+    }
+    return PCLIP_OK;
+}

@@ -890,6 +890,11 @@ int launch_conv(const void* x, const void* zero, const void* w, int B, int H, in
 }
 }  // namespace
 
+// pclip_conv_strip.hip
+extern "C" int pclip_conv3x3_strip_applies(int B, int H, int W, int Cin, int Cout);
+int pclip_conv3x3_strip_launch(const void* x, const void* w, int B, int H, int W, int Cin, int Cout, const float* scale, const float* shift, int relu,
+                               void* y, int cus, hipStream_t s);
+
 extern "C" int pclip_conv3x3_bn_f16(const void* x, const void* w, const void* zero_line, int B, int H, int W, int Cin, int Cout,
                                     const float* scale, const float* shift, int relu, void* y, pclip_stream_t stream) {
     PCLIP_REQUIRE(x && w && zero_line && scale && shift && y, "pclip_conv3x3_bn_f16: null pointer");
@@ -903,6 +908,8 @@ extern "C" int pclip_conv3x3_bn_f16(const void* x, const void* w, const void* ze
     int cus = pclip_device_cus();
     if (cus <= 0) cus = 256;
     hipStream_t s = (hipStream_t)stream;
+    if (pclip_conv3x3_strip_applies(B, H, W, Cin, Cout))                        // narrow layers at 56 x 56 / 112 x 112: weights in registers, halo blocks in LDS
+        return pclip_conv3x3_strip_launch(x, w, B, H, W, Cin, Cout, scale, shift, relu, y, cus, s);
     if (Cout == 32)                                                             // the stem's 32 -> 32 convolution: 256 x 32 tiles
         return launch_conv<CfgThin>(x, zero_line, w, B, H, W, Cin, Cout, scale, shift, relu, y, 2 * cus, s);
     static const bool small_on = !(getenv("PCLIP_GEMM_SMALL") && getenv("PCLIP_GEMM_SMALL")[0] == '0');

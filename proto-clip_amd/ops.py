@@ -495,6 +495,25 @@ def conv3x3_bn(x, w, scale, shift, B: int, H: int, W: int, Cin: int, relu: bool 
     return y
 
 
+class conv_strip:
+    """`with ops.conv_strip(on):` — routing of the narrow 3x3 convolutions (Cin, Cout in {32, 64} at 56 x 56 / 112 x 112) to csrc/pclip_conv_strip.hip (default on)
+    or to the implicit-GEMM kernel (off: its reference in the tests)."""
+    def __init__(self, on: bool):
+        self.mode = int(bool(on))
+
+    def __enter__(self):
+        self.before = _lib.load().pclip_conv3x3_strip_config(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().pclip_conv3x3_strip_config(self.before)
+        return False
+
+
+def conv_strip_applies(B: int, H: int, W: int, Cin: int, Cout: int) -> bool:
+    return bool(_lib.load().pclip_conv3x3_strip_applies(B, H, W, Cin, Cout))
+
+
 def layernorm(x, gamma, beta, eps: float = 1e-5, out=None, rows: int = None, ld: int = None):
     """fp16 in/out LayerNorm with fp32 statistics and fp32 affine (clip/model.py:155-161)."""
     require_cuda(x, gamma, beta)

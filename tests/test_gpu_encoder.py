@@ -653,7 +653,8 @@ def test_conv3x3_implicit_gemm_equals_im2col_path(ops, B, H, W, Cin, Cout, relu)
     w2 = w2.contiguous()
     cols = ops.im2col3x3(x, (H * W * Cin, W * Cin, Cin, 1), B, H, W, Cin, 1)
     ref = ops.gemm_bn(cols, w2, ss[0], ss[1], relu=relu)
-    got = ops.conv3x3_bn(x, w2, ss[0], ss[1], B, H, W, Cin, relu=relu)
+    with ops.conv_strip(False):                              # (the narrow layers have a kernel of their own: next test)
+        got = ops.conv3x3_bn(x, w2, ss[0], ss[1], B, H, W, Cin, relu=relu)
     assert torch.equal(got, ref)
     if B * H * W <= 2000:
         xt = x.view(B, H, W, Cin).permute(0, 3, 1, 2).float().cpu()
@@ -663,6 +664,53 @@ def test_conv3x3_implicit_gemm_equals_im2col_path(ops, B, H, W, Cin, Cout, relu)
             y = y.clamp_min(0)
         yt = y.permute(0, 2, 3, 1).reshape(B * H * W, Cout)
         assert (got.float().cpu() - yt).abs().max().item() <= 2e-2 * yt.abs().max().item()
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,relu", [(3, 112, 112, 32, 32, True), (2, 112, 112, 32, 64, True), (6, 56, 56, 64, 64, True), (40, 8, 56, 64, 64, False),
+                                                 (9, 16, 56, 32, 64, True), (2, 56, 112, 64, 32, True), (300, 56, 56, 64, 64, True), (70, 112, 112, 32, 32, False)])
+def test_conv3x3_strip_kernel(ops, B, H, W, Cin, Cout, relu):
+    """The narrow 3x3 convolutions of the ModifiedResNet tower (stem conv2 / conv3, layer1 conv2; clip/model.py:100-108, 20-22 of the reference) through
+    csrc/pclip_conv_strip.hip — weights in registers, the tile's input block with its halo once in LDS, zero padding by out-of-range buffer loads — against
+    (i) the implicit-GEMM kernel it replaces: the same rounding points, another fp32 summation order, so fp16 results agree except for single-ulp flips of the convolution's fp16 output, bounded and counted;
+    (ii) torch's fp32 conv2d of the same fp16 operands + the BatchNorm affine in fp32 (small cases); every border (one-strip images: top and bottom in the same
+    tile; 112-wide images: two tiles per row) and more tiles than CUs (persistent walk, both block buffers)."""
+    assert ops.conv_strip_applies(B, H, W, Cin, Cout)
+    g = torch.Generator(device="cuda").manual_seed(B * H + Cin + Cout)
+    x = (torch.randn(B * H * W, Cin, device="cuda", generator=g) * 0.7).half()
+    w = (torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) * (9 * Cin) ** -0.5).half()
+    ss = torch.stack([1 + 0.3 * torch.randn(Cout, device="cuda", generator=g), 0.2 * torch.randn(Cout, device="cuda", generator=g)]).contiguous()
+    w2 = w.reshape(Cout, 9 * Cin)
+    if (9 * Cin) % 64:
+        w2 = torch.cat([w2, w2.new_zeros(Cout, (9 * Cin + 63) // 64 * 64 - 9 * Cin)], dim=1)
+    w2 = w2.contiguous()
+    with ops.conv_strip(False):
+        ref = ops.conv3x3_bn(x, w2, ss[0], ss[1], B, H, W, Cin, relu=relu)
+    got = ops.conv3x3_bn(x, w2, ss[0], ss[1], B, H, W, Cin, relu=relu)
+    again = ops.conv3x3_bn(x, w2, ss[0], ss[1], B, H, W, Cin, relu=relu)
+    assert torch.equal(got, again)                           # deterministic
+    d = (got.float() - ref.float()).abs()
+    # one fp16 ulp of the CONVOLUTION's output (r16(acc), the first rounding point) moves the result by 2^-10 |conv| scale = 2^-10 |y - shift| <= 2^-10 (|y| + |shift|);
+    # one more ulp of y itself where the second rounding flips with it
+    bound = 2.0 ** -10 * (2 * ref.float().abs() + ss[1].abs()[None, :]) * 1.01 + 2.0 ** -24
+    assert bool((d <= bound).all()), (d / bound).max().item()
+    frac = (d > 0).float().mean().item()
+    observe(f"conv3x3 strip kernel {Cin}->{Cout} {H}x{W}: fraction of fp16 results one ulp from the implicit GEMM's", frac, 5e-3)
+    assert frac <= 5e-3
+    if B * H * W <= 80000:
+        xt = x.view(B, H, W, Cin).permute(0, 3, 1, 2).float().cpu()
+        conv = torch.nn.functional.conv2d(xt, w.permute(0, 3, 1, 2).float().cpu(), padding=1).half().float()
+        y = (conv * ss[0].cpu()[None, :, None, None] + ss[1].cpu()[None, :, None, None]).half().float()
+        if relu:
+            y = y.clamp_min(0)
+        yt = y.permute(0, 2, 3, 1).reshape(B * H * W, Cout)
+        err = (got.float().cpu() - yt).abs()
+        # the border rows / columns by themselves: a wrong halo shows there first
+        m = torch.zeros(B, H, W, dtype=torch.bool)
+        m[:, 0] = m[:, -1] = True
+        m[:, :, 0] = m[:, :, -1] = True
+        m[:, :, 55:57] = True
+        bound = 4e-3 * yt.abs().max().item()
+        assert err.max().item() <= bound and err[m.reshape(-1)].max().item() <= bound, (err.max().item(), bound)
 
 
 @pytest.mark.parametrize("B,L,H,Lq", [(5, 197, 12, 1), (3, 50, 12, 1), (2, 257, 16, 1), (4, 197, 12, 40), (2, 77, 8, 77), (2, 280, 4, 200), (3, 257, 16, 160), (2, 288, 2, 256)])      # the last three: 5 - 8 query tiles against MORE than 8 key tiles (ADVICE r4: the query-first kernel must not take them)

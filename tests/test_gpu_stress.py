@@ -3,7 +3,7 @@
 for 0 / 256 / 1024 cycles, pseudo-randomly per wave and call).  A wait that is a piece too weak or a barrier that does not cover a refill reads stale LDS in some
 launch; here every such kernel must reproduce the NORMAL library's bits, repeatedly: the eight-wave GEMM in every tile configuration (staggered refill, ring
 kernel, residual / QuickGELU epilogues), sqdist_big's norm strips, the fused row-panel classification, the one-launch mid-N classification (wave-private LDS-DMA
-rings, counted per-wave waits), attention in
+rings, counted per-wave waits), the narrow 3x3 convolution (ping-pong input blocks), attention in
 every piece-count class (query-first and looping kernels, causal).  The four-wave asm loop has its own jittered variant (test_gpu_encoder.py)."""
 import ctypes
 import os
@@ -113,6 +113,25 @@ def test_classify_mid_under_jitter(ops, slib, Q, N, D):
                                      _lib.ptr(ws), ws.numel(), _lib.stream())
         assert rc == 0, slib.pclip_last_error()
         assert torch.equal(p, p_ref) and torch.equal(am, am_ref), f"launch {rep}"
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(300, 56, 56, 64, 64), (40, 112, 112, 32, 64), (40, 112, 112, 32, 32), (50, 8, 56, 64, 32)])
+def test_conv_strip_under_jitter(ops, slib, B, H, W, Cin, Cout):
+    """The narrow 3x3 convolution kernel (csrc/pclip_conv_strip.hip) ping-pongs two LDS input blocks filled by LDS-DMA: one vmcnt(0) + LDS barrier per tile covers
+    both the landing of this tile's block and the hand-back of the other.  With waves paused at random around them, launch after launch, the normal library's bits."""
+    g = torch.Generator(device="cuda").manual_seed(B + H + Cout)
+    x = (torch.randn(B * H * W, Cin, device="cuda", generator=g) * 0.7).half()
+    w = (torch.randn(Cout, (9 * Cin + 63) // 64 * 64, device="cuda", generator=g) * (9 * Cin) ** -0.5).half()
+    sc, sh = 1 + 0.3 * torch.randn(Cout, device="cuda", generator=g), 0.2 * torch.randn(Cout, device="cuda", generator=g)
+    assert ops.conv_strip_applies(B, H, W, Cin, Cout)
+    ref = ops.conv3x3_bn(x, w, sc, sh, B, H, W, Cin, relu=True)
+    z = torch.zeros(64, dtype=torch.float16, device="cuda")
+    slib.pclip_conv3x3_strip_config(1)
+    for rep in range(3):
+        y = torch.full((B * H * W, Cout), float("nan"), dtype=torch.float16, device="cuda")
+        rc = slib.pclip_conv3x3_bn_f16(_lib.ptr(x), _lib.ptr(w), _lib.ptr(z), B, H, W, Cin, Cout, _lib.ptr(sc), _lib.ptr(sh), 1, _lib.ptr(y), _lib.stream())
+        assert rc == 0, slib.pclip_last_error()
+        assert torch.equal(y, ref), f"launch {rep}"
 
 
 @pytest.mark.parametrize("B,L,H,causal", [(64, 197, 12, False), (32, 257, 16, False), (128, 50, 12, False), (256, 77, 8, True), (16, 129, 12, False), (16, 224, 12, True),
