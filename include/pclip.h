@@ -247,6 +247,15 @@ int pclip_conv3x3_bn_f16(const void* x, const void* w, const void* zero_line, in
 int pclip_conv3x3_strip_applies(int B, int H, int W, int Cin, int Cout);
 int pclip_conv3x3_strip_config(int mode);
 
+/* The stem's first convolution (3 -> Cout channels, 3x3, stride 2, pad 1) + eval BatchNorm (+ReLU) straight from the NCHW images `img` [B, 3, R, R] (fp32 if
+ * img_is_f32 — rounded to fp16 on the way, as a separate cast would — else fp16) into NHWC fp16 y [B * Ho * Ho, Cout], Ho = (R - 1) / 2 + 1: no im2col matrix, no
+ * cast pass (clip/model.py:100-102, 138).  w [Cout][64] fp16: the im2col column order (ky, kx, channel), zero beyond column 27 — the operand pclip_gemm_bn_f16 takes
+ * after pclip_im2col3x3_f16, and the same arithmetic.  R even, Ho a multiple of 56, Cout 32 or 64 (pclip_stem_conv_applies; PCLIP_CONV_STEM=0 turns the routing of
+ * the python model off); PCLIP_E_INVALID otherwise. */
+int pclip_stem_conv_applies(int R, int Cout);
+int pclip_stem_conv_bn_f16(const void* img, int img_is_f32, int B, int R, const void* w, int Cout, const float* scale, const float* shift, int relu, void* y,
+                           pclip_stream_t stream);
+
 /* LayerNorm over the last dim with fp32 statistics and fp32 affine parameters, fp16 in/out
  * (clip/model.py:155-161).  x rows are ld_x elements apart (lets ln_post read only the CLS rows). */
 int pclip_layernorm_f16(const void* x, int ld_x, const float* gamma, const float* beta, float eps, void* y,

@@ -339,12 +339,17 @@ class ModifiedResNet(nn.Module):
 
     def _forward_chunk(self, img):
         B, R = img.shape[0], self.input_resolution
-        if img.dtype == torch.float32:
-            img = ops.cast_f16(img)
-        img = img.contiguous()
         w2 = self.conv1.weight.shape[0]
-        # stem (clip/model.py:138-142): the NCHW image is read through its strides by the first im2col
-        x = self._conv3_bn_relu("s1", img, (3 * R * R, R, 1, R * R), B, R, R, 3, self.conv1, self.bn1, stride=2)
+        if ops.stem_conv_applies(R, w2) and img.dtype in (torch.float32, torch.float16):
+            # stem conv1 + bn1 + relu straight from the NCHW images (fp32 rounded to fp16 on the way): no cast pass, no im2col matrix
+            sc, sh = self._bn_affine("s1", self.bn1)
+            x = ops.stem_conv_bn(img, self._w3x3("s1", self.conv1), sc, sh, relu=True)
+        else:
+            if img.dtype == torch.float32:
+                img = ops.cast_f16(img)
+            img = img.contiguous()
+            # stem (clip/model.py:138-142): the NCHW image is read through its strides by the first im2col
+            x = self._conv3_bn_relu("s1", img, (3 * R * R, R, 1, R * R), B, R, R, 3, self.conv1, self.bn1, stride=2)
         H = W = (R - 1) // 2 + 1
         x = self._conv3_bn_relu("s2", x, (H * W * w2, W * w2, w2, 1), B, H, W, w2, self.conv2, self.bn2)
         x = self._conv3_bn_relu("s3", x, (H * W * w2, W * w2, w2, 1), B, H, W, w2, self.conv3, self.bn3)

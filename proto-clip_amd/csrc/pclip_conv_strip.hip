@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const half_t* __r
         const int tflags = (ty == 0 ? 1 : 0) | (ty == tiles_y - 1 ? 2 : 0) | (tx == 0 ? 4 : 0) | (tx == tiles_x - 1 ? 8 : 0);
         const unsigned org = (unsigned)((img * H + ty * ST_ROWS) * W + tx * ST_COLS) * (unsigned)PXB;
         pgemm::stress_jitter(110);
+        (void)tflags; (void)org; (void)rs;                            // (the host pass parses the lambda without the device-only builtins)
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
@@ -213,6 +214,84 @@ __global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const half_t* __r
             else if (mpart == 1) run(std::integral_constant<int, 7>{}, std::integral_constant<int, 7>{}, buf, yorg);
             else if (mpart == 2) run(std::integral_constant<int, 14>{}, std::integral_constant<int, 7>{}, buf, yorg);
             else run(std::integral_constant<int, 21>{}, std::integral_constant<int, 7>{}, buf, yorg);
+        }
+    }
+}
+
+// ---- the stem's first convolution: 3 -> COUT channels, 3x3, stride 2, pad 1, straight from the NCHW image (clip/model.py:100-102, 138 of the reference) ----
+// Before: pclip_im2col3x3_f16 wrote a [B * 112 * 112, 64] matrix (27 of 64 columns used: 411 MB at 256 images) for a GEMM with K = 64 — 0.43 ms of RN50's 5.4 ms per
+// 256 images, plus the fp32 -> fp16 cast of the images as a pass of its own.  Here a workgroup loads the 17 x 114-pixel input patch of an 8 x 56 output tile into LDS
+// (fp32 images are rounded to fp16 on the way, as the cast did), every lane assembles the 27 taps of its pixel into one MFMA operand (K = 32, zero beyond 27), and the
+// result leaves through the strip kernel's epilogue: BatchNorm + ReLU, 16-byte stores of 8 channels per (pixel, lane).  Memory-bound: 77 MB in, 205 MB out per 256 images.
+constexpr int SM_PR = 2 * ST_ROWS + 1, SM_PP = ST_COLS + 2, SM_PITCH = 2 * SM_PP + 2;     // patch rows, column PAIRS, pitch in halves (118: rows 8 apart fall 24 banks apart)
+
+template <bool F32IN, int COUT, int ACT>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const void* __restrict__ img, int R, int Ho, int Wo, const half_t* __restrict__ w, int ldw,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift, half_t* __restrict__ y) {
+    __shared__ __attribute__((aligned(16))) half_t patch[3 * SM_PR * SM_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = Wo / ST_COLS, tiles_y = Ho / ST_ROWS, tpi = tiles_x * tiles_y;
+    const int tile = blockIdx.x, b = tile / tpi, rem = tile - b * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const int oy0 = ty * ST_ROWS, ox0 = tx * ST_COLS;
+    // ---- the patch: input rows 2 oy0 - 1 .. 2 oy0 + 15, columns 2 ox0 - 2 .. 2 ox0 + 113 as aligned pairs; zeros outside the image ----
+    for (int q = tid; q < 3 * SM_PR * SM_PP; q += 256) {
+        const int ch = q / (SM_PR * SM_PP), r2 = q - ch * (SM_PR * SM_PP), pr = r2 / SM_PP, pp = r2 - pr * SM_PP;
+        const int yin = 2 * oy0 - 1 + pr, xin = 2 * ox0 - 2 + 2 * pp;
+        half2_t v = {(half_t)0.f, (half_t)0.f};
+        if (yin >= 0 && yin < R && xin >= 0 && xin + 1 < R) {
+            const size_t o = ((size_t)(b * 3 + ch) * R + yin) * R + xin;
+            if (F32IN) {
+                const float2 f = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(img) + o);
+                v = half2_t{(half_t)f.x, (half_t)f.y};
+            } else {
+                v = *reinterpret_cast<const half2_t*>(reinterpret_cast<const half_t*>(img) + o);
+            }
+        }
+        *reinterpret_cast<half2_t*>(patch + (ch * SM_PR + pr) * SM_PITCH + 2 * pp) = v;
+    }
+    // ---- weights (A operand: 16 output channels x K = 32 per fragment), BatchNorm constants of the lane's channels ----
+    const int c = lane & 15, kq = lane >> 4, ci = c & 7, hb = c >> 3;
+    constexpr int NH = COUT / 32;
+    half8_t wr[NH][2];
+    float sc[NH][8], sh[NH][8];
+#pragma unroll
+    for (int nh = 0; nh < NH; ++nh) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+            wr[nh][nb] = *reinterpret_cast<const half8_t*>(w + (size_t)(nh * 32 + (c >> 2) * 8 + nb * 4 + (c & 3)) * ldw + kq * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { sc[nh][i] = scale[nh * 32 + kq * 8 + i]; sh[nh][i] = shift[nh * 32 + kq * 8 + i]; }
+    }
+    // the lane's taps: k = kq * 8 + i = (ky * 3 + kx) * 3 + channel (the im2col column order of the weights), patch offset of tap k relative to the pixel's origin
+    int koff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = kq * 8 + i, tap = k / 3, ch = k - tap * 3, ky = tap / 3, kx = tap - ky * 3;
+        koff[i] = k < 27 ? (ch * SM_PR + ky) * SM_PITCH + kx + 1 : -1;
+    }
+    __syncthreads();
+    half_t* yorg = y + ((size_t)(b * Ho + oy0) * Wo + ox0) * COUT;
+#pragma unroll 1
+    for (int bi = 0; bi < 7; ++bi) {
+        const int blk = wave * 7 + bi, s = blk >> 2, j = blk & 3;
+        const int ly = j + 4 * hb, lx = 8 * s + ci;
+        const int po = 2 * ly * SM_PITCH + 2 * lx;
+        half8_t f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = koff[i] >= 0 ? patch[po + koff[i]] : (half_t)0.f;
+#pragma unroll
+        for (int nh = 0; nh < NH; ++nh) {
+            const float4_t z = {0.f, 0.f, 0.f, 0.f};
+            const float4_t a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[nh][0], f, z, 0, 0, 0);
+            const float4_t a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[nh][1], f, z, 0, 0, 0);
+            half8_t h;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = r16(r16(i < 4 ? a0[i & 3] : a1[i & 3]) * sc[nh][i] + sh[nh][i]);
+                if (ACT == 3) v = fmaxf(v, 0.f);
+                h[i] = (half_t)v;
+            }
+            *reinterpret_cast<half8_t*>(yorg + ((size_t)ly * Wo + lx) * COUT + nh * 32 + kq * 8) = h;
         }
     }
 }
@@ -274,4 +353,34 @@ int pclip_conv3x3_strip_launch(const void* x, const void* w, int B, int H, int W
         if (rc != PCLIP_OK) return rc;
     }
     return PCLIP_OK;
+}
+
+// The stem's first convolution + BatchNorm + ReLU straight from the NCHW images (fp32 or fp16): see stem_conv_kernel.  R even, ((R - 1) / 2 + 1) a multiple of 56 (and of
+// 8), Cout 32 or 64, w [Cout][64] in im2col column order (ky, kx, channel; zero beyond 27).
+extern "C" int pclip_stem_conv_applies(int R, int Cout) {
+    static const bool env_on = !(getenv("PCLIP_CONV_STEM") && getenv("PCLIP_CONV_STEM")[0] == '0');
+    const int Ho = (R - 1) / 2 + 1;
+    return env_on && R > 0 && R % 2 == 0 && Ho % ST_ROWS == 0 && Ho % ST_COLS == 0 && (Cout == 32 || Cout == 64);
+}
+
+extern "C" int pclip_stem_conv_bn_f16(const void* img, int img_is_f32, int B, int R, const void* w, int Cout, const float* scale, const float* shift, int relu, void* y,
+                                      pclip_stream_t stream) {
+    PCLIP_REQUIRE(img && w && scale && shift && y, "pclip_stem_conv_bn_f16: null pointer");
+    PCLIP_REQUIRE(B >= 0 && R > 0 && R % 2 == 0 && ((R - 1) / 2 + 1) % ST_COLS == 0 && ((R - 1) / 2 + 1) % ST_ROWS == 0,
+                  "pclip_stem_conv_bn_f16: image side %d unsupported (even, half of it a multiple of 56; use pclip_im2col3x3_f16 + pclip_gemm_bn_f16)", R);
+    PCLIP_REQUIRE(Cout == 32 || Cout == 64, "pclip_stem_conv_bn_f16: Cout=%d unsupported (32 or 64)", Cout);
+    PCLIP_REQUIRE(((uintptr_t)img & 7) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)y & 15) == 0, "pclip_stem_conv_bn_f16: pointers must be aligned (image 8, w / y 16 bytes)");
+    if (B == 0) return PCLIP_OK;
+    const int Ho = (R - 1) / 2 + 1, ntiles = B * (Ho / ST_ROWS) * (Ho / ST_COLS);
+    hipStream_t s = (hipStream_t)stream;
+#define PCLIP_STEM_CASE(F32, CO, ACT) stem_conv_kernel<F32, CO, ACT><<<ntiles, 256, 0, s>>>(img, R, Ho, Ho, (const half_t*)w, 64, scale, shift, (half_t*)y)
+    if (Cout == 32) {
+        if (img_is_f32) { if (relu) PCLIP_STEM_CASE(true, 32, 3); else PCLIP_STEM_CASE(true, 32, 2); }
+        else { if (relu) PCLIP_STEM_CASE(false, 32, 3); else PCLIP_STEM_CASE(false, 32, 2); }
+    } else {
+        if (img_is_f32) { if (relu) PCLIP_STEM_CASE(true, 64, 3); else PCLIP_STEM_CASE(true, 64, 2); }
+        else { if (relu) PCLIP_STEM_CASE(false, 64, 3); else PCLIP_STEM_CASE(false, 64, 2); }
+    }
+#undef PCLIP_STEM_CASE
+    return pclip_check_launch("stem_conv_bn");
 }

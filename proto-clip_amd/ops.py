@@ -514,6 +514,25 @@ def conv_strip_applies(B: int, H: int, W: int, Cin: int, Cout: int) -> bool:
     return bool(_lib.load().pclip_conv3x3_strip_applies(B, H, W, Cin, Cout))
 
 
+def stem_conv_applies(R: int, Cout: int) -> bool:
+    return bool(_lib.load().pclip_stem_conv_applies(R, Cout))
+
+
+def stem_conv_bn(img, w, scale, shift, relu: bool = True):
+    """relu?(bn(conv3x3 stride 2 pad 1)) of NCHW images [B, 3, R, R] (fp32 or fp16) -> NHWC rows [B * Ho * Ho, Cout] fp16, w [Cout, 64] in im2col column order
+    (clip/model.py:100-102, 138): no im2col matrix, no separate cast."""
+    require_cuda(img, w, scale, shift)
+    if img.dim() != 4 or img.shape[1] != 3 or img.shape[2] != img.shape[3] or img.dtype not in (torch.float32, torch.float16) or w.shape[1] != 64:
+        raise _lib.PclipError("stem_conv_bn: images [B, 3, R, R] fp32 / fp16 and w [Cout, 64] expected")
+    img, w = img.contiguous(), _f16c(w)
+    B, R, Cout = img.shape[0], img.shape[2], w.shape[0]
+    Ho = (R - 1) // 2 + 1
+    y = torch.empty(B * Ho * Ho, Cout, dtype=torch.float16, device=img.device)
+    check(_lib.load().pclip_stem_conv_bn_f16(ptr(img), int(img.dtype == torch.float32), B, R, ptr(w), Cout, ptr(scale), ptr(shift), int(relu), ptr(y), stream()),
+          "pclip_stem_conv_bn_f16")
+    return y
+
+
 def layernorm(x, gamma, beta, eps: float = 1e-5, out=None, rows: int = None, ld: int = None):
     """fp16 in/out LayerNorm with fp32 statistics and fp32 affine (clip/model.py:155-161)."""
     require_cuda(x, gamma, beta)

@@ -713,6 +713,41 @@ def test_conv3x3_strip_kernel(ops, B, H, W, Cin, Cout, relu):
         assert err.max().item() <= bound and err[m.reshape(-1)].max().item() <= bound, (err.max().item(), bound)
 
 
+@pytest.mark.parametrize("B,R,Cout,f32,relu", [(3, 224, 32, True, True), (2, 224, 64, False, True), (5, 112, 32, True, False), (70, 224, 32, True, True)])
+def test_stem_conv_from_nchw_images(ops, B, R, Cout, f32, relu):
+    """The stem's first convolution (3 -> Cout, stride 2) + bn1 + relu straight from the NCHW images (csrc/pclip_conv_strip.hip: stem_conv_kernel; clip/model.py:100-102, 138
+    of the reference) against the path it replaces — cast to fp16, pclip_im2col3x3_f16 through the image's strides, pclip_gemm_bn_f16 — on the same operands: one MFMA
+    K-step over the same 27 products, so the results are compared for EQUALITY first and, where the summation order of the two MFMA shapes differs, by the bound of one
+    ulp of the convolution's fp16 output; plus torch's fp32 conv2d.  Image borders (top / left padding; the last row / column are interior at an even side) included."""
+    assert ops.stem_conv_applies(R, Cout)
+    g = torch.Generator(device="cuda").manual_seed(B + R + Cout)
+    img = torch.randn(B, 3, R, R, device="cuda", generator=g)
+    if not f32:
+        img = img.half()
+    w = (torch.randn(Cout, 3, 3, 3, device="cuda", generator=g) * 27 ** -0.5).half()           # [Cout, ky, kx, channel]
+    w2 = torch.cat([w.reshape(Cout, 27), w.new_zeros(Cout, 37)], dim=1).contiguous()
+    ss = torch.stack([1 + 0.3 * torch.randn(Cout, device="cuda", generator=g), 0.2 * torch.randn(Cout, device="cuda", generator=g)]).contiguous()
+    got = ops.stem_conv_bn(img, w2, ss[0], ss[1], relu=relu)
+    i16 = (ops.cast_f16(img) if f32 else img).contiguous()
+    cols = ops.im2col3x3(i16, (3 * R * R, R, 1, R * R), B, R, R, 3, 2)
+    ref = ops.gemm_bn(cols, w2, ss[0], ss[1], relu=relu)
+    d = (got.float() - ref.float()).abs()
+    bound = 2.0 ** -10 * (2 * ref.float().abs() + ss[1].abs()[None, :]) * 1.01 + 2.0 ** -24
+    assert bool((d <= bound).all()), (d / bound).max().item()
+    frac = (d > 0).float().mean().item()
+    observe(f"stem conv 3->{Cout} R={R}: fraction of fp16 results differing from the im2col + GEMM path", frac, 5e-3)
+    assert frac <= 5e-3
+    if B <= 5:
+        Ho = R // 2
+        conv = torch.nn.functional.conv2d(i16.float().cpu(), w.permute(0, 3, 1, 2).float().cpu(), stride=2, padding=1).half().float()
+        yv = (conv * ss[0].cpu()[None, :, None, None] + ss[1].cpu()[None, :, None, None]).half().float()
+        if relu:
+            yv = yv.clamp_min(0)
+        yt = yv.permute(0, 2, 3, 1).reshape(B * Ho * Ho, Cout)
+        err = (got.float().cpu() - yt).abs()
+        assert err.max().item() <= 4e-3 * yt.abs().max().item(), err.max().item()
+
+
 @pytest.mark.parametrize("B,L,H,Lq", [(5, 197, 12, 1), (3, 50, 12, 1), (2, 257, 16, 1), (4, 197, 12, 40), (2, 77, 8, 77), (2, 280, 4, 200), (3, 257, 16, 160), (2, 288, 2, 256)])      # the last three: 5 - 8 query tiles against MORE than 8 key tiles (ADVICE r4: the query-first kernel must not take them)
 def test_attention_first_queries_matches_full_attention(ops, B, L, H, Lq):
     """Separate-operand attention (queries of the first Lq tokens, keys / values of all tokens) against the fused-QKV kernel:
