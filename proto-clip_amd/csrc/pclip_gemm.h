@@ -86,20 +86,46 @@ __device__ __forceinline__ void wait_vm() {
     stress_jitter(2 + N);
 }
 
-// All waves of the workgroup stage a ROWS x 64 tile: each glds piece is 8 rows x 128 B (64 lanes x 16 B).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+#else
+struct rsrc_t { int w[4]; };                     // the host pass only parses the kernels; the descriptor type is device-only
+#endif
+
+// A buffer descriptor over [base, base + bytes): LDS-DMA through buffer_load ... lds instead of global_load_lds.  Two reasons (round 6, csrc/pclip_conv_strip.hip):
+// (i) hipcc models a FLAT-encoded LDS load as "may touch LDS and memory": while one is in flight EVERY LDS wait it emits is lgkmcnt(0) — a K-loop that prefetches its
+// next tile by global_load_lds cannot overlap its fragment reads with its MFMAs; behind a buffer load the waits are counted (lgkmcnt(N)); (ii) offsets beyond `bytes`
+// return zeros: padding without a zero line.  The inputs go through readfirstlane: hipcc must be able to PROVE the descriptor wave-uniform, otherwise every buffer op
+// is wrapped in a waterfall loop (guide T20).
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t addr = (uint64_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)addr), hi = __builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+#else
+    return rsrc_t{};
+#endif
+}
+
+// All waves of the workgroup stage a ROWS x 64 tile: each LDS-DMA piece is 8 rows x 128 B (64 lanes x 16 B).  The descriptor starts at the tile's first row, so
+// the lane offsets stay small whatever the matrix (rows beyond nrows re-read the last row: never stored).
 template <int ROWS, int NWAVES>
 __device__ __forceinline__ void stage_tile(const half_t* __restrict__ g, int ld, int row0, int nrows, int k0,
                                            char* lds_tile, int wave, int lane) {
     constexpr int RPW = ROWS / NWAVES;                               // rows per wave
+    const rsrc_t rs = make_rsrc(g + (size_t)row0 * ld, 0x7fffffffu);
+    const int last = nrows - 1 - row0;
+    (void)rs; (void)last;
 #pragma unroll
     for (int i = 0; i < RPW / 8; ++i) {
         const int r = wave * RPW + i * 8 + (lane >> 3);              // tile row this lane fills
         const int c = (lane & 7) ^ swz_key(r);                       // source chunk for LDS slot (lane&7)
-        int gr = row0 + r;
-        gr = gr < nrows ? gr : nrows - 1;                            // clamp: out-of-range rows are never stored
-        const half_t* src = g + (size_t)gr * ld + k0 + c * 8;
+        const int voff = ((r < last ? r : last) * ld + k0 + c * 8) * 2;
         char* dst = lds_tile + (wave * RPW + i * 8) * ROW_BYTES;     // wave-uniform base; HW adds lane*16
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+        (void)voff; (void)dst;
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, voff, 0, 0, 0);
+#endif
     }
 }
 
@@ -267,11 +293,6 @@ __device__ __forceinline__ void mainloop(const half_t* __restrict__ A, int lda, 
 // of its B columns) x one 32-wide k-step: while the 2*TM*TN MFMAs of a group issue, the next group's fragments are already
 // on their way from LDS (A next half; B of the next k-step during the second half).  Only the first group of a K-tile waits
 // for LDS with nothing to cover it.  Same k-order per accumulator as mainloop_g's M16 branch: bit-identical results.
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-#else
-struct rsrc_t { int w[4]; };                     // the host pass only parses the kernels; the descriptor type is device-only
-#endif
 
 #ifndef PCLIP_NT_A
 #define PCLIP_NT_A 0             // cache-policy bits of the A-operand LDS-DMA (2 = nt measured 7 % slower: every A line has 3 - 12 readers)
@@ -520,16 +541,18 @@ __device__ __forceinline__ void mainloop_sr(const TP& tp, int nt, char* smem, Ac
 
 // ---- implicit-GEMM gather for a 3x3 / stride 1 / pad 1 convolution on NHWC fp16 activations ------------------------------
 // Row m of the GEMM is output pixel (b, y, x); K-tile t covers tap = (t*64) / Cin and input channels c0 = (t*64) % Cin
-// (Cin % 64 == 0; Cin = 8 / 16 / 32 take the per-chunk path of stage()), i.e. the 128 contiguous bytes x[b, y+dy-1, x+dx-1, c0 .. c0+63] — or 128 zero bytes outside the image,
-// fetched from a caller-provided zero line, because an LDS-DMA cannot be predicated per lane without leaving stale LDS.
+// (Cin % 64 == 0; Cin = 8 / 16 / 32 take the per-chunk path of stage()), i.e. the 128 contiguous bytes x[b, y+dy-1, x+dx-1, c0 .. c0+63] — or 128 zero bytes outside the image:
+// a buffer load beyond the descriptor's range (an LDS-DMA cannot be predicated per lane without leaving stale LDS; round 6: was a caller-provided zero line).
 // The im2col matrix (9x the activation) is never materialised.
 template <class C>
 struct ConvGather {
     static constexpr int NR = C::BM / C::NWAVES / 8;       // A rows per lane
     const half_t* __restrict__ x;
-    const half_t* __restrict__ zero;
     int H, W, Cin, M;
+    rsrc_t rs;                                             // over the M x Cin activations: a tap outside the image takes an offset beyond it (zeros)
     int pix[NR], yx[NR];
+    __device__ __forceinline__ ConvGather(const half_t* x_, int H_, int W_, int Cin_, int M_)
+        : x(x_), H(H_), W(W_), Cin(Cin_), M(M_), rs(make_rsrc(x_, (unsigned)M_ * (unsigned)Cin_ * 2u)) {}
     __device__ __forceinline__ void prepare(int m0) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -545,7 +568,7 @@ struct ConvGather {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         if (Cin < BK) {
             // Cin = 8 / 16 / 32 (the ResNet stem): a K-tile spans 64 / Cin taps, so the tap belongs to the 16-byte chunk, not to the
-            // row; taps >= 9 (K padded to the K-tile, zero weights there) read the zero line
+            // row; taps >= 9 (K padded to the K-tile, zero weights there) read zeros
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
                 const int r = wave * (C::BM / C::NWAVES) + i * 8 + (lane >> 3);
@@ -553,8 +576,11 @@ struct ConvGather {
                 const int k = t * BK + c * 8, tap = k / Cin, ci = k - tap * Cin, dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
                 const int y = (yx[i] >> 16) + dy, xx = (yx[i] & 0xffff) + dx;
                 const bool in = tap < 9 && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
-                const half_t* src = in ? x + ((size_t)(pix[i] + dy * W + dx) * Cin + ci) : zero + c * 8;
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dst + (wave * (C::BM / C::NWAVES) + i * 8) * ROW_BYTES), 16, 0, 0);
+                const unsigned voff = in ? (unsigned)((pix[i] + dy * W + dx) * Cin + ci) * 2u : 0xfffffff0u;
+                (void)voff;
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + (wave * (C::BM / C::NWAVES) + i * 8) * ROW_BYTES), 16, (int)voff, 0, 0, 0);
+#endif
             }
             return;
         }
@@ -565,8 +591,11 @@ struct ConvGather {
             const int c = (lane & 7) ^ swz_key(r);
             const int y = (yx[i] >> 16) + dy, xx = (yx[i] & 0xffff) + dx;
             const bool in = (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
-            const half_t* src = in ? x + ((size_t)(pix[i] + dy * W + dx) * Cin + c0 + c * 8) : zero + c * 8;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dst + (wave * (C::BM / C::NWAVES) + i * 8) * ROW_BYTES), 16, 0, 0);
+            const unsigned voff = in ? (unsigned)((pix[i] + dy * W + dx) * Cin + c0 + c * 8) * 2u : 0xfffffff0u;
+            (void)voff;
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + (wave * (C::BM / C::NWAVES) + i * 8) * ROW_BYTES), 16, (int)voff, 0, 0, 0);
+#endif
         }
     }
 };

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv3x3_fast_kernel(const half
     if (tile >= ntiles) return;
     const int nt = (9 * Cin + pgemm::BK - 1) / pgemm::BK, ldb = nt * pgemm::BK;    // w rows are zero-padded to the K-tile (Cin < 64)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave % C::WN;
-    pgemm::ConvGather<C> ga{x, zero, H, W, Cin, M, {}, {}};
+    pgemm::ConvGather<C> ga(x, H, W, Cin, M);
     auto copy_affine = [&](int t, int par) {
         const int tn = t - (t / tiles_n) * tiles_n;
         if (lane < C::BN / 4) {
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void conv3x3_small_kernel(co
     const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
     const int nt = (9 * Cin + pgemm::BK - 1) / pgemm::BK, K = nt * pgemm::BK;       // w rows are zero-padded to the K-tile (Cin < 64)
     const int tid = threadIdx.x, wave = tid >> 6, wn = wave % C::WN;
-    pgemm::ConvGather<C> ga{x, zero, H, W, Cin, M, {}, {}};
+    pgemm::ConvGather<C> ga(x, H, W, Cin, M);
     ga.prepare(m0);
     pgemm::Acc<C> acc;
     pgemm::mainloop_ring_g<C, kSmallStages>([&](int t, char* dst) { ga.stage(t, dst); }, w, K, N, nt, n0, smem, acc, [&]() {
@@ -908,6 +908,19 @@ extern "C" int pclip_conv3x3_bn_f16(const void* x, const void* w, const void* ze
     int cus = pclip_device_cus();
     if (cus <= 0) cus = 256;
     hipStream_t s = (hipStream_t)stream;
+    // the gather addresses the activations through a buffer descriptor with 32-bit offsets: a larger batch goes in slices of whole images (same kernels, same bits)
+    const long per_image = (long)H * W * Cin * 2;
+    PCLIP_REQUIRE(per_image < (1L << 31), "pclip_conv3x3_bn_f16: one image of %ld bytes is too large", per_image);
+    if ((long)B * per_image >= (1L << 31)) {
+        const int slice = (int)((1L << 31) / per_image);
+        for (int b0 = 0; b0 < B; b0 += slice) {
+            const int nb = B - b0 < slice ? B - b0 : slice;
+            if (int e = pclip_conv3x3_bn_f16((const char*)x + (size_t)b0 * per_image, w, zero_line, nb, H, W, Cin, Cout, scale, shift, relu,
+                                             (char*)y + (size_t)b0 * H * W * Cout * 2, stream))
+                return e;
+        }
+        return PCLIP_OK;
+    }
     if (pclip_conv3x3_strip_applies(B, H, W, Cin, Cout))                        // narrow layers at 56 x 56 / 112 x 112: weights in registers, halo blocks in LDS
         return pclip_conv3x3_strip_launch(x, w, B, H, W, Cin, Cout, scale, shift, relu, y, cus, s);
     if (Cout == 32)                                                             // the stem's 32 -> 32 convolution: 256 x 32 tiles
