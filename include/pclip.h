@@ -252,6 +252,13 @@ int pclip_conv3x3_strip_config(int mode);
  * cast pass (clip/model.py:100-102, 138).  w [Cout][64] fp16: the im2col column order (ky, kx, channel), zero beyond column 27 — the operand pclip_gemm_bn_f16 takes
  * after pclip_im2col3x3_f16, and the same arithmetic.  R even, Ho a multiple of 56, Cout 32 or 64 (pclip_stem_conv_applies; PCLIP_CONV_STEM=0 turns the routing of
  * the python model off); PCLIP_E_INVALID otherwise. */
+/* relu(bn(conv3x3(x))) followed by nn.AvgPool2d(2) in one launch (the stem's conv3 / bn3 / relu / avgpool, clip/model.py:104-105, 142-143): y [B * (H / 2) * (W / 2), Cout].
+ * The same bits as pclip_conv3x3_bn_f16 + pclip_avgpool_nhwc_f16 without writing and re-reading the unpooled activation.  Cin 32, Cout 64, H % 8 == 0, W % 56 == 0
+ * (pclip_conv3x3_pool_applies, which also honours PCLIP_CONV_STRIP / pclip_conv3x3_strip_config); PCLIP_E_INVALID otherwise. */
+int pclip_conv3x3_pool_applies(int H, int W, int Cin, int Cout);
+int pclip_conv3x3_bn_pool_f16(const void* x, const void* w, int B, int H, int W, int Cin, int Cout, const float* scale, const float* shift, void* y,
+                              pclip_stream_t stream);
+
 int pclip_stem_conv_applies(int R, int Cout);
 int pclip_stem_conv_bn_f16(const void* img, int img_is_f32, int B, int R, const void* w, int Cout, const float* scale, const float* shift, int relu, void* y,
                            pclip_stream_t stream);

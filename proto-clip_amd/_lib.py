@@ -63,6 +63,8 @@ _SIGS = {
     "pclip_conv3x3_bn_f16": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P],
     "pclip_conv3x3_strip_applies": [c_int, c_int, c_int, c_int, c_int],
     "pclip_conv3x3_strip_config": [c_int],
+    "pclip_conv3x3_pool_applies": [c_int, c_int, c_int, c_int],
+    "pclip_conv3x3_bn_pool_f16": [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P],
     "pclip_stem_conv_applies": [c_int, c_int],
     "pclip_stem_conv_bn_f16": [_P, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, _P],
     "pclip_layernorm_f16": [_P, c_int, _P, _P, c_float, _P, c_int, c_int, _P],

@@ -352,9 +352,13 @@ class ModifiedResNet(nn.Module):
             x = self._conv3_bn_relu("s1", img, (3 * R * R, R, 1, R * R), B, R, R, 3, self.conv1, self.bn1, stride=2)
         H = W = (R - 1) // 2 + 1
         x = self._conv3_bn_relu("s2", x, (H * W * w2, W * w2, w2, 1), B, H, W, w2, self.conv2, self.bn2)
-        x = self._conv3_bn_relu("s3", x, (H * W * w2, W * w2, w2, 1), B, H, W, w2, self.conv3, self.bn3)
         C = self.conv3.weight.shape[0]
-        x = ops.avgpool_nhwc(x, B, H, W, C, 2)
+        if ops.conv3x3_pool_applies(H, W, w2, C):           # conv3 + bn3 + relu + avgpool(2) in one launch (the same bits)
+            sc, sh = self._bn_affine("s3", self.bn3)
+            x = ops.conv3x3_bn_pool(x, self._w3x3("s3", self.conv3), sc, sh, B, H, W, w2)
+        else:
+            x = self._conv3_bn_relu("s3", x, (H * W * w2, W * w2, w2, 1), B, H, W, w2, self.conv3, self.bn3)
+            x = ops.avgpool_nhwc(x, B, H, W, C, 2)
         H, W = H // 2, W // 2
         for li in (1, 2, 3, 4):
             for bi, blk in enumerate(getattr(self, f"layer{li}")):

@@ -24,6 +24,7 @@
 
 namespace {
 
+typedef int int4_t __attribute__((ext_vector_type(4)));
 constexpr int ST_ROWS = 8, ST_COLS = 56, ST_HR = ST_ROWS + 2, ST_HC = ST_COLS + 2;
 
 template <int CIN>
@@ -94,7 +95,10 @@ __device__ __forceinline__ void strip_compute(const char* __restrict__ buf, cons
     });
 }
 
-template <int CIN, int COUT, int ACT>
+// POOL: the 2 x 2 average pool behind the convolution (the stem's conv3 -> bn3 -> relu -> avgpool, clip/model.py:104-105, 142-143) in the epilogue — y is the POOLED
+// image [B, H / 2, W / 2, COUT]: the fp16 results of a window (rows j, j + 1: two blocks of the lane; columns: the neighbouring lane, one DPP exchange) are summed in
+// pclip_avgpool_nhwc_f16's order and rounded once — the same bits without writing and re-reading the 4x larger activation.
+template <int CIN, int COUT, int ACT, bool POOL = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w, int ldw,
                                                                int H, int W, int ntiles, const float* __restrict__ scale, const float* __restrict__ shift,
                                                                half_t* __restrict__ y) {
@@ -183,9 +187,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const half_t* __r
         for (int b = 0; b < NB; ++b) { acc[b][0] = float4_t{0.f, 0.f, 0.f, 0.f}; acc[b][1] = float4_t{0.f, 0.f, 0.f, 0.f}; }
         strip_compute<CIN, B0, NB>(buf, base, wr, acc);
         // BatchNorm (+ ReLU) with the implicit-GEMM kernel's rounding points (r16(acc): the convolution's fp16 output; r16 of the affine), 16-byte stores
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int s = (B0 + b) >> 2, j = (B0 + b) & 3;
+        auto finish = [&](int b) {
             half8_t h;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -193,7 +195,38 @@ __global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const half_t* __r
                 if (ACT == 3) v = fmaxf(v, 0.f);
                 h[i] = (half_t)v;
             }
-            *reinterpret_cast<half8_t*>(yorg + ((size_t)(j + 4 * hb) * W + 8 * s + ci) * COUT + co0) = h;
+            return h;
+        };
+        if constexpr (POOL) {
+            static_assert(!POOL || (B0 % 2 == 0 && NB % 2 == 0), "a window's two rows are consecutive blocks of one wave");
+#pragma unroll
+            for (int b = 0; b < NB; b += 2) {
+                const int s = (B0 + b) >> 2, j = (B0 + b) & 3;                // j = 0 / 2: rows (j, j + 1) of both halves
+                const half8_t h0 = finish(b), h1 = finish(b + 1);
+                const int4_t i0 = __builtin_bit_cast(int4_t, h0), i1 = __builtin_bit_cast(int4_t, h1);
+                int4_t n0, n1;                                                // the neighbouring column's values (lane ^ 1)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    n0[e] = __builtin_amdgcn_update_dpp(0, i0[e], 0xB1, 0xF, 0xF, false);      // quad_perm [1, 0, 3, 2]
+                    n1[e] = __builtin_amdgcn_update_dpp(0, i1[e], 0xB1, 0xF, 0xF, false);
+                }
+                const half8_t g0 = __builtin_bit_cast(half8_t, n0), g1 = __builtin_bit_cast(half8_t, n1);
+                half8_t o;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {                                  // (dy 0, dx 0), (0, 1), (1, 0), (1, 1): pclip_avgpool_nhwc_f16's order, for the even column
+                    float a = 0.f;
+                    a += (float)h0[i]; a += (float)g0[i]; a += (float)h1[i]; a += (float)g1[i];
+                    o[i] = (half_t)(a * 0.25f);
+                }
+                if (!(ci & 1))
+                    *reinterpret_cast<half8_t*>(yorg + ((size_t)((j >> 1) + 2 * hb) * (W >> 1) + 4 * s + (ci >> 1)) * COUT + co0) = o;
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int s = (B0 + b) >> 2, j = (B0 + b) & 3;
+                *reinterpret_cast<half8_t*>(yorg + ((size_t)(j + 4 * hb) * W + 8 * s + ci) * COUT + co0) = finish(b);
+            }
         }
     };
 
@@ -204,9 +237,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const half_t* __r
         pgemm::lds_barrier();                                         // everybody's pieces; everybody is done reading the other buffer
         if (tile + G < ntiles) issue(tile + G, p ^ 1);
         const int img = tile / tpi, rem = tile - img * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
-        half_t* yorg = y + ((size_t)(img * H + ty * ST_ROWS) * W + tx * ST_COLS) * COUT;
+        half_t* yorg = POOL ? y + ((size_t)(img * (H >> 1) + ty * (ST_ROWS / 2)) * (W >> 1) + tx * (ST_COLS / 2)) * COUT
+                            : y + ((size_t)(img * H + ty * ST_ROWS) * W + tx * ST_COLS) * COUT;
         const char* buf = smem + p * Geo::BUF;
-        if (COUT == 64) {
+        if constexpr (COUT == 64) {
             if (mpart == 0) run(std::integral_constant<int, 0>{}, std::integral_constant<int, 14>{}, buf, yorg);
             else run(std::integral_constant<int, 14>{}, std::integral_constant<int, 14>{}, buf, yorg);
         } else {
@@ -298,19 +332,19 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const void* __restrict__
 
 int g_strip_mode = -1;                                                // -1: environment (PCLIP_CONV_STRIP, default on), 0 off, 1 on
 
-template <int CIN, int COUT, int ACT>
+template <int CIN, int COUT, int ACT, bool POOL = false>
 int launch_strip(const void* x, const void* w, int B, int H, int W, const float* scale, const float* shift, void* y, int cus, hipStream_t s) {
     static DevOnce attr;
     constexpr int LDS = 2 * StripGeo<CIN>::BUF;
     if (!attr.done()) {
-        if (hipFuncSetAttribute((const void*)conv3x3_strip_kernel<CIN, COUT, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)conv3x3_strip_kernel<CIN, COUT, ACT, POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
             pclip_set_error("pclip_conv3x3_bn_f16: cannot raise the dynamic LDS limit to %d", LDS);
             return PCLIP_E_LAUNCH;
         }
         attr.set();
     }
     const int ntiles = B * (H / ST_ROWS) * (W / ST_COLS), ldw = (9 * CIN + 63) / 64 * 64;
-    conv3x3_strip_kernel<CIN, COUT, ACT><<<ntiles < cus ? ntiles : cus, 256, LDS, s>>>((const half_t*)x, (const half_t*)w, ldw, H, W, ntiles, scale,
+    conv3x3_strip_kernel<CIN, COUT, ACT, POOL><<<ntiles < cus ? ntiles : cus, 256, LDS, s>>>((const half_t*)x, (const half_t*)w, ldw, H, W, ntiles, scale,
                                                                                       shift, (half_t*)y);
     return pclip_check_launch("conv3x3_bn (strip)");
 }
@@ -333,15 +367,20 @@ extern "C" int pclip_conv3x3_strip_config(int mode) {
 }
 
 int pclip_conv3x3_strip_launch(const void* x, const void* w, int B, int H, int W, int Cin, int Cout, const float* scale, const float* shift, int relu,
-                               void* y, int cus, hipStream_t s) {
+                               void* y, int cus, hipStream_t s, int pool) {
     // the buffer descriptor addresses 2^31 bytes: larger batches go in slices of whole images (the same kernel, the same bits)
     const long per_image = (long)H * W * Cin * 2;
     const int slice = (int)((1L << 31) / per_image);
     for (int b0 = 0; b0 < B; b0 += slice) {
         const int nb = B - b0 < slice ? B - b0 : slice;
         const void* xs = (const char*)x + (size_t)b0 * per_image;
-        void* ys = (char*)y + (size_t)b0 * H * W * Cout * 2;
+        void* ys = (char*)y + (size_t)b0 * (H / pool) * (W / pool) * Cout * 2;
         int rc = PCLIP_E_INVALID;
+        if (pool == 2) {
+            if (Cin == 32 && Cout == 64 && relu) rc = launch_strip<32, 64, 3, true>(xs, w, nb, H, W, scale, shift, ys, cus, s);
+            if (rc != PCLIP_OK) return rc;
+            continue;
+        }
 #define PCLIP_STRIP_CASE(CI, CO)                                                                                             \
     if (Cin == CI && Cout == CO)                                                                                             \
         rc = relu ? launch_strip<CI, CO, 3>(xs, w, nb, H, W, scale, shift, ys, cus, s) : launch_strip<CI, CO, 2>(xs, w, nb, H, W, scale, shift, ys, cus, s);
@@ -383,4 +422,23 @@ extern "C" int pclip_stem_conv_bn_f16(const void* img, int img_is_f32, int B, in
     }
 #undef PCLIP_STEM_CASE
     return pclip_check_launch("stem_conv_bn");
+}
+
+// relu(bn(conv3x3(x))) followed by nn.AvgPool2d(2), in one launch: y [B * (H / 2) * (W / 2), Cout] — the stem's conv3 / bn3 / relu / avgpool (clip/model.py:104-105,
+// 142-143).  Same bits as pclip_conv3x3_bn_f16 (strip kernel) + pclip_avgpool_nhwc_f16.  Shapes: pclip_conv3x3_pool_applies (Cin 32, Cout 64, H % 8 == 0, W % 56 == 0).
+extern "C" int pclip_conv3x3_pool_applies(int H, int W, int Cin, int Cout) {
+    static const bool env_on = !(getenv("PCLIP_CONV_POOL") && getenv("PCLIP_CONV_POOL")[0] == '0');
+    return env_on && pclip_conv3x3_strip_applies(1, H, W, Cin, Cout) && Cin == 32 && Cout == 64;
+}
+
+extern "C" int pclip_conv3x3_bn_pool_f16(const void* x, const void* w, int B, int H, int W, int Cin, int Cout, const float* scale, const float* shift, void* y,
+                                         pclip_stream_t stream) {
+    PCLIP_REQUIRE(x && w && scale && shift && y, "pclip_conv3x3_bn_pool_f16: null pointer");
+    PCLIP_REQUIRE(B >= 0 && H > 0 && W > 0 && pclip_conv3x3_pool_applies(H, W, Cin, Cout),
+                  "pclip_conv3x3_bn_pool_f16: shape H=%d W=%d Cin=%d Cout=%d not supported (pclip_conv3x3_pool_applies; use pclip_conv3x3_bn_f16 + pclip_avgpool_nhwc_f16)", H, W, Cin, Cout);
+    PCLIP_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)y & 15) == 0, "pclip_conv3x3_bn_pool_f16: pointers must be 16-byte aligned");
+    if (B == 0) return PCLIP_OK;
+    int cus = pclip_device_cus();
+    if (cus <= 0) cus = 256;
+    return pclip_conv3x3_strip_launch(x, w, B, H, W, Cin, Cout, scale, shift, 1, y, cus, (hipStream_t)stream, 2);
 }

@@ -893,7 +893,7 @@ int launch_conv(const void* x, const void* zero, const void* w, int B, int H, in
 // pclip_conv_strip.hip
 extern "C" int pclip_conv3x3_strip_applies(int B, int H, int W, int Cin, int Cout);
 int pclip_conv3x3_strip_launch(const void* x, const void* w, int B, int H, int W, int Cin, int Cout, const float* scale, const float* shift, int relu,
-                               void* y, int cus, hipStream_t s);
+                               void* y, int cus, hipStream_t s, int pool);
 
 extern "C" int pclip_conv3x3_bn_f16(const void* x, const void* w, const void* zero_line, int B, int H, int W, int Cin, int Cout,
                                     const float* scale, const float* shift, int relu, void* y, pclip_stream_t stream) {
@@ -922,7 +922,7 @@ extern "C" int pclip_conv3x3_bn_f16(const void* x, const void* w, const void* ze
         return PCLIP_OK;
     }
     if (pclip_conv3x3_strip_applies(B, H, W, Cin, Cout))                        // narrow layers at 56 x 56 / 112 x 112: weights in registers, halo blocks in LDS
-        return pclip_conv3x3_strip_launch(x, w, B, H, W, Cin, Cout, scale, shift, relu, y, cus, s);
+        return pclip_conv3x3_strip_launch(x, w, B, H, W, Cin, Cout, scale, shift, relu, y, cus, s, 1);
     if (Cout == 32)                                                             // the stem's 32 -> 32 convolution: 256 x 32 tiles
         return launch_conv<CfgThin>(x, zero_line, w, B, H, W, Cin, Cout, scale, shift, relu, y, 2 * cus, s);
     static const bool small_on = !(getenv("PCLIP_GEMM_SMALL") && getenv("PCLIP_GEMM_SMALL")[0] == '0');

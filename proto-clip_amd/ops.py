@@ -514,6 +514,22 @@ def conv_strip_applies(B: int, H: int, W: int, Cin: int, Cout: int) -> bool:
     return bool(_lib.load().pclip_conv3x3_strip_applies(B, H, W, Cin, Cout))
 
 
+def conv3x3_pool_applies(H: int, W: int, Cin: int, Cout: int) -> bool:
+    return bool(_lib.load().pclip_conv3x3_pool_applies(H, W, Cin, Cout))
+
+
+def conv3x3_bn_pool(x, w, scale, shift, B: int, H: int, W: int, Cin: int):
+    """avgpool2(relu(bn(conv3x3(x)))) in one launch: [B * (H / 2) * (W / 2), Cout] (the stem's tail, clip/model.py:104-105, 142-143)."""
+    require_cuda(x, w, scale, shift)
+    x, w = _f16c(x), _f16c(w)
+    Cout = w.shape[0]
+    if w.shape[1] != (9 * Cin + 63) // 64 * 64 or x.numel() != B * H * W * Cin:
+        raise _lib.PclipError("conv3x3_bn_pool: shape mismatch")
+    y = torch.empty(B * (H // 2) * (W // 2), Cout, dtype=torch.float16, device=x.device)
+    check(_lib.load().pclip_conv3x3_bn_pool_f16(ptr(x), ptr(w), B, H, W, Cin, Cout, ptr(scale), ptr(shift), ptr(y), stream()), "pclip_conv3x3_bn_pool_f16")
+    return y
+
+
 def stem_conv_applies(R: int, Cout: int) -> bool:
     return bool(_lib.load().pclip_stem_conv_applies(R, Cout))
 

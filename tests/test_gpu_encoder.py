@@ -713,6 +713,22 @@ def test_conv3x3_strip_kernel(ops, B, H, W, Cin, Cout, relu):
         assert err.max().item() <= bound and err[m.reshape(-1)].max().item() <= bound, (err.max().item(), bound)
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 112, 112), (40, 8, 56), (70, 112, 112), (5, 16, 112)])
+def test_conv3x3_bn_relu_avgpool_in_one_launch(ops, B, H, W):
+    """The stem's tail — conv3 / bn3 / relu / AvgPool2d(2), clip/model.py:104-105, 142-143 of the reference — in one launch (the strip kernel's pooling epilogue) must
+    be pclip_conv3x3_bn_f16 followed by pclip_avgpool_nhwc_f16 bit for bit."""
+    Cin, Cout = 32, 64
+    assert ops.conv3x3_pool_applies(H, W, Cin, Cout)
+    g = torch.Generator(device="cuda").manual_seed(B + H)
+    x = (torch.randn(B * H * W, Cin, device="cuda", generator=g) * 0.7).half()
+    w = (torch.randn(Cout, 320, device="cuda", generator=g) * 288 ** -0.5).half()
+    w[:, 288:] = 0
+    sc, sh = 1 + 0.3 * torch.randn(Cout, device="cuda", generator=g), 0.2 * torch.randn(Cout, device="cuda", generator=g)
+    ref = ops.avgpool_nhwc(ops.conv3x3_bn(x, w, sc, sh, B, H, W, Cin, relu=True), B, H, W, Cout, 2)
+    got = ops.conv3x3_bn_pool(x, w, sc, sh, B, H, W, Cin)
+    assert got.shape == ref.shape and torch.equal(got, ref)
+
+
 @pytest.mark.parametrize("B,R,Cout,f32,relu", [(3, 224, 32, True, True), (2, 224, 64, False, True), (5, 112, 32, True, False), (70, 224, 32, True, True)])
 def test_stem_conv_from_nchw_images(ops, B, R, Cout, f32, relu):
     """The stem's first convolution (3 -> Cout, stride 2) + bn1 + relu straight from the NCHW images (csrc/pclip_conv_strip.hip: stem_conv_kernel; clip/model.py:100-102, 138
