@@ -142,7 +142,11 @@ __global__ __launch_bounds__(2 * SL * 64) void classify_mid_kernel(const half_t*
             // pgemm::stage_tile's addressing), the hardware places lane l at base + 16 l.  PFD blocks in flight; block b + PFD lands in the slot block b - 1 was read
             // from (its fragments are in registers: the MFMAs that consumed them precede the request).  Every wait is the wave's own counted vmcnt — the ring is private.
             constexpr int PFD = mid_ring_slots(SL) - 1, NSLOT = PFD + 1;
-            const half_t* zsrc[TPW][2];
+            // (BUFFER LDS-DMA, the k-block in the scalar offset: behind a FLAT-encoded global_load_lds hipcc answers every LDS wait with lgkmcnt(0) while the piece
+            // is in flight — here always — pclip_gemm.h: make_rsrc)
+            const pgemm::rsrc_t rs = pgemm::make_rsrc(z, (unsigned)N * (unsigned)D * 2u);
+            (void)rs;
+            int zoff[TPW][2];
 #pragma unroll
             for (int i = 0; i < TPW; ++i)
 #pragma unroll
@@ -152,14 +156,17 @@ __global__ __launch_bounds__(2 * SL * 64) void classify_mid_kernel(const half_t*
                     asm volatile("" : "+v"(r));                                         // opaque: see zrow
 #endif
                     const int c = (slot + MID_SLOTS * i) * 16 + r;
-                    zsrc[i][j] = z + (size_t)(c < N ? c : N - 1) * D + ((lch ^ ((r >> 1) & 7)) << 3);
+                    zoff[i][j] = ((c < N ? c : N - 1) * D + ((lch ^ ((r >> 1) & 7)) << 3)) * 2;
                 }
             auto request = [&](int b) {
                 const int kb = b / TPW, i = b % TPW;
                 char* dst = tbuf + (b % NSLOT) * 2048;
+                (void)kb; (void)dst;
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(zsrc[i][j] + kb * 64), (pgemm::lds_ptr_t)(dst + j * 1024), 16, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (pgemm::lds_ptr_t)(dst + j * 1024), 16, zoff[i][j], kb * 128, 0, 0);
+#endif
             };
 #pragma unroll
             for (int b = 0; b < PFD && b < NBLK; ++b) request(b);

@@ -4,7 +4,7 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from proto_clip_amd.clip.model import BACKBONES, build_model, random_state_dict
 GF = {"ViT-B/32": 8.8, "ViT-B/16": 35.1, "ViT-L/14": 162.0, "RN50": 12.2, "RN101": 19.6}     # GFLOP per image
-for name, B in (("ViT-B/32", 1024), ("ViT-B/16", 1024), ("ViT-L/14", 512), ("RN50", 256), ("RN101", 256)):
+for name, B in (("ViT-B/32", 1024), ("ViT-B/16", 1024), ("ViT-L/14", 512), ("RN50", 256), ("RN50", 1024), ("RN101", 256), ("RN101", 1024)):
     kw = BACKBONES[name]
     model = build_model(random_state_dict(seed=1, **kw)).cuda()
     x = torch.randn(B, 3, kw["image_resolution"], kw["image_resolution"], device="cuda")

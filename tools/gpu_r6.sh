@@ -13,7 +13,7 @@ cp $R/gpurun_out/prof_r06_$TAG/bench_kernel_stats.csv $R/gpurun_out/r06_bench_${
 head -14 $R/gpurun_out/r06_bench_${TAG}_kernel_stats.csv | cut -d, -f1-4 | cut -c1-180
 python $R/tools/roofline_check.py $R/gpurun_out/r06_bench_$TAG.json $R/gpurun_out/r06_bench_${TAG}_kernel_stats.csv | tee $R/gpurun_out/r06_roofline_check_$TAG.txt
 cd $R
-( echo "== small_bench"; python tools/small_bench.py; echo "== encoder_bench"; python tools/encoder_bench.py; echo "== adapter_bench"; python tools/adapter_bench.py; echo "== train_bench"; python tools/train_bench.py ) 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_tool_benches_$TAG.txt
+( echo "== small_bench"; python tools/small_bench.py; echo "== encoder_bench"; python tools/encoder_bench.py; echo "== adapter_bench"; python tools/adapter_bench.py; echo "== train_bench"; python tools/train_bench.py; echo "== conv_strip_bench"; python tools/conv_strip_bench.py ) 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_tool_benches_$TAG.txt
 tail -12 gpurun_out/r06_tool_benches_$TAG.txt
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-extra > gpurun_out/r06_bench_torchrun_$TAG.json 2> gpurun_out/r06_bench_torchrun_$TAG.err; python -c "import json; d=json.load(open('gpurun_out/r06_bench_torchrun_$TAG.json')); print('TORCHRUN', round(d['value']), d['rccl_world_size'], d['self_check'])"
 # ---- PMC passes LAST, same tree
