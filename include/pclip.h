@@ -233,8 +233,8 @@ int pclip_gemm_bn_res_f16(const void* A, int lda, const void* B, int ldb, void* 
                           const float* scale, const float* shift, const void* residual, pclip_stream_t stream);
 
 /* 3x3 convolution, stride 1, padding 1, on NHWC fp16 activations x [B, H, W, Cin] + eval BatchNorm (+ReLU), as an implicit
- * GEMM: the im2col matrix is never materialised (each K-tile is gathered by LDS-DMA; taps outside the image read
- * `zero_line`, >= 128 zero bytes in device memory supplied by the caller).  w [Cout, 3, 3, Cin] fp16; y [B*H*W, Cout].
+ * GEMM: the im2col matrix is never materialised (each K-tile is gathered by buffer LDS-DMA; taps outside the image are out-of-range
+ * offsets, i.e. zeros — `zero_line`, >= 128 zero bytes in device memory, is still required non-null for ABI stability but no longer read).  w [Cout, 3, 3, Cin] fp16; y [B*H*W, Cout].
  * Cin % 64 == 0, or Cin = 8 / 16 / 32 (the stem, clip/model.py:138-142) with every row of w zero-padded to a multiple of 64
  * halves; Cout % 64 == 0, or Cout = 32.  Identical to pclip_im2col3x3_f16 + pclip_gemm_bn_f16 (clip/model.py:20-22, 45-46). */
 int pclip_conv3x3_bn_f16(const void* x, const void* w, const void* zero_line, int B, int H, int W, int Cin, int Cout,
