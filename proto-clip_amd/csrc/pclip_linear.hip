@@ -61,21 +61,29 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
     // The bias enters as the INITIAL VALUE of the accumulators (fp32 copy of the fp16 bias: r16(bias + sum) instead of
     // r16(sum + bias), same value up to fp32 summation order), so the epilogue has no bias pass.  Its strip is copied one
     // tile ahead (double-buffered); every wave copies the same BN values: uniform vmcnt bookkeeping.
+    const pgemm::rsrc_t rs_bias = pgemm::make_rsrc(bias, 0x7fffffffu), rs_scale = pgemm::make_rsrc(scale, 0x7fffffffu), rs_shift = pgemm::make_rsrc(shift, 0x7fffffffu);
+    (void)rs_bias; (void)rs_scale; (void)rs_shift;
     auto copy_bias = [&](int t, int par) {
         int tm_, tn;
         decomp(t, tm_, tn);
-        if (lane < C::BN / 8)
-            __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(bias + tn * C::BN + lane * 8), (pgemm::lds_ptr_t)(bias_lds + par * C::BN), 16, 0, 0);
+        (void)tn;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (lane < C::BN / 8)      // (buffer LDS-DMA like the tiles: a FLAT-encoded global_load_lds in flight turns every LDS wait of the first K-tile into lgkmcnt(0): pclip_gemm.h make_rsrc)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_bias, (pgemm::lds_ptr_t)(bias_lds + par * C::BN), 16, (tn * C::BN + lane * 8) * 2, 0, 0, 0);
+#endif
     };
     // eval-mode BatchNorm (+ReLU) of the ResNet tower (clip/model.py:43-52) as the epilogue of the convolution's GEMM: the
     // per-column scale / shift strips travel like the bias strip, one tile ahead
     auto copy_affine = [&](int t, int par) {
         int tm_, tn;
         decomp(t, tm_, tn);
+        (void)tn;
+#if defined(__HIP_DEVICE_COMPILE__)
         if (lane < C::BN / 4) {
-            __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(scale + tn * C::BN + lane * 4), (pgemm::lds_ptr_t)(affine_lds + par * 2 * C::BN), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(shift + tn * C::BN + lane * 4), (pgemm::lds_ptr_t)(affine_lds + par * 2 * C::BN + C::BN), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_scale, (pgemm::lds_ptr_t)(affine_lds + par * 2 * C::BN), 16, (tn * C::BN + lane * 4) * 4, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_shift, (pgemm::lds_ptr_t)(affine_lds + par * 2 * C::BN + C::BN), 16, (tn * C::BN + lane * 4) * 4, 0, 0, 0);
         }
+#endif
     };
     if (HAS_BIAS || AFFINE) {
         if (AFFINE) copy_affine(tile, 0); else copy_bias(tile, 0);
@@ -239,12 +247,17 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv3x3_fast_kernel(const half
     const int nt = (9 * Cin + pgemm::BK - 1) / pgemm::BK, ldb = nt * pgemm::BK;    // w rows are zero-padded to the K-tile (Cin < 64)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave % C::WN;
     pgemm::ConvGather<C> ga(x, H, W, Cin, M);
+    const pgemm::rsrc_t rs_scale = pgemm::make_rsrc(scale, 0x7fffffffu), rs_shift = pgemm::make_rsrc(shift, 0x7fffffffu);
+    (void)rs_scale; (void)rs_shift;
     auto copy_affine = [&](int t, int par) {
         const int tn = t - (t / tiles_n) * tiles_n;
+        (void)tn;
+#if defined(__HIP_DEVICE_COMPILE__)
         if (lane < C::BN / 4) {
-            __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(scale + tn * C::BN + lane * 4), (pgemm::lds_ptr_t)(affine_lds + par * 2 * C::BN), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(shift + tn * C::BN + lane * 4), (pgemm::lds_ptr_t)(affine_lds + par * 2 * C::BN + C::BN), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_scale, (pgemm::lds_ptr_t)(affine_lds + par * 2 * C::BN), 16, (tn * C::BN + lane * 4) * 4, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_shift, (pgemm::lds_ptr_t)(affine_lds + par * 2 * C::BN + C::BN), 16, (tn * C::BN + lane * 4) * 4, 0, 0, 0);
         }
+#endif
     };
     auto stage0 = [&](int t, int pbuf) {                       // K-tile 0 of tile t into buffer pbuf (ga prepared for t)
         const int tm = t / tiles_n, tn = t - tm * tiles_n;
