@@ -129,8 +129,13 @@ __global__ __launch_bounds__(512, 2) void sqdist_big_kernel(const half_t* __rest
             int qi = m0 + 4 * lane, zi4 = n0 + 4 * lane;
             qi = qi + 4 <= Q ? qi : Q - 4;
             zi4 = zi4 + 4 <= N ? zi4 : N - 4;
-            __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(q_sq + qi), (pgemm::lds_ptr_t)qn, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((pgemm::gbl_ptr_t)(z_sq + zi4), (pgemm::lds_ptr_t)zn, 16, 0, 0);
+            // (buffer LDS-DMA, like the tiles: behind a FLAT-encoded global_load_lds hipcc answers every LDS wait of the first K-tile with lgkmcnt(0): pclip_gemm.h make_rsrc)
+            const pgemm::rsrc_t rq = pgemm::make_rsrc(q_sq, 0x7fffffffu), rz = pgemm::make_rsrc(z_sq, 0x7fffffffu);
+            (void)rq; (void)rz; (void)qi; (void)zi4;
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (pgemm::lds_ptr_t)qn, 16, qi * 4, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (pgemm::lds_ptr_t)zn, 16, zi4 * 4, 0, 0, 0);
+#endif
         }
         pgemm::Acc<C> acc;
         pgemm::mainloop<C, NSTORE + 2>(q, D, z, D, Q, N, D, m0, n0, smem, acc, p, prev_full);

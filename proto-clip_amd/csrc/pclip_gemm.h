@@ -551,21 +551,28 @@ struct ConvGather {
     int H, W, Cin, M;
     rsrc_t rs;                                             // over the M x Cin activations: a tap outside the image takes an offset beyond it (zeros)
     int pix[NR], yx[NR];
+    int off[NR], taps[NR];                                 // Cin % 64 == 0: byte offset of the lane's chunk of pixel i (swizzled), 9-bit mask of the taps inside the image
     __device__ __forceinline__ ConvGather(const half_t* x_, int H_, int W_, int Cin_, int M_)
         : x(x_), H(H_), W(W_), Cin(Cin_), M(M_), rs(make_rsrc(x_, (unsigned)M_ * (unsigned)Cin_ * 2u)) {}
     __device__ __forceinline__ void prepare(int m0) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            int m = m0 + wave * (C::BM / C::NWAVES) + i * 8 + (lane >> 3);
+            const int r = wave * (C::BM / C::NWAVES) + i * 8 + (lane >> 3);
+            int m = m0 + r;
             m = m < M ? m : M - 1;                          // rows beyond M are never stored
             const int b = m / (H * W), rem = m - b * H * W, y = rem / W, xx = rem - y * W;
             pix[i] = m;                                     // (b*H + y)*W + x == m for stride 1 / pad 1
             yx[i] = (y << 16) | xx;
+            off[i] = (m * Cin + (((lane & 7) ^ swz_key(r)) << 3)) * 2;
+            const int rows = (y > 0 ? 1 : 0) | 2 | (y + 1 < H ? 4 : 0), cols = (xx > 0 ? 1 : 0) | 2 | (xx + 1 < W ? 4 : 0);
+            taps[i] = ((rows & 1) ? cols : 0) | ((rows & 2) ? cols << 3 : 0) | ((rows & 4) ? cols << 6 : 0);
         }
     }
-    __device__ __forceinline__ void stage(int t, char* dst) const {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // K-tile t into `dst` (the A image of a stage buffer); `wave` wave-uniform (readfirstlane): the LDS destination travels in M0
+    __device__ __forceinline__ void stage(int t, char* dst, int wave) const {
+        const int lane = threadIdx.x & 63;
+        (void)lane;
         if (Cin < BK) {
             // Cin = 8 / 16 / 32 (the ResNet stem): a K-tile spans 64 / Cin taps, so the tap belongs to the 16-byte chunk, not to the
             // row; taps >= 9 (K padded to the K-tile, zero weights there) read zeros
@@ -584,19 +591,36 @@ struct ConvGather {
             }
             return;
         }
+        // Cin % 64 == 0: the tap and the channel block are wave-uniform — one scalar offset per K-tile, per piece a mask test and an add
         const int k0 = t * BK, tap = k0 / Cin, c0 = k0 - tap * Cin, dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int tapoff = ((dy * W + dx) * Cin + c0) * 2;
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const int r = wave * (C::BM / C::NWAVES) + i * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ swz_key(r);
-            const int y = (yx[i] >> 16) + dy, xx = (yx[i] & 0xffff) + dx;
-            const bool in = (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
-            const unsigned voff = in ? (unsigned)((pix[i] + dy * W + dx) * Cin + c0 + c * 8) * 2u : 0xfffffff0u;
+            const unsigned voff = (taps[i] >> tap) & 1 ? (unsigned)(off[i] + tapoff) : 0xfffffff0u;
             (void)voff;
 #if defined(__HIP_DEVICE_COMPILE__)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + (wave * (C::BM / C::NWAVES) + i * 8) * ROW_BYTES), 16, (int)voff, 0, 0, 0);
 #endif
         }
+    }
+    __device__ __forceinline__ void stage(int t, char* dst) const { stage(t, dst, (int)(threadIdx.x >> 6)); }
+};
+
+// The convolution's operand pair for mainloop_sr (the software-pipelined K-loop with the staggered refill): A = the gather above, B = the weights [Cout, 9 Cin].
+template <class C>
+struct ConvPair {
+    static constexpr bool ROLES = false;
+    static constexpr int NA = ConvGather<C>::NR, NB = TileSrc<C::BN, C::NWAVES>::NL;
+    struct AOp {
+        ConvGather<C> g;
+        template <int AUX = 0>
+        __device__ __forceinline__ void stage(int k_bytes, char* dst, int wave) const { g.stage(k_bytes / (BK * 2), dst, wave); }
+    } a;
+    TileSrc<C::BN, C::NWAVES> b;
+    __device__ __forceinline__ ConvPair(const half_t* x, int H, int W, int Cin, int M) : a{ConvGather<C>(x, H, W, Cin, M)} {}
+    __device__ __forceinline__ void stage(int t, char* stage_buf, int wave) const {
+        a.g.stage(t, stage_buf, wave);
+        b.template stage<0>(t * (BK * 2), stage_buf + C::A_BYTES, wave);
     }
 };
 

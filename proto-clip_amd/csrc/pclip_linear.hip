@@ -233,6 +233,8 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
 // ---- 3x3 convolution (stride 1, pad 1, NHWC) + eval BatchNorm (+ReLU) as an implicit GEMM -----------------------------------
 // Same persistent structure as linear_fast_kernel; the A operand is gathered by pgemm::ConvGather instead of read from an
 // im2col matrix (clip/model.py:20-22, 45-46: conv2 / bn2 / relu of every bottleneck).  w is [Cout, ky, kx, Cin].
+// K-loop: the software-pipelined loop of the linears (pgemm::mainloop_sr: fragments a group ahead, K-tile t + 2 requested in two halves during iteration t) over
+// pgemm::ConvPair (round 6; before: mainloop_g's read-everything-then-multiply loop — the same k order, the same bits, RN50 +2 % in a same-box A/B).
 template <class C, int ACT>
 __global__ __launch_bounds__(C::NTHREADS, 2) void conv3x3_fast_kernel(const half_t* __restrict__ x, const half_t* __restrict__ zero,
                                                                       const half_t* __restrict__ w, int H, int W, int Cin, int M,
@@ -245,8 +247,9 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv3x3_fast_kernel(const half
     int tile = pgemm::xcd_remap(blockIdx.x, G);
     if (tile >= ntiles) return;
     const int nt = (9 * Cin + pgemm::BK - 1) / pgemm::BK, ldb = nt * pgemm::BK;    // w rows are zero-padded to the K-tile (Cin < 64)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave % C::WN;
-    pgemm::ConvGather<C> ga(x, H, W, Cin, M);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave % C::WN;
+    pgemm::ConvPair<C> cp(x, H, W, Cin, M);
+    pgemm::ConvGather<C>& ga = cp.a.g;
     const pgemm::rsrc_t rs_scale = pgemm::make_rsrc(scale, 0x7fffffffu), rs_shift = pgemm::make_rsrc(shift, 0x7fffffffu);
     (void)rs_scale; (void)rs_shift;
     auto copy_affine = [&](int t, int par) {
@@ -262,8 +265,8 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv3x3_fast_kernel(const half
     auto stage0 = [&](int t, int pbuf) {                       // K-tile 0 of tile t into buffer pbuf (ga prepared for t)
         const int tm = t / tiles_n, tn = t - tm * tiles_n;
         char* a = smem + pbuf * C::STAGE_BYTES;
-        ga.stage(0, a);
-        pgemm::stage_tile<C::BN, C::NWAVES>(w, ldb, tn * C::BN, N, 0, a + C::A_BYTES, wave, lane);
+        cp.b.prepare(w, ldb, tn * C::BN, N, wave, lane);
+        cp.stage(0, a, wave);
     };
     copy_affine(tile, 0);
     pgemm::wait_vm<0>();
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv3x3_fast_kernel(const half
         const bool full = m0 + C::BM <= M;
         pgemm::Acc<C> acc;
         copy_affine(tile + G < ntiles ? tile + G : tile, parity ^ 1);
-        pgemm::mainloop_g<C, YOUNGER, true, true>([&](int t, char* dst) { ga.stage(t, dst); }, w, ldb, N, nt, n0, smem, acc, p, prev_full);
+        pgemm::mainloop_sr<C, YOUNGER, true, pgemm::ConvPair<C>>(cp, nt, smem, acc, p, prev_full, wave, lane);
         const int next = tile + G;
         if (next < ntiles) {                                  // buffer p is free: prefetch the next tile's K-tile 0
             ga.prepare((next / tiles_n) * C::BM);
