@@ -713,6 +713,27 @@ def test_conv3x3_strip_kernel(ops, B, H, W, Cin, Cout, relu):
         assert err.max().item() <= bound and err[m.reshape(-1)].max().item() <= bound, (err.max().item(), bound)
 
 
+@pytest.mark.parametrize("strip", [True, False])
+def test_conv3x3_batches_beyond_32_bit_offsets_go_in_slices(ops, strip):
+    """The convolution kernels address their input through buffer descriptors with 32-bit offsets: a batch of more than 2^31 bytes (2 700 stem-sized images) is cut
+    into slices of whole images by the launcher — the result of every image must be the bits it has in a small batch (first, middle around the cut, last images)."""
+    B, H, W, Cin, Cout = 2700, 112, 112, 32, 32
+    assert B * H * W * Cin * 2 > 2 ** 31
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.empty(B * H * W, Cin, dtype=torch.float16, device="cuda")
+    x.view(-1)[:] = (torch.randn(64 * H * W * Cin, device="cuda", generator=g) * 0.7).half().repeat(B // 64 + 1)[: x.numel()]
+    w = (torch.randn(Cout, 320, device="cuda", generator=g) * 288 ** -0.5).half()
+    w[:, 288:] = 0
+    sc, sh = 1 + 0.3 * torch.randn(Cout, device="cuda", generator=g), 0.2 * torch.randn(Cout, device="cuda", generator=g)
+    with ops.conv_strip(strip):
+        y = ops.conv3x3_bn(x, w, sc, sh, B, H, W, Cin, relu=True).view(B, H * W, Cout)
+        cut = (2 ** 31) // (H * W * Cin * 2)
+        for b0, n in ((0, 3), (cut - 2, 4), (B - 3, 3)):
+            part = ops.conv3x3_bn(x.view(B, -1)[b0:b0 + n].reshape(n * H * W, Cin), w, sc, sh, n, H, W, Cin, relu=True).view(n, H * W, Cout)
+            assert torch.equal(y[b0:b0 + n], part), (strip, b0)
+    del x, y
+
+
 @pytest.mark.parametrize("B,H,W", [(3, 112, 112), (40, 8, 56), (70, 112, 112), (5, 16, 112)])
 def test_conv3x3_bn_relu_avgpool_in_one_launch(ops, B, H, W):
     """The stem's tail — conv3 / bn3 / relu / AvgPool2d(2), clip/model.py:104-105, 142-143 of the reference — in one launch (the strip kernel's pooling epilogue) must
