@@ -852,6 +852,12 @@ extern "C" int pclip_gemm_splitk_f16(const void* A, int lda, const void* B, int 
     return pclip_check_launch("gemm_f16 (split-K)");
 }
 
+// tuning override of the BatchNorm-epilogue GEMMs (A/B runs): PCLIP_GEMM_BN_CFG = 0 small (128 x 128, two workgroups per CU), 1 wide, 2 big, 4 narrow; default: the cost model
+static int bn_forced_cfg() {
+    static const int f = getenv("PCLIP_GEMM_BN_CFG") ? atoi(getenv("PCLIP_GEMM_BN_CFG")) : -1;
+    return f;
+}
+
 extern "C" int pclip_gemm_bn_res_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                                      const float* scale, const float* shift, const void* residual, pclip_stream_t stream) {
     PCLIP_REQUIRE(A && B && C && scale && shift && residual, "pclip_gemm_bn_res_f16: null pointer");
@@ -863,7 +869,7 @@ extern "C" int pclip_gemm_bn_res_f16(const void* A, int lda, const void* B, int 
     LinearEpi epi{nullptr, (const half_t*)residual, (half_t*)C, ldc, 5, scale, shift};
     int cus = pclip_device_cus();
     if (cus <= 0) cus = 256;
-    return gemm_dispatch((const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, cus, -1, true, (hipStream_t)stream);
+    return gemm_dispatch((const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, cus, bn_forced_cfg(), true, (hipStream_t)stream);
 }
 
 extern "C" int pclip_gemm_bn_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
@@ -877,7 +883,7 @@ extern "C" int pclip_gemm_bn_f16(const void* A, int lda, const void* B, int ldb,
     int cus = pclip_device_cus();
     if (cus <= 0) cus = 256;
     const bool strips_ok = N % 4 == 0 && ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0;
-    return gemm_dispatch((const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, cus, strips_ok ? -1 : -2, true, (hipStream_t)stream);
+    return gemm_dispatch((const half_t*)A, lda, (const half_t*)B, ldb, M, N, K, epi, cus, strips_ok ? bn_forced_cfg() : -2, true, (hipStream_t)stream);
 }
 
 namespace {
