@@ -158,14 +158,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_strip_kernel(const half_t* __r
     // LDS-DMA through a BUFFER descriptor over the whole input (not global_load_lds): out-of-image pieces take an offset beyond the buffer and the hardware writes
     // zeros — the padding needs no zero line — and hipcc keeps counting its LDS waits (lgkmcnt(N)) while the DMA is in flight: with a FLAT-encoded LDS load pending it
     // falls back to lgkmcnt(0) before every group of MFMAs, i.e. it exposes the latency of the fragment reads it had just issued ahead.
-    pgemm::rsrc_t rs;
-#if defined(__HIP_DEVICE_COMPILE__)
-    {
-        const uint64_t addr = (uint64_t)x;
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)addr), hi = __builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
-        rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, (int)((unsigned)ntiles * (unsigned)(ST_ROWS * ST_COLS * PXB)), 0x00020000);
-    }
-#endif
+    const pgemm::rsrc_t rs = pgemm::make_rsrc(x, (unsigned)ntiles * (unsigned)(ST_ROWS * ST_COLS * PXB));
     auto issue = [&](int t, int pbuf) {
         const int img = t / tpi, rem = t - img * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
         const int tflags = (ty == 0 ? 1 : 0) | (ty == tiles_y - 1 ? 2 : 0) | (tx == 0 ? 4 : 0) | (tx == tiles_x - 1 ? 8 : 0);

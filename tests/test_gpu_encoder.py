@@ -667,7 +667,8 @@ def test_conv3x3_implicit_gemm_equals_im2col_path(ops, B, H, W, Cin, Cout, relu)
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,relu", [(3, 112, 112, 32, 32, True), (2, 112, 112, 32, 64, True), (6, 56, 56, 64, 64, True), (40, 8, 56, 64, 64, False),
-                                                 (9, 16, 56, 32, 64, True), (2, 56, 112, 64, 32, True), (300, 56, 56, 64, 64, True), (70, 112, 112, 32, 32, False)])
+                                                 (9, 16, 56, 32, 64, True), (2, 56, 112, 64, 32, True), (300, 56, 56, 64, 64, True), (70, 112, 112, 32, 32, False),
+                                                 (1, 24, 168, 64, 64, True), (1, 8, 56, 32, 32, True), (7, 40, 168, 32, 64, False), (3, 72, 224, 64, 32, True)])
 def test_conv3x3_strip_kernel(ops, B, H, W, Cin, Cout, relu):
     """The narrow 3x3 convolutions of the ModifiedResNet tower (stem conv2 / conv3, layer1 conv2; clip/model.py:100-108, 20-22 of the reference) through
     csrc/pclip_conv_strip.hip — weights in registers, the tile's input block with its halo once in LDS, zero padding by out-of-range buffer loads — against
