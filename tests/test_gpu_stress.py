@@ -123,8 +123,9 @@ def test_conv_strip_under_jitter(ops, slib, B, H, W, Cin, Cout):
     x = (torch.randn(B * H * W, Cin, device="cuda", generator=g) * 0.7).half()
     w = (torch.randn(Cout, (9 * Cin + 63) // 64 * 64, device="cuda", generator=g) * (9 * Cin) ** -0.5).half()
     sc, sh = 1 + 0.3 * torch.randn(Cout, device="cuda", generator=g), 0.2 * torch.randn(Cout, device="cuda", generator=g)
-    assert ops.conv_strip_applies(B, H, W, Cin, Cout)
-    ref = ops.conv3x3_bn(x, w, sc, sh, B, H, W, Cin, relu=True)
+    with ops.conv_strip(True):
+        assert ops.conv_strip_applies(B, H, W, Cin, Cout)
+        ref = ops.conv3x3_bn(x, w, sc, sh, B, H, W, Cin, relu=True)
     z = torch.zeros(64, dtype=torch.float16, device="cuda")
     slib.pclip_conv3x3_strip_config(1)
     for rep in range(3):
