@@ -279,7 +279,9 @@ class ModifiedResNet(nn.Module):
         # images per pass: small passes are launch-bound and leave the tail tiles of every convolution idle — 1024 images in passes of 128 / 256 / 512 / 1024:
         # RN50 33.4 / 37.0 / 39.6 / 41.6 k img/s, RN101 22.5 / 25.7 / 27.0 / 28.5 k (profiles/r06_rn_chunk_probe.txt); the widest activation of a 1024-image pass
         # (layer1's 56 x 56 x 256 fp16) is 1.6 GB.  Same bits for every pass size (tests/test_gpu_encoder.py).
-        self.chunk = int(os.environ.get("PCLIP_RN_CHUNK", "1024"))
+        # (Widths whose narrow convolutions go through a materialised im2col matrix — RN50x4 / x16: 40 / 48 stem channels — keep passes of 256: the matrix of a
+        # 1024-image pass would be 16 - 34 GB.)
+        self.chunk = int(os.environ.get("PCLIP_RN_CHUNK", "1024" if width // 2 in (32, 64) else "256"))
 
     # -- helpers ---------------------------------------------------------------------------------------------------
     def _bn_affine(self, key, bn):
