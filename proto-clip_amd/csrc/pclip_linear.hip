@@ -236,7 +236,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void linear_fast_kernel(const half_
 // K-loop: the software-pipelined loop of the linears (pgemm::mainloop_sr: fragments a group ahead, K-tile t + 2 requested in two halves during iteration t) over
 // pgemm::ConvPair (round 6; before: mainloop_g's read-everything-then-multiply loop — the same k order, the same bits, RN50 +2 % in a same-box A/B).
 template <class C, int ACT>
-__global__ __launch_bounds__(C::NTHREADS, 2) void conv3x3_fast_kernel(const half_t* __restrict__ x, const half_t* __restrict__ zero,
+__global__ __launch_bounds__(C::NTHREADS, 2) void conv3x3_fast_kernel(const half_t* __restrict__ x,
                                                                       const half_t* __restrict__ w, int H, int W, int Cin, int M,
                                                                       int N, const float* __restrict__ scale,
                                                                       const float* __restrict__ shift, half_t* __restrict__ Cout,
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void linear_small_kernel(con
 // The implicit-GEMM 3x3 convolution (conv3x3_fast_kernel) for launches with no more tiles than CUs: the same gather, the ring
 // K-loop, the same BatchNorm (+ReLU) epilogue — bit-identical to the persistent kernel.
 template <int ACT>
-__global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void conv3x3_small_kernel(const half_t* __restrict__ x, const half_t* __restrict__ zero,
+__global__ __launch_bounds__(CfgSplit::NTHREADS, 1) void conv3x3_small_kernel(const half_t* __restrict__ x,
                                                                             const half_t* __restrict__ w, int H, int W, int Cin, int M,
                                                                             int N, const float* __restrict__ scale,
                                                                             const float* __restrict__ shift, half_t* __restrict__ Cout,
@@ -888,7 +888,7 @@ extern "C" int pclip_gemm_bn_f16(const void* A, int lda, const void* B, int ldb,
 
 namespace {
 template <class C, int ACT>
-int launch_conv2(const void* x, const void* zero, const void* w, int B, int H, int W, int Cin, int Cout, const float* scale,
+int launch_conv2(const void* x, const void* w, int B, int H, int W, int Cin, int Cout, const float* scale,
                  const float* shift, void* y, int slots, hipStream_t s) {
     static DevOnce attr;
     constexpr int LDS = C::LDS_BYTES + 2 * 2 * C::BN * 4;
@@ -901,14 +901,14 @@ int launch_conv2(const void* x, const void* zero, const void* w, int B, int H, i
     }
     const int M = B * H * W, tiles_m = ceil_div(M, C::BM), tiles_n = Cout / C::BN, ntiles = tiles_m * tiles_n;
     conv3x3_fast_kernel<C, ACT><<<ntiles < slots ? ntiles : slots, C::NTHREADS, LDS, s>>>(
-        (const half_t*)x, (const half_t*)zero, (const half_t*)w, H, W, Cin, M, Cout, scale, shift, (half_t*)y, tiles_n, ntiles);
+        (const half_t*)x, (const half_t*)w, H, W, Cin, M, Cout, scale, shift, (half_t*)y, tiles_n, ntiles);
     return pclip_check_launch("conv3x3_bn");
 }
 template <class C>
-int launch_conv(const void* x, const void* zero, const void* w, int B, int H, int W, int Cin, int Cout, const float* scale,
+int launch_conv(const void* x, const void* w, int B, int H, int W, int Cin, int Cout, const float* scale,
                 const float* shift, int relu, void* y, int slots, hipStream_t s) {
-    return relu ? launch_conv2<C, 3>(x, zero, w, B, H, W, Cin, Cout, scale, shift, y, slots, s)
-                : launch_conv2<C, 2>(x, zero, w, B, H, W, Cin, Cout, scale, shift, y, slots, s);
+    return relu ? launch_conv2<C, 3>(x, w, B, H, W, Cin, Cout, scale, shift, y, slots, s)
+                : launch_conv2<C, 2>(x, w, B, H, W, Cin, Cout, scale, shift, y, slots, s);
 }
 }  // namespace
 
@@ -946,24 +946,24 @@ extern "C" int pclip_conv3x3_bn_f16(const void* x, const void* w, const void* ze
     if (pclip_conv3x3_strip_applies(B, H, W, Cin, Cout))                        // narrow layers at 56 x 56 / 112 x 112: weights in registers, halo blocks in LDS
         return pclip_conv3x3_strip_launch(x, w, B, H, W, Cin, Cout, scale, shift, relu, y, cus, s, 1);
     if (Cout == 32)                                                             // the stem's 32 -> 32 convolution: 256 x 32 tiles
-        return launch_conv<CfgThin>(x, zero_line, w, B, H, W, Cin, Cout, scale, shift, relu, y, 2 * cus, s);
+        return launch_conv<CfgThin>(x, w, B, H, W, Cin, Cout, scale, shift, relu, y, 2 * cus, s);
     static const bool small_on = !(getenv("PCLIP_GEMM_SMALL") && getenv("PCLIP_GEMM_SMALL")[0] == '0');
     if (small_on && small_applies(B * H * W, Cout, cus)) {                     // a request of a few images: the ring kernel
         if (int e = small_attr()) return e;
         const int tiles_n = Cout / CfgSplit::BN, grid = ceil_div(B * H * W, CfgSplit::BM) * tiles_n;
         if (relu)
-            conv3x3_small_kernel<3><<<grid, CfgSplit::NTHREADS, kSmallLds, s>>>((const half_t*)x, (const half_t*)zero_line, (const half_t*)w, H, W, Cin,
+            conv3x3_small_kernel<3><<<grid, CfgSplit::NTHREADS, kSmallLds, s>>>((const half_t*)x, (const half_t*)w, H, W, Cin,
                                                                            B * H * W, Cout, scale, shift, (half_t*)y, tiles_n);
         else
-            conv3x3_small_kernel<2><<<grid, CfgSplit::NTHREADS, kSmallLds, s>>>((const half_t*)x, (const half_t*)zero_line, (const half_t*)w, H, W, Cin,
+            conv3x3_small_kernel<2><<<grid, CfgSplit::NTHREADS, kSmallLds, s>>>((const half_t*)x, (const half_t*)w, H, W, Cin,
                                                                            B * H * W, Cout, scale, shift, (half_t*)y, tiles_n);
         return pclip_check_launch("conv3x3_bn (small M)");
     }
     double cost;
     int pick = best_cfg((long)B * H * W, Cout, cus, &cost);
     if (pick == 4 || pick < 0) pick = 3;                        // the 4-wave thin tile has no gather variant; Cout % 64 == 0 always fits 256x64
-    if (pick == 2) return launch_conv<CfgBig>(x, zero_line, w, B, H, W, Cin, Cout, scale, shift, relu, y, cus, s);
-    if (pick == 1) return launch_conv<CfgWide>(x, zero_line, w, B, H, W, Cin, Cout, scale, shift, relu, y, cus, s);
-    if (pick == 0) return launch_conv<CfgSmall>(x, zero_line, w, B, H, W, Cin, Cout, scale, shift, relu, y, 2 * cus, s);
-    return launch_conv<CfgNarrow>(x, zero_line, w, B, H, W, Cin, Cout, scale, shift, relu, y, cus, s);
+    if (pick == 2) return launch_conv<CfgBig>(x, w, B, H, W, Cin, Cout, scale, shift, relu, y, cus, s);
+    if (pick == 1) return launch_conv<CfgWide>(x, w, B, H, W, Cin, Cout, scale, shift, relu, y, cus, s);
+    if (pick == 0) return launch_conv<CfgSmall>(x, w, B, H, W, Cin, Cout, scale, shift, relu, y, 2 * cus, s);
+    return launch_conv<CfgNarrow>(x, w, B, H, W, Cin, Cout, scale, shift, relu, y, cus, s);
 }
